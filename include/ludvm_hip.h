@@ -1,0 +1,163 @@
+/*
+ * ludvm_hip.h -- C ABI of libludvm_hip.so, the MI355X (gfx950) all-pairs vortex-induction engine
+ * that sits behind the LUDVM Python class.
+ *
+ * The reference (jcatalang/LUDVM) has no FFI: its "operator boundary" for this path is the Python
+ * method surface of class LUDVM.  Each entry point below cites the reference code it replaces
+ * (file:line into LUDVM.py).  The Python host (ludvm_amd/_ffi.py, ctypes) binds exactly these
+ * symbols; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = LUDVM_OK, otherwise one of LUDVM_E_*; nothing
+ *     throws across the ABI and nothing calls exit();
+ *   - ludvm_last_error(ctx) returns a human-readable message for the last failure on that context
+ *     (pointer owned by the context, valid until the next call on it);
+ *   - plain pointers and sizes only; "host" pointers are ordinary process memory, "dev" pointers
+ *     are HIP device memory on the context's device (e.g. a torch tensor's data_ptr());
+ *   - host-pointer entry points are synchronous (results are in the output arrays on return);
+ *     dev-pointer entry points are asynchronous on the context's stream (ludvm_set_stream /
+ *     ludvm_synchronize);
+ *   - a context is not thread-safe: one host thread at a time per context (the reference is
+ *     single-threaded); distinct contexts are independent;
+ *   - coordinates follow the reference: x (horizontal), z (vertical), circulation Gamma, and the
+ *     Vatistas core radius v_core (= 1.3*dt*Uinf, LUDVM.py:259-260); v_core = 0 means point
+ *     vortices (the reference's `viscous != True` branch, LUDVM.py:562-563), for which a
+ *     coincident source/target pair yields NaN exactly as the reference's 0/0 does.
+ */
+#ifndef LUDVM_HIP_H
+#define LUDVM_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LUDVM_ABI_VERSION 1
+
+enum {
+  LUDVM_OK = 0,
+  LUDVM_E_ARG = 1,      /* bad argument (null pointer, range outside the wake, ...) */
+  LUDVM_E_HIP = 2,      /* a HIP runtime call failed; message has the HIP error string */
+  LUDVM_E_NOMEM = 3,    /* device or host allocation failed */
+  LUDVM_E_NODEVICE = 4, /* no usable gfx950 device */
+  LUDVM_E_STATE = 5     /* call not valid in the current state (e.g. wake not reserved) */
+};
+
+/* Arithmetic the pair sum is evaluated in. */
+enum {
+  LUDVM_PREC_F32 = 0,   /* fp32 positions and arithmetic (headline kernel) */
+  LUDVM_PREC_F32X2 = 1, /* positions as hi+lo fp32 pairs: dx = (xh_p - xh_w) + (xl_p - xl_w), rest fp32.
+                           Removes the cancellation error of |x| ~ 50 vs spacing ~ 1e-3. */
+  LUDVM_PREC_F64 = 2    /* fp64 throughout (parity / debug mode, and the small chord-target calls) */
+};
+
+typedef struct ludvm_ctx ludvm_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+
+int ludvm_abi_version(void);
+/* Create a context bound to HIP device `device_ordinal` (must be a gfx950 part unless the
+ * environment variable LUDVM_ALLOW_ANY_ARCH=1 is set).  Owns one stream and its workspaces. */
+int ludvm_create(int device_ordinal, ludvm_ctx** out);
+int ludvm_destroy(ludvm_ctx* ctx);
+const char* ludvm_last_error(const ludvm_ctx* ctx);
+/* Device facts for the roofline: CU count, max shader clock (kHz), HBM bytes, name (NUL-terminated). */
+int ludvm_device_info(ludvm_ctx* ctx, int* cu_count, int* clock_khz, long long* hbm_bytes, char* name,
+                      int name_len);
+/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) for all
+ * subsequent launches; NULL restores the context's own stream. */
+int ludvm_set_stream(ludvm_ctx* ctx, void* hip_stream);
+int ludvm_synchronize(ludvm_ctx* ctx);
+/* Launch shape knobs (0 keeps the built-in heuristic): targets per lane {1,2,4}, source splits. */
+int ludvm_set_tuning(ludvm_ctx* ctx, int targets_per_lane, int source_splits);
+
+/* ---- stateless pair sum: backs LUDVM.induced_velocity (LUDVM.py:549-570) ------------------ */
+
+/* u[p] =  sum_w g[w]*(zt[p]-zs[w]) / (2 pi sqrt(r^4 + vcore^4))
+ * w[p] = -sum_w g[w]*(xt[p]-xs[w]) / (2 pi sqrt(r^4 + vcore^4)),  r^2 = dx^2+dz^2.
+ * Host float64 in/out (what the reference passes and returns); `precision` selects the device
+ * arithmetic.  ns == 0 or nt == 0 is valid (u, w zero-filled / untouched). */
+int ludvm_induce_f64(ludvm_ctx* ctx, const double* xs, const double* zs, const double* gs, size_t ns,
+                     const double* xt, const double* zt, size_t nt, double vcore, int precision,
+                     double* u, double* w);
+/* Same with host float32 buffers (always LUDVM_PREC_F32 arithmetic). */
+int ludvm_induce_f32(ludvm_ctx* ctx, const float* xs, const float* zs, const float* gs, size_t ns,
+                     const float* xt, const float* zt, size_t nt, float vcore, float* u, float* w);
+/* Device-resident fp32 SoA (torch tensors): asynchronous on the context stream.  Used by the
+ * benchmark, the multi-GPU shard step and the flow-field path. */
+int ludvm_induce_dev_f32(ludvm_ctx* ctx, const float* d_xs, const float* d_zs, const float* d_gs, size_t ns,
+                         const float* d_xt, const float* d_zt, size_t nt, float vcore, float* d_u,
+                         float* d_w);
+/* One explicit-Euler advection step on device fp32 SoA (LUDVM.py:1105-1127 with the wake as both
+ * source and target set): (u,w) induced by all ns sources on targets [t_first, t_first+nt) of the
+ * same arrays, then x_out[i] = x[t_first+i] + dt*u[i], z_out likewise.  x_out/z_out must not alias
+ * the source arrays (the multi-GPU step all-gathers them into the next source buffer). */
+int ludvm_advect_dev_f32(ludvm_ctx* ctx, const float* d_xs, const float* d_zs, const float* d_gs, size_t ns,
+                         size_t t_first, size_t nt, float vcore, float dt, float* d_x_out, float* d_z_out);
+
+/* ---- resident wake: backs LUDVM.time_loop (LUDVM.py:597-1171) ----------------------------- */
+/* The wake (TEV, LEV and FREE vortices, in an order the host chooses) lives on the device across
+ * time steps as float64 master copies plus the fp32 (hi, lo) SoA the pair kernel reads. */
+
+int ludvm_wake_reserve(ludvm_ctx* ctx, size_t capacity);      /* grow-only; keeps contents */
+int ludvm_wake_clear(ludvm_ctx* ctx);                          /* size := 0 */
+int ludvm_wake_size(ludvm_ctx* ctx, size_t* n);
+/* Append `count` vortices (new TEV / LEV placement, LUDVM.py:672-681, 788-800). */
+int ludvm_wake_append(ludvm_ctx* ctx, const double* x, const double* z, const double* gamma, size_t count);
+/* Overwrite positions and/or circulation of [first, first+count); NULL leaves that field as is.
+ * The circulation of the newest TEV/LEV is solved after placement (LUDVM.py:758-760, 953-954). */
+int ludvm_wake_write(ludvm_ctx* ctx, size_t first, size_t count, const double* x, const double* z,
+                     const double* gamma);
+/* Read back [first, first+count) (history rows of path['TEV'|'LEV'|'FREE'], LUDVM.py:615-618).
+ * Any of x, z, gamma may be NULL. */
+int ludvm_wake_read(ludvm_ctx* ctx, size_t first, size_t count, double* x, double* z, double* gamma);
+/* Velocity induced by wake vortices [src_first, src_first+src_count) at nt host points (the
+ * Npoints-1 bound-vortex points of the chord: LUDVM.py:582-584, 1049-1054).  fp64 arithmetic:
+ * these O(Npanels x Nw) sums feed the Gamma solve and the loads and cost <1 % of a step. */
+int ludvm_wake_induce_on_points(ludvm_ctx* ctx, size_t src_first, size_t src_count, const double* xt,
+                                const double* zt, size_t nt, double vcore, double* u, double* w);
+/* Wake roll-up, fused (LUDVM.py:1095-1127): for every wake vortex i in [0, size):
+ *   (u,w)_i = induced by all wake vortices  +  induced by the nfoil bound vortices (foil_x, foil_z,
+ *   foil_dgamma: LUDVM.py:1096,1099-1100), both with the same core radius;
+ *   x_i += dt*u_i ; z_i += dt*w_i   (explicit Euler, float64 update of the master copy).
+ * `precision` selects the pair arithmetic.  If u_out/w_out are non-NULL the induced velocities
+ * (before the update) are also returned (size doubles each). */
+int ludvm_wake_advect(ludvm_ctx* ctx, double dt, const double* foil_x, const double* foil_z,
+                      const double* foil_dgamma, size_t nfoil, double vcore, int precision, double* u_out,
+                      double* w_out);
+
+/* ---- flow field: backs LUDVM.flowfield (LUDVM.py:1186-1298) -------------------------------- */
+
+/* Grid targets generated on the device, x-major ravel like np.meshgrid(indexing='ij')
+ * (LUDVM.py:1193-1195): point (i,j) = (xmin + i*dr, zmin + j*dr), i < nx, j < nz, index i*nz + j.
+ * Sources are host float64 arrays (wake ++ foil as the caller gathered them, LUDVM.py:1202-1217).
+ * Outputs u, w are host float32 arrays of nx*nz (fp32 arithmetic).  d_u/d_w variants keep the result
+ * on the device for the vorticity stencil. */
+int ludvm_flowfield_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz,
+                        const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
+                        float* u, float* w);
+/* Same, device-resident fp32 sources and outputs (asynchronous). */
+int ludvm_flowfield_dev_f32(ludvm_ctx* ctx, float xmin, float zmin, float dr, size_t nx, size_t nz,
+                            const float* d_xs, const float* d_zs, const float* d_gs, size_t ns, float vcore,
+                            float* d_u, float* d_w);
+/* Vorticity dw/dx - du/dz on the uniform grid: centred differences inside, one-sided on edges and
+ * corners (LUDVM.py:1224-1292).  Host float32 in/out, nx*nz each. */
+int ludvm_vorticity_f32(ludvm_ctx* ctx, const float* u, const float* w, size_t nx, size_t nz, double dr,
+                        float* ome);
+int ludvm_vorticity_dev_f32(ludvm_ctx* ctx, const float* d_u, const float* d_w, size_t nx, size_t nz, float dr,
+                            float* d_ome);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+
+/* Average device time (ms) of the pair kernel launches (main kernel only, not the split
+ * reduction) issued since the last call with reset != 0, measured with HIP events on the stream the
+ * kernel is launched on; *launches = number of launches averaged.  Timing is off until
+ * ludvm_kernel_timing(ctx, 1). */
+int ludvm_kernel_timing(ludvm_ctx* ctx, int enable);
+int ludvm_kernel_time_ms(ludvm_ctx* ctx, int reset, double* avg_ms, long long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUDVM_HIP_H */

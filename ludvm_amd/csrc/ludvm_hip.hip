@@ -1,0 +1,807 @@
+// libludvm_hip.so -- C-ABI implementation (see include/ludvm_hip.h for the contract and the
+// reference file:line each entry point replaces).  gfx950 only; no CPU path: every entry point
+// either runs the HIP kernels or returns an error code.
+#include "../../include/ludvm_hip.h"
+#include "pair_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace ludvm;
+
+namespace {
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct TimedLaunch {
+  hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct ludvm_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop;
+  std::string err;
+
+  int tune_tpl = 0;
+  int tune_split = 0;
+
+  Buf part;   // partial slabs of the split reduction
+  Buf arena;  // staging for the host-pointer entry points
+  char* pin = nullptr;  // pinned host ring for small uploads from entry points that do not synchronize
+  size_t pin_off = 0;
+
+  // resident wake (float64 master + fp32 mirrors)
+  size_t wake_cap = 0, wake_n = 0;
+  double *x64 = nullptr, *z64 = nullptr, *g64 = nullptr;
+  float *xh = nullptr, *xl = nullptr, *zh = nullptr, *zl = nullptr, *g32 = nullptr;
+
+  // kernel timing
+  bool timing = false;
+  std::vector<TimedLaunch> pending;
+  std::vector<TimedLaunch> pool;
+  double total_ms = 0.0;
+  long long launches = 0;
+};
+
+namespace {
+
+int fail(ludvm_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+int fail_hip(ludvm_ctx* c, const char* what, hipError_t e) {
+  return fail(c, e == hipErrorOutOfMemory ? LUDVM_E_NOMEM : LUDVM_E_HIP,
+              std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIPCHK(c, call)                                     \
+  do {                                                      \
+    hipError_t e__ = (call);                                \
+    if (e__ != hipSuccess) return fail_hip((c), #call, e__); \
+  } while (0)
+
+#define CHK(call)                     \
+  do {                                \
+    int rc__ = (call);                \
+    if (rc__ != LUDVM_OK) return rc__; \
+  } while (0)
+
+int ensure(ludvm_ctx* c, Buf& b, size_t bytes) {
+  if (bytes <= b.cap) return LUDVM_OK;
+  // the old contents are never needed across a grow; wait for in-flight users, then replace
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (b.p) HIPCHK(c, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = std::max(bytes, (size_t)1 << 20);
+  HIPCHK(c, hipMalloc(&b.p, want));
+  b.cap = want;
+  return LUDVM_OK;
+}
+
+constexpr size_t kPinBytes = (size_t)1 << 20;
+
+// Host -> device copy for entry points that return without synchronizing: the caller may free or
+// overwrite its arrays right after the call, so small uploads go through a context-owned pinned
+// ring (a wrap waits for the stream); large ones are copied directly and waited for.
+int h2d(ludvm_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return LUDVM_OK;
+  if (bytes > kPinBytes / 4) {
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LUDVM_OK;
+  }
+  if (!c->pin) HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin), kPinBytes, hipHostMallocDefault));
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  if (c->pin_off + need > kPinBytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pin_off = 0;
+  }
+  std::memcpy(c->pin + c->pin_off, src, bytes);
+  HIPCHK(c, hipMemcpyAsync(dst, c->pin + c->pin_off, bytes, hipMemcpyHostToDevice, c->stream));
+  c->pin_off += need;
+  return LUDVM_OK;
+}
+
+// bump allocator over the staging arena
+struct Arena {
+  char* base;
+  size_t off = 0;
+  explicit Arena(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t n) {
+    T* r = reinterpret_cast<T*>(base + off);
+    off += (n * sizeof(T) + 255) & ~(size_t)255;
+    return r;
+  }
+  static size_t need(size_t n, size_t elt) { return (n * elt + 255) & ~(size_t)255; }
+};
+
+inline unsigned blocks_for(long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+struct Plan {
+  int tpl;
+  int tile;
+  int nsplit;
+  long long chunk;
+  long long nt_pad;
+  dim3 grid;
+};
+
+constexpr int kTileF32 = 1024;
+constexpr int kTileF64 = 512;
+constexpr long long kTargetBlocks = 16384;  // total workgroups aimed for (2048 resident at 8/CU)
+constexpr int kMaxSplit = 2048;
+
+Plan make_plan(const ludvm_ctx* c, long long nt, long long ns, int precision) {
+  Plan p{};
+  const bool f64 = precision == LUDVM_PREC_F64;
+  p.tile = f64 ? kTileF64 : kTileF32;
+  if (f64) {
+    p.tpl = 1;
+  } else if (c->tune_tpl == 1 || c->tune_tpl == 2 || c->tune_tpl == 4) {
+    p.tpl = c->tune_tpl;
+  } else {
+    p.tpl = nt >= 131072 ? 2 : 1;
+  }
+  const long long ttiles = std::max<long long>(1, (nt + (long long)kBlock * p.tpl - 1) / ((long long)kBlock * p.tpl));
+  const long long max_split = std::max<long long>(1, (ns + p.tile - 1) / p.tile);
+  long long nsplit = c->tune_split > 0 ? c->tune_split : (kTargetBlocks + ttiles - 1) / ttiles;
+  nsplit = std::max<long long>(1, std::min<long long>(std::min<long long>(nsplit, max_split), kMaxSplit));
+  long long chunk = (std::max<long long>(ns, 1) + nsplit - 1) / nsplit;
+  chunk = (chunk + p.tile - 1) / p.tile * p.tile;
+  p.chunk = chunk;
+  p.nsplit = (int)std::max<long long>(1, (ns + chunk - 1) / chunk);
+  p.nt_pad = (nt + 63) / 64 * 64;
+  p.grid = dim3((unsigned)ttiles, (unsigned)p.nsplit, 1);
+  return p;
+}
+
+int timed_begin(ludvm_ctx* c, TimedLaunch& t, bool& active) {
+  active = c->timing;
+  if (!active) return LUDVM_OK;
+  if (!c->pool.empty()) {
+    t = c->pool.back();
+    c->pool.pop_back();
+  } else {
+    HIPCHK(c, hipEventCreate(&t.e0));
+    HIPCHK(c, hipEventCreate(&t.e1));
+  }
+  HIPCHK(c, hipEventRecord(t.e0, c->stream));
+  return LUDVM_OK;
+}
+
+int timed_end(ludvm_ctx* c, TimedLaunch& t, bool active) {
+  if (!active) return LUDVM_OK;
+  HIPCHK(c, hipEventRecord(t.e1, c->stream));
+  c->pending.push_back(t);
+  return LUDVM_OK;
+}
+
+int drain_timing(ludvm_ctx* c) {
+  for (auto& t : c->pending) {
+    HIPCHK(c, hipEventSynchronize(t.e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, t.e0, t.e1));
+    c->total_ms += ms;
+    c->launches += 1;
+    c->pool.push_back(t);
+  }
+  c->pending.clear();
+  return LUDVM_OK;
+}
+
+// Launch the main pair kernel described by `a` (sources, targets and vc4 filled in by the caller)
+// under plan `p`; a.part / a.u / a.w / a.nt_pad / a.chunk are completed here.  With more than one
+// split the results are left in c->part for a finisher; with one split they go to (u, w).
+int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u, void* w) {
+  const size_t elt = precision == LUDVM_PREC_F64 ? sizeof(double) : sizeof(float);
+  a.chunk = p.chunk;
+  a.nt_pad = p.nt_pad;
+  a.u = u;
+  a.w = w;
+  a.part = nullptr;
+  if (p.nsplit > 1 || u == nullptr) {
+    CHK(ensure(c, c->part, (size_t)p.nsplit * 2 * (size_t)p.nt_pad * elt));
+    a.part = c->part.p;
+  }
+  dim3 grid = p.grid;
+  // a single split asked to land in the slab (fused finisher): the kernel distinguishes by
+  // gridDim.y, so give it the direct pointers into slab row 0
+  if (p.nsplit == 1 && u == nullptr) {
+    a.u = c->part.p;
+    a.w = static_cast<char*>(c->part.p) + (size_t)p.nt_pad * elt;
+  }
+  TimedLaunch t{};
+  bool active = false;
+  CHK(timed_begin(c, t, active));
+  if (precision == LUDVM_PREC_F64) {
+    hipLaunchKernelGGL((pair_f64<kTileF64>), grid, dim3(kBlock), 0, c->stream, a);
+  } else if (precision == LUDVM_PREC_F32X2) {
+    switch (p.tpl) {
+      case 1: hipLaunchKernelGGL((pair_f32<1, kTileF32, true>), grid, dim3(kBlock), 0, c->stream, a); break;
+      case 2: hipLaunchKernelGGL((pair_f32<2, kTileF32, true>), grid, dim3(kBlock), 0, c->stream, a); break;
+      default: hipLaunchKernelGGL((pair_f32<4, kTileF32, true>), grid, dim3(kBlock), 0, c->stream, a); break;
+    }
+  } else {
+    switch (p.tpl) {
+      case 1: hipLaunchKernelGGL((pair_f32<1, kTileF32, false>), grid, dim3(kBlock), 0, c->stream, a); break;
+      case 2: hipLaunchKernelGGL((pair_f32<2, kTileF32, false>), grid, dim3(kBlock), 0, c->stream, a); break;
+      default: hipLaunchKernelGGL((pair_f32<4, kTileF32, false>), grid, dim3(kBlock), 0, c->stream, a); break;
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  CHK(timed_end(c, t, active));
+  return LUDVM_OK;
+}
+
+// pair kernel + split reduction into (u, w) device arrays of the precision's type
+int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, int precision, void* u, void* w) {
+  if (nt == 0) return LUDVM_OK;
+  const size_t elt = precision == LUDVM_PREC_F64 ? sizeof(double) : sizeof(float);
+  if (ns == 0) {
+    HIPCHK(c, hipMemsetAsync(u, 0, (size_t)nt * elt, c->stream));
+    HIPCHK(c, hipMemsetAsync(w, 0, (size_t)nt * elt, c->stream));
+    return LUDVM_OK;
+  }
+  Plan p = make_plan(c, nt, ns, precision);
+  CHK(launch_pair(c, a, p, precision, u, w));
+  if (p.nsplit > 1) {
+    if (precision == LUDVM_PREC_F64)
+      hipLaunchKernelGGL(finish_sum<double>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
+                         static_cast<const double*>(c->part.p), nt, p.nt_pad, p.nsplit, static_cast<double*>(u),
+                         static_cast<double*>(w));
+    else
+      hipLaunchKernelGGL(finish_sum<float>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
+                         static_cast<const float*>(c->part.p), nt, p.nt_pad, p.nsplit, static_cast<float*>(u),
+                         static_cast<float*>(w));
+    HIPCHK(c, hipGetLastError());
+  }
+  return LUDVM_OK;
+}
+
+bool valid_precision(int p) { return p == LUDVM_PREC_F32 || p == LUDVM_PREC_F32X2 || p == LUDVM_PREC_F64; }
+
+int wake_grow(ludvm_ctx* c, size_t capacity) {
+  if (capacity <= c->wake_cap) return LUDVM_OK;
+  size_t cap = std::max(capacity, std::max<size_t>(4096, c->wake_cap * 2));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double *x64, *z64, *g64;
+  float *xh, *xl, *zh, *zl, *g32;
+  HIPCHK(c, hipMalloc(&x64, cap * sizeof(double)));
+  HIPCHK(c, hipMalloc(&z64, cap * sizeof(double)));
+  HIPCHK(c, hipMalloc(&g64, cap * sizeof(double)));
+  HIPCHK(c, hipMalloc(&xh, cap * sizeof(float)));
+  HIPCHK(c, hipMalloc(&xl, cap * sizeof(float)));
+  HIPCHK(c, hipMalloc(&zh, cap * sizeof(float)));
+  HIPCHK(c, hipMalloc(&zl, cap * sizeof(float)));
+  HIPCHK(c, hipMalloc(&g32, cap * sizeof(float)));
+  const size_t n = c->wake_n;
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(x64, c->x64, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(z64, c->z64, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(g64, c->g64, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(xh, c->xh, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(xl, c->xl, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(zh, c->zh, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(zl, c->zl, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(g32, c->g32, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  void* old[] = {c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32};
+  for (void* p : old)
+    if (p) HIPCHK(c, hipFree(p));
+  c->x64 = x64; c->z64 = z64; c->g64 = g64;
+  c->xh = xh; c->xl = xl; c->zh = zh; c->zl = zl; c->g32 = g32;
+  c->wake_cap = cap;
+  return LUDVM_OK;
+}
+
+int wake_refresh(ludvm_ctx* c, size_t first, size_t count) {
+  if (!count) return LUDVM_OK;
+  hipLaunchKernelGGL(refresh_mirrors, dim3(blocks_for((long long)count)), dim3(kBlock), 0, c->stream, (long long)first,
+                     (long long)count, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32);
+  HIPCHK(c, hipGetLastError());
+  return LUDVM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ludvm_abi_version(void) { return LUDVM_ABI_VERSION; }
+
+int ludvm_create(int device_ordinal, ludvm_ctx** out) {
+  if (!out) return LUDVM_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LUDVM_E_NODEVICE;
+  if (device_ordinal < 0 || device_ordinal >= ndev) return LUDVM_E_ARG;
+  ludvm_ctx* c = new (std::nothrow) ludvm_ctx();
+  if (!c) return LUDVM_E_NOMEM;
+  c->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&c->prop, device_ordinal) != hipSuccess) {
+    delete c;
+    return LUDVM_E_HIP;
+  }
+  const char* any = std::getenv("LUDVM_ALLOW_ANY_ARCH");
+  if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0 && !(any && any[0] == '1')) {
+    delete c;
+    return LUDVM_E_NODEVICE;
+  }
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return LUDVM_E_HIP;
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return LUDVM_OK;
+}
+
+int ludvm_destroy(ludvm_ctx* c) {
+  if (!c) return LUDVM_E_ARG;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& t : c->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+  for (auto& t : c->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+  void* bufs[] = {c->part.p, c->arena.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32};
+  for (void* p : bufs)
+    if (p) (void)hipFree(p);
+  if (c->pin) (void)hipHostFree(c->pin);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return LUDVM_OK;
+}
+
+const char* ludvm_last_error(const ludvm_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int ludvm_device_info(ludvm_ctx* c, int* cu_count, int* clock_khz, long long* hbm_bytes, char* name, int name_len) {
+  if (!c) return LUDVM_E_ARG;
+  if (cu_count) *cu_count = c->prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = c->prop.clockRate;
+  if (hbm_bytes) *hbm_bytes = (long long)c->prop.totalGlobalMem;
+  if (name && name_len > 0) {
+    std::snprintf(name, (size_t)name_len, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+  }
+  return LUDVM_OK;
+}
+
+int ludvm_set_stream(ludvm_ctx* c, void* hip_stream) {
+  if (!c) return LUDVM_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return LUDVM_OK;
+}
+
+int ludvm_synchronize(ludvm_ctx* c) {
+  if (!c) return LUDVM_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LUDVM_OK;
+}
+
+int ludvm_set_tuning(ludvm_ctx* c, int targets_per_lane, int source_splits) {
+  if (!c) return LUDVM_E_ARG;
+  if (!(targets_per_lane == 0 || targets_per_lane == 1 || targets_per_lane == 2 || targets_per_lane == 4))
+    return fail(c, LUDVM_E_ARG, "targets_per_lane must be 0, 1, 2 or 4");
+  if (source_splits < 0 || source_splits > kMaxSplit) return fail(c, LUDVM_E_ARG, "source_splits out of range");
+  c->tune_tpl = targets_per_lane;
+  c->tune_split = source_splits;
+  return LUDVM_OK;
+}
+
+/* ---- stateless pair sum ------------------------------------------------------------------- */
+
+int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const double* gs, size_t ns, const double* xt,
+                     const double* zt, size_t nt, double vcore, int precision, double* u, double* w) {
+  if (!c) return LUDVM_E_ARG;
+  if (!valid_precision(precision)) return fail(c, LUDVM_E_ARG, "unknown precision");
+  if ((ns && (!xs || !zs || !gs)) || (nt && (!xt || !zt || !u || !w))) return fail(c, LUDVM_E_ARG, "null array");
+  if (nt == 0) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (ns == 0) {
+    std::memset(u, 0, nt * sizeof(double));
+    std::memset(w, 0, nt * sizeof(double));
+    return LUDVM_OK;
+  }
+  const bool f64 = precision == LUDVM_PREC_F64;
+  size_t bytes = 3 * Arena::need(ns, 8) + 4 * Arena::need(nt, 8);
+  if (!f64) bytes += 5 * Arena::need(ns, 4) + 6 * Arena::need(nt, 4);
+  CHK(ensure(c, c->arena, bytes));
+  Arena ar(c->arena.p);
+  double* dxs = ar.take<double>(ns);
+  double* dzs = ar.take<double>(ns);
+  double* dgs = ar.take<double>(ns);
+  double* dxt = ar.take<double>(nt);
+  double* dzt = ar.take<double>(nt);
+  double* du = ar.take<double>(nt);
+  double* dw = ar.take<double>(nt);
+  HIPCHK(c, hipMemcpyAsync(dxs, xs, ns * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dzs, zs, ns * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dgs, gs, ns * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dxt, xt, nt * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dzt, zt, nt * 8, hipMemcpyHostToDevice, c->stream));
+  PairArgs a{};
+  a.ns = (long long)ns;
+  a.nt = (long long)nt;
+  const double v2 = vcore * vcore;
+  a.vc4 = v2 * v2;
+  if (f64) {
+    a.xs = dxs; a.zs = dzs; a.gs = dgs; a.xt = dxt; a.zt = dzt;
+    CHK(induce_device(c, a, (long long)nt, (long long)ns, precision, du, dw));
+  } else {
+    float* fxs = ar.take<float>(ns);
+    float* fxsl = ar.take<float>(ns);
+    float* fzs = ar.take<float>(ns);
+    float* fzsl = ar.take<float>(ns);
+    float* fgs = ar.take<float>(ns);
+    float* fxt = ar.take<float>(nt);
+    float* fxtl = ar.take<float>(nt);
+    float* fzt = ar.take<float>(nt);
+    float* fztl = ar.take<float>(nt);
+    float* fu = ar.take<float>(nt);
+    float* fw = ar.take<float>(nt);
+    const dim3 bs(kBlock);
+    hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)ns)), bs, 0, c->stream, dxs, fxs, fxsl, (long long)ns);
+    hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)ns)), bs, 0, c->stream, dzs, fzs, fzsl, (long long)ns);
+    hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)ns)), bs, 0, c->stream, dgs, fgs, (float*)nullptr,
+                       (long long)ns);
+    hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)nt)), bs, 0, c->stream, dxt, fxt, fxtl, (long long)nt);
+    hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)nt)), bs, 0, c->stream, dzt, fzt, fztl, (long long)nt);
+    HIPCHK(c, hipGetLastError());
+    a.xs = fxs; a.zs = fzs; a.gs = fgs; a.xsl = fxsl; a.zsl = fzsl;
+    a.xt = fxt; a.zt = fzt; a.xtl = fxtl; a.ztl = fztl;
+    CHK(induce_device(c, a, (long long)nt, (long long)ns, precision, fu, fw));
+    hipLaunchKernelGGL(cvt_f32_to_f64, dim3(blocks_for((long long)nt)), bs, 0, c->stream, fu, du, (long long)nt);
+    hipLaunchKernelGGL(cvt_f32_to_f64, dim3(blocks_for((long long)nt)), bs, 0, c->stream, fw, dw, (long long)nt);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, hipMemcpyAsync(u, du, nt * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(w, dw, nt * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LUDVM_OK;
+}
+
+int ludvm_induce_f32(ludvm_ctx* c, const float* xs, const float* zs, const float* gs, size_t ns, const float* xt,
+                     const float* zt, size_t nt, float vcore, float* u, float* w) {
+  if (!c) return LUDVM_E_ARG;
+  if ((ns && (!xs || !zs || !gs)) || (nt && (!xt || !zt || !u || !w))) return fail(c, LUDVM_E_ARG, "null array");
+  if (nt == 0) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (ns == 0) {
+    std::memset(u, 0, nt * sizeof(float));
+    std::memset(w, 0, nt * sizeof(float));
+    return LUDVM_OK;
+  }
+  CHK(ensure(c, c->arena, 3 * Arena::need(ns, 4) + 4 * Arena::need(nt, 4)));
+  Arena ar(c->arena.p);
+  float* dxs = ar.take<float>(ns);
+  float* dzs = ar.take<float>(ns);
+  float* dgs = ar.take<float>(ns);
+  float* dxt = ar.take<float>(nt);
+  float* dzt = ar.take<float>(nt);
+  float* du = ar.take<float>(nt);
+  float* dw = ar.take<float>(nt);
+  HIPCHK(c, hipMemcpyAsync(dxs, xs, ns * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dzs, zs, ns * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dgs, gs, ns * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dxt, xt, nt * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dzt, zt, nt * 4, hipMemcpyHostToDevice, c->stream));
+  CHK(ludvm_induce_dev_f32(c, dxs, dzs, dgs, ns, dxt, dzt, nt, vcore, du, dw));
+  HIPCHK(c, hipMemcpyAsync(u, du, nt * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(w, dw, nt * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LUDVM_OK;
+}
+
+int ludvm_induce_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, const float* d_gs, size_t ns,
+                         const float* d_xt, const float* d_zt, size_t nt, float vcore, float* d_u, float* d_w) {
+  if (!c) return LUDVM_E_ARG;
+  if ((ns && (!d_xs || !d_zs || !d_gs)) || (nt && (!d_xt || !d_zt || !d_u || !d_w)))
+    return fail(c, LUDVM_E_ARG, "null array");
+  HIPCHK(c, hipSetDevice(c->device));
+  PairArgs a{};
+  a.xs = d_xs; a.zs = d_zs; a.gs = d_gs; a.ns = (long long)ns;
+  a.xt = d_xt; a.zt = d_zt; a.nt = (long long)nt;
+  const double v2 = (double)vcore * (double)vcore;
+  a.vc4 = v2 * v2;
+  return induce_device(c, a, (long long)nt, (long long)ns, LUDVM_PREC_F32, d_u, d_w);
+}
+
+int ludvm_advect_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, const float* d_gs, size_t ns,
+                         size_t t_first, size_t nt, float vcore, float dt, float* d_x_out, float* d_z_out) {
+  if (!c) return LUDVM_E_ARG;
+  if (!d_xs || !d_zs || !d_gs || !d_x_out || !d_z_out) return fail(c, LUDVM_E_ARG, "null array");
+  if (t_first + nt > ns) return fail(c, LUDVM_E_ARG, "target range outside the source arrays");
+  if (nt == 0) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  PairArgs a{};
+  a.xs = d_xs; a.zs = d_zs; a.gs = d_gs; a.ns = (long long)ns;
+  a.xt = d_xs + t_first; a.zt = d_zs + t_first; a.nt = (long long)nt;
+  const double v2 = (double)vcore * (double)vcore;
+  a.vc4 = v2 * v2;
+  Plan p = make_plan(c, (long long)nt, (long long)ns, LUDVM_PREC_F32);
+  CHK(launch_pair(c, a, p, LUDVM_PREC_F32, nullptr, nullptr));  // results stay in the slab
+  hipLaunchKernelGGL(finish_advect_f32, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream,
+                     static_cast<const float*>(c->part.p), (long long)nt, p.nt_pad, p.nsplit, d_xs, d_zs,
+                     (long long)t_first, dt, d_x_out, d_z_out);
+  HIPCHK(c, hipGetLastError());
+  return LUDVM_OK;
+}
+
+/* ---- resident wake ------------------------------------------------------------------------ */
+
+int ludvm_wake_reserve(ludvm_ctx* c, size_t capacity) {
+  if (!c) return LUDVM_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  return wake_grow(c, capacity);
+}
+
+int ludvm_wake_clear(ludvm_ctx* c) {
+  if (!c) return LUDVM_E_ARG;
+  c->wake_n = 0;
+  return LUDVM_OK;
+}
+
+int ludvm_wake_size(ludvm_ctx* c, size_t* n) {
+  if (!c || !n) return LUDVM_E_ARG;
+  *n = c->wake_n;
+  return LUDVM_OK;
+}
+
+int ludvm_wake_append(ludvm_ctx* c, const double* x, const double* z, const double* gamma, size_t count) {
+  if (!c) return LUDVM_E_ARG;
+  if (count == 0) return LUDVM_OK;
+  if (!x || !z || !gamma) return fail(c, LUDVM_E_ARG, "null array");
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(wake_grow(c, c->wake_n + count));
+  const size_t n = c->wake_n;
+  CHK(h2d(c, c->x64 + n, x, count * 8));
+  CHK(h2d(c, c->z64 + n, z, count * 8));
+  CHK(h2d(c, c->g64 + n, gamma, count * 8));
+  CHK(wake_refresh(c, n, count));
+  c->wake_n = n + count;
+  return LUDVM_OK;
+}
+
+int ludvm_wake_write(ludvm_ctx* c, size_t first, size_t count, const double* x, const double* z, const double* gamma) {
+  if (!c) return LUDVM_E_ARG;
+  if (first + count > c->wake_n) return fail(c, LUDVM_E_ARG, "range outside the wake");
+  if (count == 0) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (x) CHK(h2d(c, c->x64 + first, x, count * 8));
+  if (z) CHK(h2d(c, c->z64 + first, z, count * 8));
+  if (gamma) CHK(h2d(c, c->g64 + first, gamma, count * 8));
+  return wake_refresh(c, first, count);
+}
+
+int ludvm_wake_read(ludvm_ctx* c, size_t first, size_t count, double* x, double* z, double* gamma) {
+  if (!c) return LUDVM_E_ARG;
+  if (first + count > c->wake_n) return fail(c, LUDVM_E_ARG, "range outside the wake");
+  if (count == 0) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (x) HIPCHK(c, hipMemcpyAsync(x, c->x64 + first, count * 8, hipMemcpyDeviceToHost, c->stream));
+  if (z) HIPCHK(c, hipMemcpyAsync(z, c->z64 + first, count * 8, hipMemcpyDeviceToHost, c->stream));
+  if (gamma) HIPCHK(c, hipMemcpyAsync(gamma, c->g64 + first, count * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LUDVM_OK;
+}
+
+int ludvm_wake_induce_on_points(ludvm_ctx* c, size_t src_first, size_t src_count, const double* xt, const double* zt,
+                                size_t nt, double vcore, double* u, double* w) {
+  if (!c) return LUDVM_E_ARG;
+  if (src_first + src_count > c->wake_n) return fail(c, LUDVM_E_ARG, "source range outside the wake");
+  if (nt && (!xt || !zt || !u || !w)) return fail(c, LUDVM_E_ARG, "null array");
+  if (nt == 0) return LUDVM_OK;
+  if (src_count == 0) {
+    std::memset(u, 0, nt * sizeof(double));
+    std::memset(w, 0, nt * sizeof(double));
+    return LUDVM_OK;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(ensure(c, c->arena, 4 * Arena::need(nt, 8)));
+  Arena ar(c->arena.p);
+  double* dxt = ar.take<double>(nt);
+  double* dzt = ar.take<double>(nt);
+  double* du = ar.take<double>(nt);
+  double* dw = ar.take<double>(nt);
+  HIPCHK(c, hipMemcpyAsync(dxt, xt, nt * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dzt, zt, nt * 8, hipMemcpyHostToDevice, c->stream));
+  PairArgs a{};
+  a.xs = c->x64 + src_first; a.zs = c->z64 + src_first; a.gs = c->g64 + src_first;
+  a.ns = (long long)src_count;
+  a.xt = dxt; a.zt = dzt; a.nt = (long long)nt;
+  const double v2 = vcore * vcore;
+  a.vc4 = v2 * v2;
+  CHK(induce_device(c, a, (long long)nt, (long long)src_count, LUDVM_PREC_F64, du, dw));
+  HIPCHK(c, hipMemcpyAsync(u, du, nt * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(w, dw, nt * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LUDVM_OK;
+}
+
+int ludvm_wake_advect(ludvm_ctx* c, double dt, const double* foil_x, const double* foil_z, const double* foil_dgamma,
+                      size_t nfoil, double vcore, int precision, double* u_out, double* w_out) {
+  if (!c) return LUDVM_E_ARG;
+  if (!valid_precision(precision)) return fail(c, LUDVM_E_ARG, "unknown precision");
+  if (nfoil && (!foil_x || !foil_z || !foil_dgamma)) return fail(c, LUDVM_E_ARG, "null foil array");
+  if ((u_out == nullptr) != (w_out == nullptr)) return fail(c, LUDVM_E_ARG, "u_out and w_out go together");
+  const size_t n = c->wake_n;
+  if (n == 0) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  // bound vortices ride behind the wake in the same source arrays for this launch
+  CHK(wake_grow(c, n + nfoil));
+  if (nfoil) {
+    CHK(h2d(c, c->x64 + n, foil_x, nfoil * 8));
+    CHK(h2d(c, c->z64 + n, foil_z, nfoil * 8));
+    CHK(h2d(c, c->g64 + n, foil_dgamma, nfoil * 8));
+    CHK(wake_refresh(c, n, nfoil));
+  }
+  const long long ns = (long long)(n + nfoil), nt = (long long)n;
+  PairArgs a{};
+  a.ns = ns;
+  a.nt = nt;
+  const double v2 = vcore * vcore;
+  a.vc4 = v2 * v2;
+  if (precision == LUDVM_PREC_F64) {
+    a.xs = c->x64; a.zs = c->z64; a.gs = c->g64; a.xt = c->x64; a.zt = c->z64;
+  } else {
+    a.xs = c->xh; a.zs = c->zh; a.gs = c->g32; a.xsl = c->xl; a.zsl = c->zl;
+    a.xt = c->xh; a.zt = c->zh; a.xtl = c->xl; a.ztl = c->zl;
+  }
+  Plan p = make_plan(c, nt, ns, precision);
+  CHK(launch_pair(c, a, p, precision, nullptr, nullptr));  // results stay in the slab
+  double *du = nullptr, *dw = nullptr;
+  if (u_out) {
+    CHK(ensure(c, c->arena, 2 * Arena::need(n, 8)));
+    Arena ar(c->arena.p);
+    du = ar.take<double>(n);
+    dw = ar.take<double>(n);
+  }
+  if (precision == LUDVM_PREC_F64)
+    hipLaunchKernelGGL(finish_wake_advect<double>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
+                       static_cast<const double*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->xh, c->xl,
+                       c->zh, c->zl, du, dw);
+  else
+    hipLaunchKernelGGL(finish_wake_advect<float>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
+                       static_cast<const float*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->xh, c->xl,
+                       c->zh, c->zl, du, dw);
+  HIPCHK(c, hipGetLastError());
+  if (u_out) {
+    HIPCHK(c, hipMemcpyAsync(u_out, du, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(w_out, dw, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return LUDVM_OK;
+}
+
+/* ---- flow field ---------------------------------------------------------------------------- */
+
+int ludvm_flowfield_dev_f32(ludvm_ctx* c, float xmin, float zmin, float dr, size_t nx, size_t nz, const float* d_xs,
+                            const float* d_zs, const float* d_gs, size_t ns, float vcore, float* d_u, float* d_w) {
+  if (!c) return LUDVM_E_ARG;
+  if (nx == 0 || nz == 0) return LUDVM_OK;
+  if ((ns && (!d_xs || !d_zs || !d_gs)) || !d_u || !d_w) return fail(c, LUDVM_E_ARG, "null array");
+  HIPCHK(c, hipSetDevice(c->device));
+  PairArgs a{};
+  a.xs = d_xs; a.zs = d_zs; a.gs = d_gs; a.ns = (long long)ns;
+  a.nt = (long long)(nx * nz);
+  a.grid_nz = (long long)nz;
+  a.xmin = xmin; a.zmin = zmin; a.dr = dr;
+  const double v2 = (double)vcore * (double)vcore;
+  a.vc4 = v2 * v2;
+  return induce_device(c, a, a.nt, a.ns, LUDVM_PREC_F32, d_u, d_w);
+}
+
+int ludvm_flowfield_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, const double* xs,
+                        const double* zs, const double* gs, size_t ns, double vcore, float* u, float* w) {
+  if (!c) return LUDVM_E_ARG;
+  const size_t nt = nx * nz;
+  if (nt == 0) return LUDVM_OK;
+  if ((ns && (!xs || !zs || !gs)) || !u || !w) return fail(c, LUDVM_E_ARG, "null array");
+  if (ns == 0) {
+    std::memset(u, 0, nt * sizeof(float));
+    std::memset(w, 0, nt * sizeof(float));
+    return LUDVM_OK;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(ensure(c, c->arena, 3 * Arena::need(ns, 8) + 3 * Arena::need(ns, 4) + 2 * Arena::need(nt, 4)));
+  Arena ar(c->arena.p);
+  double* dxs = ar.take<double>(ns);
+  double* dzs = ar.take<double>(ns);
+  double* dgs = ar.take<double>(ns);
+  float* fxs = ar.take<float>(ns);
+  float* fzs = ar.take<float>(ns);
+  float* fgs = ar.take<float>(ns);
+  float* du = ar.take<float>(nt);
+  float* dw = ar.take<float>(nt);
+  HIPCHK(c, hipMemcpyAsync(dxs, xs, ns * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dzs, zs, ns * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dgs, gs, ns * 8, hipMemcpyHostToDevice, c->stream));
+  const dim3 bs(kBlock), gs_(blocks_for((long long)ns));
+  hipLaunchKernelGGL(cvt_f64_to_f32, gs_, bs, 0, c->stream, dxs, fxs, (float*)nullptr, (long long)ns);
+  hipLaunchKernelGGL(cvt_f64_to_f32, gs_, bs, 0, c->stream, dzs, fzs, (float*)nullptr, (long long)ns);
+  hipLaunchKernelGGL(cvt_f64_to_f32, gs_, bs, 0, c->stream, dgs, fgs, (float*)nullptr, (long long)ns);
+  HIPCHK(c, hipGetLastError());
+  PairArgs a{};
+  a.xs = fxs; a.zs = fzs; a.gs = fgs; a.ns = (long long)ns;
+  a.nt = (long long)nt;
+  a.grid_nz = (long long)nz;
+  a.xmin = xmin; a.zmin = zmin; a.dr = dr;
+  const double v2 = vcore * vcore;
+  a.vc4 = v2 * v2;
+  CHK(induce_device(c, a, a.nt, a.ns, LUDVM_PREC_F32, du, dw));
+  HIPCHK(c, hipMemcpyAsync(u, du, nt * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(w, dw, nt * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LUDVM_OK;
+}
+
+int ludvm_vorticity_dev_f32(ludvm_ctx* c, const float* d_u, const float* d_w, size_t nx, size_t nz, float dr,
+                            float* d_ome) {
+  if (!c) return LUDVM_E_ARG;
+  if (nx < 2 || nz < 2) return fail(c, LUDVM_E_ARG, "vorticity needs nx, nz >= 2");
+  if (!d_u || !d_w || !d_ome) return fail(c, LUDVM_E_ARG, "null array");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(vorticity_f32, dim3(blocks_for((long long)(nx * nz))), dim3(kBlock), 0, c->stream, d_u, d_w,
+                     (long long)nx, (long long)nz, dr, d_ome);
+  HIPCHK(c, hipGetLastError());
+  return LUDVM_OK;
+}
+
+int ludvm_vorticity_f32(ludvm_ctx* c, const float* u, const float* w, size_t nx, size_t nz, double dr, float* ome) {
+  if (!c) return LUDVM_E_ARG;
+  if (nx < 2 || nz < 2) return fail(c, LUDVM_E_ARG, "vorticity needs nx, nz >= 2");
+  if (!u || !w || !ome) return fail(c, LUDVM_E_ARG, "null array");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nt = nx * nz;
+  CHK(ensure(c, c->arena, 3 * Arena::need(nt, 4)));
+  Arena ar(c->arena.p);
+  float* du = ar.take<float>(nt);
+  float* dw = ar.take<float>(nt);
+  float* dome = ar.take<float>(nt);
+  HIPCHK(c, hipMemcpyAsync(du, u, nt * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dw, w, nt * 4, hipMemcpyHostToDevice, c->stream));
+  CHK(ludvm_vorticity_dev_f32(c, du, dw, nx, nz, (float)dr, dome));
+  HIPCHK(c, hipMemcpyAsync(ome, dome, nt * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LUDVM_OK;
+}
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+
+int ludvm_kernel_timing(ludvm_ctx* c, int enable) {
+  if (!c) return LUDVM_E_ARG;
+  c->timing = enable != 0;
+  return LUDVM_OK;
+}
+
+int ludvm_kernel_time_ms(ludvm_ctx* c, int reset, double* avg_ms, long long* launches) {
+  if (!c) return LUDVM_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(drain_timing(c));
+  if (avg_ms) *avg_ms = c->launches ? c->total_ms / (double)c->launches : 0.0;
+  if (launches) *launches = c->launches;
+  if (reset) {
+    c->total_ms = 0.0;
+    c->launches = 0;
+  }
+  return LUDVM_OK;
+}
+
+}  // extern "C"

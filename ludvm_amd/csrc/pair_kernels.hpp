@@ -1,0 +1,378 @@
+// Vatistas-core (n=2) Biot-Savart all-pairs kernels for gfx950 (MI355X, CDNA4).
+//
+// Replaces the O(Np*Nw) NumPy broadcast in LUDVM.induced_velocity
+// (reference LUDVM.py:549-570):
+//     u_p =  sum_w G_w (z_p - z_w) / (2 pi sqrt(r^4 + vc^4))
+//     w_p = -sum_w G_w (x_p - x_w) / (2 pi sqrt(r^4 + vc^4)),   r^2 = dx^2 + dz^2
+//
+// Design:
+//  * one wavefront lane owns TPL targets; the source range is walked in tiles staged in LDS as
+//    SoA (x[], z[], G[]); every lane reads the same LDS address (broadcast ds_read_b128);
+//  * the fp32 arithmetic is packed over SOURCES: one v_pk_* instruction advances two pairs of a
+//    lane (sources j and j+1 against the same target), so targets are duplicated into register
+//    pairs once, outside the loop, and no op_sel broadcast is needed inside it;
+//  * per pair: sub, sub, mul, fma, fma, rsq, mul, fma, fma  (13 FLOP, FMA = 2, rsq = 1);
+//    the 1/(2 pi) factor and the sign of w are applied once per target in the epilogue;
+//  * grid = (target tiles) x (source splits); with more than one split each block writes its
+//    partial (u, w) to a workspace slab and a second, tiny kernel sums the slabs in split order
+//    (bitwise reproducible; no float atomics) and applies the fused epilogue (Euler update).
+//
+// No MFMA: the kernel is pairwise and non-linear in (p, w); there is no contraction to feed a
+// matrix core with.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ludvm {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts, one per SIMD
+constexpr double kInv2PiD = 0.15915494309189533576888;
+// Padding for source slots past the end of the range: far enough that r^4 overflows to +inf, so
+// rsq() returns exactly 0 and the (zero-circulation) slot contributes exactly 0 even when vc = 0
+// (inviscid), yet small enough that dx^2 + dz^2 itself stays finite.
+constexpr float kPadPosF = 3.0e18f;
+constexpr double kPadPosD = 1.0e150;
+
+// Where a launch takes its targets from and where its results go.
+struct PairArgs {
+  // sources (device).  f32: xs, zs, gs (float).  f32x2: + xsl, zsl (lo parts).  f64: double arrays.
+  const void* xs; const void* zs; const void* gs;
+  const float* xsl; const float* zsl;
+  long long ns;
+  // targets: arrays (same typing as sources) or a uniform grid generated in registers
+  const void* xt; const void* zt;
+  const float* xtl; const float* ztl;
+  long long nt;
+  long long grid_nz;          // > 0: target p = (xmin + (p / nz) * dr, zmin + (p % nz) * dr)
+  double xmin, zmin, dr;
+  // results: direct (nsplit == 1) or partial slabs [split][2][nt_pad] (nsplit > 1)
+  void* u; void* w;
+  void* part;
+  long long nt_pad;
+  long long chunk;            // sources per split (a multiple of the LDS tile)
+  double vc4;                 // v_core^4 (0 when inviscid)
+};
+
+__device__ __forceinline__ void grid_point(const PairArgs& a, long long p, double& x, double& z) {
+  const long long i = p / a.grid_nz;
+  const long long j = p - i * a.grid_nz;
+  x = a.xmin + (double)i * a.dr;
+  z = a.zmin + (double)j * a.dr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32, packed over sources.  TPL = targets per lane, TILE = sources per LDS tile.
+// HILO = false: plain fp32 positions.
+// HILO = true : positions are hi+lo fp32 pairs, dx = (xh_p - xh_w) + (xl_p - xl_w); everything
+//               after the difference is plain fp32 (removes the cancellation error of
+//               |x| ~ 50 against a vortex spacing of ~1e-3).
+// ---------------------------------------------------------------------------------------------
+template <int TPL, int TILE, bool HILO>
+__global__ void __launch_bounds__(kBlock)
+pair_f32(PairArgs a) {
+  static_assert(TILE % kBlock == 0, "tile must be a multiple of the block size");
+  __shared__ __attribute__((aligned(16))) float lx[TILE];
+  __shared__ __attribute__((aligned(16))) float lz[TILE];
+  __shared__ __attribute__((aligned(16))) float lg[TILE];
+  __shared__ __attribute__((aligned(16))) float lxl[HILO ? TILE : 4];
+  __shared__ __attribute__((aligned(16))) float lzl[HILO ? TILE : 4];
+
+  const float* __restrict__ xs = static_cast<const float*>(a.xs);
+  const float* __restrict__ zs = static_cast<const float*>(a.zs);
+  const float* __restrict__ gs = static_cast<const float*>(a.gs);
+
+  const int tid = threadIdx.x;
+  const long long t0 = ((long long)blockIdx.x * kBlock) * TPL + tid;  // targets tid, tid+256, ...
+  const long long s_begin = (long long)blockIdx.y * a.chunk;
+  long long s_end = s_begin + a.chunk;
+  if (s_end > a.ns) s_end = a.ns;
+
+  f32x2 xp[TPL], zp[TPL], xpl[TPL], zpl[TPL], au[TPL], aw[TPL];
+#pragma unroll
+  for (int t = 0; t < TPL; ++t) {
+    const long long ti = t0 + (long long)t * kBlock;
+    float x = 0.0f, z = 0.0f, xl = 0.0f, zl = 0.0f;
+    if (ti < a.nt) {
+      if (a.grid_nz > 0) {
+        double xd, zd;
+        grid_point(a, ti, xd, zd);
+        x = (float)xd;
+        z = (float)zd;
+        if (HILO) { xl = (float)(xd - (double)x); zl = (float)(zd - (double)z); }
+      } else {
+        x = static_cast<const float*>(a.xt)[ti];
+        z = static_cast<const float*>(a.zt)[ti];
+        if (HILO) { xl = a.xtl[ti]; zl = a.ztl[ti]; }
+      }
+    }
+    xp[t] = (f32x2){x, x};
+    zp[t] = (f32x2){z, z};
+    xpl[t] = (f32x2){xl, xl};
+    zpl[t] = (f32x2){zl, zl};
+    au[t] = (f32x2){0.0f, 0.0f};
+    aw[t] = (f32x2){0.0f, 0.0f};
+  }
+  const float vc4s = (float)a.vc4;
+  const f32x2 vc4 = {vc4s, vc4s};
+
+  for (long long base = s_begin; base < s_end; base += TILE) {
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int k = 0; k < TILE / kBlock; ++k) {
+      const int l = tid + k * kBlock;
+      const long long si = base + l;
+      const bool ok = si < s_end;
+      lx[l] = ok ? xs[si] : kPadPosF;
+      lz[l] = ok ? zs[si] : kPadPosF;
+      lg[l] = ok ? gs[si] : 0.0f;
+      if (HILO) {
+        lxl[l] = ok ? a.xsl[si] : 0.0f;
+        lzl[l] = ok ? a.zsl[si] : 0.0f;
+      }
+    }
+    __syncthreads();
+
+#pragma unroll 2
+    for (int j = 0; j < TILE; j += 4) {
+      const f32x4 X = *reinterpret_cast<const f32x4*>(&lx[j]);
+      const f32x4 Z = *reinterpret_cast<const f32x4*>(&lz[j]);
+      const f32x4 G = *reinterpret_cast<const f32x4*>(&lg[j]);
+      f32x4 XL, ZL;
+      if (HILO) {
+        XL = *reinterpret_cast<const f32x4*>(&lxl[j]);
+        ZL = *reinterpret_cast<const f32x4*>(&lzl[j]);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x2 xs2 = h ? (f32x2){X.z, X.w} : (f32x2){X.x, X.y};
+        const f32x2 zs2 = h ? (f32x2){Z.z, Z.w} : (f32x2){Z.x, Z.y};
+        const f32x2 gs2 = h ? (f32x2){G.z, G.w} : (f32x2){G.x, G.y};
+        f32x2 xl2, zl2;
+        if (HILO) {
+          xl2 = h ? (f32x2){XL.z, XL.w} : (f32x2){XL.x, XL.y};
+          zl2 = h ? (f32x2){ZL.z, ZL.w} : (f32x2){ZL.x, ZL.y};
+        }
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) {
+          f32x2 dx = xp[t] - xs2;
+          f32x2 dz = zp[t] - zs2;
+          if (HILO) {
+            dx = dx + (xpl[t] - xl2);
+            dz = dz + (zpl[t] - zl2);
+          }
+          f32x2 r2 = dx * dx;
+          r2 = __builtin_elementwise_fma(dz, dz, r2);
+          const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
+          f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+          s = s * gs2;
+          au[t] = __builtin_elementwise_fma(dz, s, au[t]);
+          aw[t] = __builtin_elementwise_fma(dx, s, aw[t]);
+        }
+      }
+    }
+  }
+
+  const float scale = (float)kInv2PiD;
+#pragma unroll
+  for (int t = 0; t < TPL; ++t) {
+    const long long ti = t0 + (long long)t * kBlock;
+    if (ti < a.nt) {
+      const float uu = (au[t].x + au[t].y) * scale;
+      const float ww = -(aw[t].x + aw[t].y) * scale;
+      if (gridDim.y == 1) {
+        static_cast<float*>(a.u)[ti] = uu;
+        static_cast<float*>(a.w)[ti] = ww;
+      } else {
+        float* row = static_cast<float*>(a.part) + (long long)blockIdx.y * 2 * a.nt_pad;
+        row[ti] = uu;
+        row[a.nt_pad + ti] = ww;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp64 throughout (parity / debug mode and the small chord-target calls).  One target per lane.
+// ---------------------------------------------------------------------------------------------
+template <int TILE>
+__global__ void __launch_bounds__(kBlock)
+pair_f64(PairArgs a) {
+  __shared__ __attribute__((aligned(16))) double lx[TILE];
+  __shared__ __attribute__((aligned(16))) double lz[TILE];
+  __shared__ __attribute__((aligned(16))) double lg[TILE];
+
+  const double* __restrict__ xs = static_cast<const double*>(a.xs);
+  const double* __restrict__ zs = static_cast<const double*>(a.zs);
+  const double* __restrict__ gs = static_cast<const double*>(a.gs);
+
+  const int tid = threadIdx.x;
+  const long long ti = (long long)blockIdx.x * kBlock + tid;
+  const long long s_begin = (long long)blockIdx.y * a.chunk;
+  long long s_end = s_begin + a.chunk;
+  if (s_end > a.ns) s_end = a.ns;
+
+  double xp = 0.0, zp = 0.0;
+  if (ti < a.nt) {
+    if (a.grid_nz > 0) {
+      grid_point(a, ti, xp, zp);
+    } else {
+      xp = static_cast<const double*>(a.xt)[ti];
+      zp = static_cast<const double*>(a.zt)[ti];
+    }
+  }
+  double au = 0.0, aw = 0.0;
+  const double vc4 = a.vc4;
+
+  for (long long base = s_begin; base < s_end; base += TILE) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TILE / kBlock; ++k) {
+      const int l = tid + k * kBlock;
+      const long long si = base + l;
+      const bool ok = si < s_end;
+      lx[l] = ok ? xs[si] : kPadPosD;
+      lz[l] = ok ? zs[si] : kPadPosD;
+      lg[l] = ok ? gs[si] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < TILE; ++j) {
+      const double dx = xp - lx[j];
+      const double dz = zp - lz[j];
+      const double r2 = __builtin_fma(dz, dz, dx * dx);
+      const double q = __builtin_fma(r2, r2, vc4);
+      const double s = lg[j] / __builtin_sqrt(q);
+      au = __builtin_fma(dz, s, au);
+      aw = __builtin_fma(dx, s, aw);
+    }
+  }
+
+  if (ti < a.nt) {
+    const double uu = au * kInv2PiD;
+    const double ww = -aw * kInv2PiD;
+    if (gridDim.y == 1) {
+      static_cast<double*>(a.u)[ti] = uu;
+      static_cast<double*>(a.w)[ti] = ww;
+    } else {
+      double* row = static_cast<double*>(a.part) + (long long)blockIdx.y * 2 * a.nt_pad;
+      row[ti] = uu;
+      row[a.nt_pad + ti] = ww;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Finishers: sum the per-split partial slabs in split order (deterministic), then the epilogue.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void sum_splits(const T* part, long long i, long long nt_pad, int nsplit, T& su, T& sw) {
+  su = 0;
+  sw = 0;
+  for (int s = 0; s < nsplit; ++s) {
+    su += part[(long long)s * 2 * nt_pad + i];
+    sw += part[(long long)s * 2 * nt_pad + nt_pad + i];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+finish_sum(const T* part, long long nt, long long nt_pad, int nsplit, T* u, T* w) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nt) return;
+  T su, sw;
+  sum_splits(part, i, nt_pad, nsplit, su, sw);
+  u[i] = su;
+  w[i] = sw;
+}
+
+// fp32 device SoA Euler step: x_out[i] = x[t_first + i] + dt * u_i  (LUDVM.py:1108-1109).
+// src_u/src_w are either the partial slabs (nsplit > 1) or the direct results (nsplit == 1,
+// nt_pad == stride between u and w rows is irrelevant then: pass part = u, and w separately).
+__global__ void __launch_bounds__(kBlock)
+finish_advect_f32(const float* part, long long nt, long long nt_pad, int nsplit, const float* x, const float* z,
+                  long long t_first, float dt, float* x_out, float* z_out) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nt) return;
+  float su, sw;
+  sum_splits(part, i, nt_pad, nsplit, su, sw);
+  x_out[i] = __builtin_fmaf(dt, su, x[t_first + i]);
+  z_out[i] = __builtin_fmaf(dt, sw, z[t_first + i]);
+}
+
+// Split a float64 master position into the fp32 (hi, lo) pair the kernels read.
+__device__ __forceinline__ void split_hilo(double v, float& hi, float& lo) {
+  hi = (float)v;
+  lo = (float)(v - (double)hi);
+}
+
+// Resident-wake Euler step (LUDVM.py:1108-1127): float64 update of the master copy from the summed
+// partials (T = float for the fp32 kernels, double for the fp64 one), refresh of the fp32 mirrors.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+finish_wake_advect(const T* part, long long nt, long long nt_pad, int nsplit, double dt, double* x64, double* z64,
+                   float* xh, float* xl, float* zh, float* zl, double* u_out, double* w_out) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nt) return;
+  T su, sw;
+  sum_splits(part, i, nt_pad, nsplit, su, sw);
+  if (u_out) { u_out[i] = (double)su; w_out[i] = (double)sw; }
+  const double xn = x64[i] + dt * (double)su;
+  const double zn = z64[i] + dt * (double)sw;
+  x64[i] = xn;
+  z64[i] = zn;
+  split_hilo(xn, xh[i], xl[i]);
+  split_hilo(zn, zh[i], zl[i]);
+}
+
+// Refresh the fp32 mirrors of [first, first+count) after a host write of the float64 master.
+__global__ void __launch_bounds__(kBlock)
+refresh_mirrors(long long first, long long count, const double* x64, const double* z64, const double* g64,
+                float* xh, float* xl, float* zh, float* zl, float* g32) {
+  const long long k = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= count) return;
+  const long long i = first + k;
+  split_hilo(x64[i], xh[i], xl[i]);
+  split_hilo(z64[i], zh[i], zl[i]);
+  g32[i] = (float)g64[i];
+}
+
+// float64 -> float32 staging conversion for the stateless host API.
+__global__ void __launch_bounds__(kBlock)
+cvt_f64_to_f32(const double* in, float* hi, float* lo, long long n) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float h, l;
+  split_hilo(in[i], h, l);
+  hi[i] = h;
+  if (lo) lo[i] = l;
+}
+
+__global__ void __launch_bounds__(kBlock)
+cvt_f32_to_f64(const float* in, double* out, long long n) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = (double)in[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vorticity stencil of LUDVM.flowfield (LUDVM.py:1224-1292): ome = dw/dx - du/dz on the uniform
+// grid, centred in the interior, one-sided on edges and corners.  u, w, ome are [nx][nz], z fastest.
+// HBM-bound (reads ~4 neighbours from L2, writes one float).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+vorticity_f32(const float* u, const float* w, long long nx, long long nz, float dr, float* ome) {
+  const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= nx * nz) return;
+  const long long i = p / nz, j = p - i * nz;
+  const long long ip = i + 1 < nx ? i + 1 : i, im = i > 0 ? i - 1 : i;
+  const long long jp = j + 1 < nz ? j + 1 : j, jm = j > 0 ? j - 1 : j;
+  // the reference takes dx, dz from the mesh itself: (ip - im) * dr, (jp - jm) * dr
+  const float dxm = (float)(ip - im) * dr;
+  const float dzm = (float)(jp - jm) * dr;
+  const float dw = w[ip * nz + j] - w[im * nz + j];
+  const float du = u[i * nz + jp] - u[i * nz + jm];
+  ome[p] = dw / dxm - du / dzm;
+}
+
+}  // namespace ludvm

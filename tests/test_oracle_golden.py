@@ -1,0 +1,142 @@
+"""Pins the CPU oracle (oracle/ludvm_oracle.py) against the golden vectors that
+oracle/gen_golden.py produced by running the unmodified reference.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import CONFIG1, grouped, load_golden
+from oracle import ludvm_oracle as O
+
+
+def test_g1_kernel_kats_bit_exact(g1_cases):
+    assert len(g1_cases) >= 19
+    for name, c in g1_cases.items():
+        with np.errstate(all="ignore"):
+            u, w = O.induced_velocity(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], float(c["v_core"]), bool(c["viscous"]))
+        # same arithmetic, same order -> identical bits (NaNs of the inviscid self pair included)
+        np.testing.assert_array_equal(u, c["u"], err_msg=name)
+        np.testing.assert_array_equal(w, c["w"], err_msg=name)
+
+
+def test_g1_row_chunking_is_bit_identical(g1_cases):
+    c = g1_cases["p2048x2048_self_vc065"]
+    u, w = O.induced_velocity(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], float(c["v_core"]), rows_per_chunk=100)
+    np.testing.assert_array_equal(u, c["u"])
+    np.testing.assert_array_equal(w, c["w"])
+
+
+def test_g1_inviscid_self_pair_is_nan(g1_cases):
+    c = g1_cases["p3x3_inviscid_self"]
+    assert np.isnan(c["u"]).any()  # the reference's 0/0
+    assert not np.isnan(c["u"]).all()
+
+
+@pytest.fixture(scope="module")
+def oracle_config1():
+    return O.OracleLUDVM(**CONFIG1)
+
+
+def _check_run(sim, g, tol):
+    assert sim.nt == int(g["nt"]) and sim.itev == int(g["itev"]) and sim.ilev == int(g["ilev"])
+    assert sim.v_core == float(g["v_core"])
+    np.testing.assert_array_equal(sim.LEV_shed, g["LEV_shed"])
+    for name in ("Cl", "Cd", "Cm", "Cn", "Cs", "Fn", "Fs", "L", "D", "M", "LESP", "LESP_prev"):
+        np.testing.assert_allclose(getattr(sim, name), g[name], rtol=0, atol=tol, err_msg=name)
+    np.testing.assert_allclose(sim.circulation["TEV"], g["circ_TEV"], rtol=0, atol=tol)
+    np.testing.assert_allclose(sim.circulation["LEV"], g["circ_LEV"], rtol=0, atol=tol)
+    np.testing.assert_allclose(sim.circulation["bound"], g["circ_bound"], rtol=0, atol=tol)
+    np.testing.assert_allclose(sim.fourier, g["fourier"], rtol=0, atol=tol)
+    for s in g["snap_steps"]:
+        for key in ("TEV", "LEV", "FREE"):
+            np.testing.assert_allclose(sim.path[key][s], g[f"{key}_{s}"], rtol=0, atol=tol, err_msg=f"{key}@{s}")
+
+
+def test_g2_config1_run(oracle_config1, g2):
+    # same float64 operations in the same order: agreement to rounding, through all 400 steps
+    # (phantom LEV slots of non-shedding steps included)
+    _check_run(oracle_config1, g2, tol=1e-10)
+    np.testing.assert_allclose(oracle_config1.alpha, g2["alpha"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(oracle_config1.path["airfoil"][-1], g2["path_airfoil_last"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(oracle_config1.airfoil["theta_panel"], g2["airfoil_theta_panel"], rtol=0, atol=1e-15)
+
+
+def test_g2_invariants(oracle_config1):
+    s = oracle_config1
+    c = s.circulation
+    # Kelvin (LUDVM.py:698-699, 758-762) and |A0| <= LESPcrit after modulation (:949, :959)
+    k = s.itev
+    total = c["bound"][k] + c["TEV"][: k + 1].sum() + c["LEV"][: s.ilev + 1].sum() + np.sum(c["FREE"])
+    assert abs(total - c["IC"]) < 1e-10
+    assert np.max(np.abs(s.LESP)) <= 0.2 + 1e-12
+    # sum of panel circulations ~ bound circulation (:983-984)
+    assert abs(c["airfoil"][k].sum() - c["bound"][k]) < 5e-3 * max(1.0, abs(c["bound"][k]))
+
+
+def test_g3_boundary_trace():
+    """Every induced_velocity call of steps 1-5, 100 and 400 of config 1: same arguments (gather and
+    slice logic incl. phantom slots), same returns."""
+    g3 = load_golden("g3_boundary_trace.npz")
+    want = grouped(g3)
+    n = int(g3["ncalls"])
+    steps = {1, 2, 3, 4, 5, 100, 400}
+    got = []
+
+    class Spy(O.OracleLUDVM):
+        step = None
+
+        def airfoil_downwash(self, circulation, xw, zw, i):
+            self.step = i
+            return super().airfoil_downwash(circulation, xw, zw, i)
+
+        def induced_velocity(self, circulation, xw, zw, xp, zp, viscous=True):
+            u, w = super().induced_velocity(circulation, xw, zw, xp, zp, viscous)
+            if self.step in steps:
+                got.append(dict(step=self.step, g=np.array(circulation), xw=np.array(xw), zw=np.array(zw),
+                                xp=np.array(xp), zp=np.array(zp), u=u, w=w))
+            return u, w
+
+    Spy(**CONFIG1)
+    assert len(got) == n
+    for k in range(n):
+        ref, mine = want[str(k)], got[k]
+        assert int(ref["step"]) == mine["step"]
+        for key in ("g", "xw", "zw", "xp", "zp"):
+            assert ref[key].shape == mine[key].shape, (k, key)
+        tol = 1e-12 if mine["step"] <= 5 else 1e-9
+        for key in ("g", "xw", "zw", "xp", "zp", "u", "w"):
+            np.testing.assert_allclose(mine[key], ref[key], rtol=0, atol=tol, err_msg=f"call {k} {key}")
+
+
+def test_g4_flowfield(oracle_config1):
+    g4 = load_golden("g4_flowfield.npz")
+    s = oracle_config1
+    xmin, xmax, zmin, zmax = g4["box"]
+    s.flowfield(xmin=xmin, xmax=xmax, zmin=zmin, zmax=zmax, dr=float(g4["dr"]), tsteps=list(g4["tsteps"]))
+    np.testing.assert_array_equal(s.x_ff, g4["x_ff"])
+    np.testing.assert_array_equal(s.z_ff, g4["z_ff"])
+    np.testing.assert_allclose(s.u_ff, g4["u_ff"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(s.w_ff, g4["w_ff"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(s.ome_ff, g4["ome_ff"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("fixture,kwargs", [
+    ("g5_ramesh.npz", dict(tf=2, method="Ramesh")),
+    ("g5_alpham.npz", dict(tf=5, alpha_m=5, alpha_max=15)),
+])
+def test_g5_variants(fixture, kwargs):
+    g = load_golden(fixture)
+    sim = O.OracleLUDVM(**dict(CONFIG1, **kwargs))
+    _check_run(sim, g, tol=1e-9)
+
+
+def test_g5_free_vortices():
+    g = load_golden("g5_freevort.npz")
+    sim = O.OracleLUDVM(**dict(CONFIG1, tf=5, circulation_freevort=g["gamma_freevort"], xy_freevort=g["xy_freevort"]))
+    assert sim.n_freevort == 61
+    _check_run(sim, g, tol=1e-9)
+
+
+def test_naca4_camber_formula():
+    x = np.linspace(0, 1, 11)
+    assert np.all(O.naca4_camber("0012", x) == 0)
+    yc = O.naca4_camber("2412", x)
+    assert abs(yc[4] - 0.02) < 1e-15 and yc[0] == 0 and abs(yc[-1]) < 1e-15  # max camber 2 % at x = 0.4
