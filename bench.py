@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Biot-Savart pair-interactions/s of the all-pairs vortex-induction kernel.
+
+    python bench.py                       # 1 GPU, config 3: N = 1e6 synthetic wake, all-pairs call
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus G --steps K --warmup W      # config 4: N = 8e6, sharded
+
+A "step" is one pass of the hot path over the synthetic wake held in HBM:
+  * 1 GPU  (BASELINE config 3): one induced_velocity all-pairs call, N sources x N targets;
+  * G GPUs (BASELINE config 4): one self-advection step of the N = 8e6 wake -- every rank evaluates
+    all N sources on its own N/G targets, Euler-updates them, and one RCCL all-gather republishes
+    the positions (ludvm_amd/sharded.py).  Total work per step is fixed (N^2 pairs): strong scaling.
+value = ordered pair interactions (self pairs count) of all ranks / wall time, max over ranks.
+
+Prints ONE JSON line on rank 0.  Synthetic inputs follow SURVEY.md section 8(d):
+rng = default_rng(20260101); x ~ U(-10,0), z ~ U(-2,2), Gamma ~ N(0,1)/N; v_core = 0.065.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBPS = 8000.0
+FLOP_PER_PAIR = 13                # sub sub mul fma fma rsq mul fma fma (FMA = 2, rsq = 1), SURVEY 8(d)
+V_CORE = 0.065
+DT = 5e-2
+
+
+def synthetic_wake(n):
+    rng = np.random.default_rng(20260101)
+    x = rng.uniform(-10, 0, n)
+    z = rng.uniform(-2, 2, n)
+    g = rng.standard_normal(n) / n
+    return x.astype(np.float32), z.astype(np.float32), g.astype(np.float32)
+
+
+def cpu_baseline(x, z, g, u_gpu, w_gpu, rows, budget_s):
+    """The reference arithmetic as written (float64 NumPy broadcast, oracle/ludvm_oracle.py restating
+    LUDVM.py:549-570) on a bounded sample: the first `rows` targets against all sources, one core."""
+    from oracle import ludvm_oracle as O
+    xs, zs, gs = x.astype(np.float64), z.astype(np.float64), g.astype(np.float64)
+    per_chunk = max(1, int(2.0e7 // len(xs)))   # ~160 MB per [rows, N] float64 temporary
+    done, t0 = 0, time.perf_counter()
+    u = np.empty(rows)
+    w = np.empty(rows)
+    while done < rows and (time.perf_counter() - t0 < budget_s or done == 0):
+        b = min(rows, done + per_chunk)
+        u[done:b], w[done:b] = O.induced_velocity(gs, xs, zs, xs[done:b], zs[done:b], V_CORE)
+        done = b
+    el = time.perf_counter() - t0
+    err = None
+    if u_gpu is not None:
+        scale = max(np.abs(u[:done]).max(), np.abs(w[:done]).max())
+        err = float(max(np.abs(u_gpu[:done] - u[:done]).max(), np.abs(w_gpu[:done] - w[:done]).max()) / scale)
+    return {"value": done * len(xs) / el, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"first {done} targets x all {len(xs)} sources, float64 NumPy broadcast as the reference "
+                      f"writes it (LUDVM.py:549-570), {el:.1f} s; host has {os.cpu_count()} logical CPUs",
+            "gpu_vs_oracle_max_rel_err": err}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["auto", "cfg3", "cfg4"], default="auto")
+    ap.add_argument("--n", type=int, default=0, help="override the number of vortices")
+    ap.add_argument("--tpl", type=int, default=0, help="targets per lane (0 = engine heuristic)")
+    ap.add_argument("--splits", type=int, default=0, help="source splits (0 = engine heuristic)")
+    ap.add_argument("--cpu-rows", type=int, default=2048, help="targets in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work at most")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ludvm_amd import Engine
+    from ludvm_amd.sharded import HipShardKernel, ShardedWake
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    workload = args.workload if args.workload != "auto" else ("cfg3" if world == 1 else "cfg4")
+    n = args.n or (1_000_000 if workload == "cfg3" else 8_000_000)
+    x, z, g = synthetic_wake(n)
+
+    eng = Engine(local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_tuning(args.tpl, args.splits)
+    info = eng.device_info()
+
+    if workload == "cfg3":
+        dx, dz, dg = (torch.from_numpy(a).to(device) for a in (x, z, g))
+        du, dw = torch.empty_like(dx), torch.empty_like(dx)
+
+        def step():
+            eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, dx.data_ptr(), dz.data_ptr(), n, V_CORE,
+                           du.data_ptr(), dw.data_ptr())
+        pairs_per_step = float(n) * float(n)
+        pairs_per_launch = pairs_per_step
+        desc = f"config 3: synthetic wake N={n}, one induced_velocity all-pairs call per step (targets = sources)"
+        scaling = "strong"
+    else:
+        wake = ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device)
+        step = wake.step
+        pairs_per_step = wake.pairs_per_step
+        pairs_per_launch = float(wake.n_loc) * float(wake.n_pad)
+        desc = (f"config 4: synthetic wake N={n}, targets sharded over {world} GPU(s), per step: all-pairs "
+                f"kernel on own N/G targets + Euler update + one RCCL all-gather of positions")
+        scaling = "strong"
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.kernel_timing(True)
+    eng.kernel_time_ms(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = eng.kernel_time_ms(reset=True)
+    eng.kernel_timing(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        value = pairs_per_step * args.steps / elapsed
+        kern_s = kernel_ms * 1e-3
+        achieved_tflops = FLOP_PER_PAIR * pairs_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
+        # algorithmic HBM bytes per launch: 12 B per source read, 8 B per target read, 8 B written
+        ns_l = n if workload == "cfg3" else wake.n_pad
+        nt_l = n if workload == "cfg3" else wake.n_loc
+        alg_bytes = 12.0 * ns_l + 16.0 * nt_l
+        out = {
+            "metric": "biot_savart_pair_interactions_per_s", "value": value, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "n_vortices": n, "v_core": V_CORE, "device": info["name"],
+                       "cu_count": info["cu_count"], "targets_per_lane": args.tpl or "auto",
+                       "source_splits": args.splits or "auto"},
+            "roofline": {
+                "bound": "valu", "kernel": "ludvm::pair_f32 (packed fp32 vector ALU; no MFMA, not HBM-bound)",
+                "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
+                "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": pairs_per_launch,
+                "kernel_ms_avg": kernel_ms, "kernel_launches_timed": launches,
+                "pct_fp32_vector_peak": 100.0 * achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
+                "hbm_algorithmic_bytes_per_launch": alg_bytes,
+                "hbm_achieved_gbps": alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0, "hbm_peak_gbps": HBM_PEAK_GBPS,
+                "traffic": None,
+            },
+        }
+        if workload == "cfg3" and world == 1 and args.cpu_rows > 0:
+            u_gpu = du[: args.cpu_rows].cpu().numpy().astype(np.float64)
+            w_gpu = dw[: args.cpu_rows].cpu().numpy().astype(np.float64)
+            out["cpu_baseline"] = cpu_baseline(x, z, g, u_gpu, w_gpu, args.cpu_rows, args.cpu_budget)
+        elif world == 1 and args.cpu_rows > 0:
+            out["cpu_baseline"] = cpu_baseline(x, z, g, None, None, args.cpu_rows, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,9 +65,10 @@ const char* ludvm_last_error(const ludvm_ctx* ctx);
 /* Device facts for the roofline: CU count, max shader clock (kHz), HBM bytes, name (NUL-terminated). */
 int ludvm_device_info(ludvm_ctx* ctx, int* cu_count, int* clock_khz, long long* hbm_bytes, char* name,
                       int name_len);
-/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) for all
- * subsequent launches; NULL restores the context's own stream. */
-int ludvm_set_stream(ludvm_ctx* ctx, void* hip_stream);
+/* external != 0: use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) for all
+ * subsequent launches -- a NULL handle then means the device's default (null) stream, which is what
+ * torch's default stream is.  external == 0: go back to the context's own stream. */
+int ludvm_set_stream(ludvm_ctx* ctx, void* hip_stream, int external);
 int ludvm_synchronize(ludvm_ctx* ctx);
 /* Launch shape knobs (0 keeps the built-in heuristic): targets per lane {1,2,4}, source splits. */
 int ludvm_set_tuning(ludvm_ctx* ctx, int targets_per_lane, int source_splits);
@@ -103,6 +104,10 @@ int ludvm_advect_dev_f32(ludvm_ctx* ctx, const float* d_xs, const float* d_zs, c
 int ludvm_wake_reserve(ludvm_ctx* ctx, size_t capacity);      /* grow-only; keeps contents */
 int ludvm_wake_clear(ludvm_ctx* ctx);                          /* size := 0 */
 int ludvm_wake_size(ludvm_ctx* ctx, size_t* n);
+/* Drop the vortices past the first n (n <= size).  The phantom LEV slot of a non-shedding step
+ * (LUDVM.py:1112-1118 moves slot ilev although nothing was shed) is appended, advected, read back
+ * and dropped this way. */
+int ludvm_wake_truncate(ludvm_ctx* ctx, size_t n);
 /* Append `count` vortices (new TEV / LEV placement, LUDVM.py:672-681, 788-800). */
 int ludvm_wake_append(ludvm_ctx* ctx, const double* x, const double* z, const double* gamma, size_t count);
 /* Overwrite positions and/or circulation of [first, first+count); NULL leaves that field as is.

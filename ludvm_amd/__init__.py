@@ -1,0 +1,14 @@
+"""ludvm_amd -- MI355X (gfx950) all-pairs vortex-induction engine behind the LUDVM method surface.
+
+    from ludvm_amd import LUDVM
+    sim = LUDVM(t0=0, tf=20, dt=5e-2, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30,
+                LESPcrit=0.2, Naca='0012')
+
+The package holds only what the hot path needs: csrc/ (HIP kernels + the C ABI of
+include/ludvm_hip.h), the ctypes binding, and the host-side mirror of the reference class.
+"""
+from ._ffi import LudvmHipError  # noqa: F401
+from .engine import Engine  # noqa: F401
+from .ludvm import LUDVM, SparseHistory  # noqa: F401
+
+__version__ = "0.1.0"

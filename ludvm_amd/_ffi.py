@@ -1,0 +1,82 @@
+"""ctypes binding of libludvm_hip.so (the C ABI declared in include/ludvm_hip.h).
+
+There is no CPU implementation behind this module: if the shared library is missing or cannot be
+loaded, `load()` raises, and so does every product entry point that needs it.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libludvm_hip.so")
+
+OK, E_ARG, E_HIP, E_NOMEM, E_NODEVICE, E_STATE = range(6)
+PREC_F32, PREC_F32X2, PREC_F64 = 0, 1, 2
+ABI_VERSION = 1
+
+_pd, _pf = POINTER(c_double), POINTER(c_float)
+
+# name -> argtypes; every function returns int except ludvm_last_error (const char*).  Keep in step
+# with include/ludvm_hip.h (tests/test_cabi.py checks the header, this table and the library agree).
+SIGNATURES = {
+    "ludvm_abi_version": [],
+    "ludvm_create": [c_int, POINTER(c_void_p)],
+    "ludvm_destroy": [c_void_p],
+    "ludvm_last_error": [c_void_p],
+    "ludvm_device_info": [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_longlong), c_char_p, c_int],
+    "ludvm_set_stream": [c_void_p, c_void_p, c_int],
+    "ludvm_synchronize": [c_void_p],
+    "ludvm_set_tuning": [c_void_p, c_int, c_int],
+    "ludvm_induce_f64": [c_void_p, _pd, _pd, _pd, c_size_t, _pd, _pd, c_size_t, c_double, c_int, _pd, _pd],
+    "ludvm_induce_f32": [c_void_p, _pf, _pf, _pf, c_size_t, _pf, _pf, c_size_t, c_float, _pf, _pf],
+    "ludvm_induce_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,
+                             c_float, c_void_p, c_void_p],
+    "ludvm_advect_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float,
+                             c_float, c_void_p, c_void_p],
+    "ludvm_wake_reserve": [c_void_p, c_size_t],
+    "ludvm_wake_clear": [c_void_p],
+    "ludvm_wake_size": [c_void_p, POINTER(c_size_t)],
+    "ludvm_wake_truncate": [c_void_p, c_size_t],
+    "ludvm_wake_append": [c_void_p, _pd, _pd, _pd, c_size_t],
+    "ludvm_wake_write": [c_void_p, c_size_t, c_size_t, _pd, _pd, _pd],
+    "ludvm_wake_read": [c_void_p, c_size_t, c_size_t, _pd, _pd, _pd],
+    "ludvm_wake_induce_on_points": [c_void_p, c_size_t, c_size_t, _pd, _pd, c_size_t, c_double, _pd, _pd],
+    "ludvm_wake_advect": [c_void_p, c_double, _pd, _pd, _pd, c_size_t, c_double, c_int, _pd, _pd],
+    "ludvm_flowfield_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, _pd, _pd, _pd, c_size_t,
+                            c_double, _pf, _pf],
+    "ludvm_flowfield_dev_f32": [c_void_p, c_float, c_float, c_float, c_size_t, c_size_t, c_void_p, c_void_p,
+                                c_void_p, c_size_t, c_float, c_void_p, c_void_p],
+    "ludvm_vorticity_f32": [c_void_p, _pf, _pf, c_size_t, c_size_t, c_double, _pf],
+    "ludvm_vorticity_dev_f32": [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_void_p],
+    "ludvm_kernel_timing": [c_void_p, c_int],
+    "ludvm_kernel_time_ms": [c_void_p, c_int, POINTER(c_double), POINTER(c_longlong)],
+}
+
+_lib = None
+
+
+class LudvmHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libludvm_hip error {code}: {message}")
+        self.code = code
+
+
+def load(path=None):
+    """dlopen the engine and set the prototypes.  Raises OSError when the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("LUDVM_HIP_LIB") or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError(f"{p} not found: build it with `make -C ludvm_amd/csrc` (or __graft_entry__.build()); "
+                      "there is no CPU fallback")
+    lib = ctypes.CDLL(p)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_char_p if name == "ludvm_last_error" else c_int
+    if lib.ludvm_abi_version() != ABI_VERSION:
+        raise OSError(f"{p}: ABI version {lib.ludvm_abi_version()} != {ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib

@@ -380,11 +380,14 @@ int ludvm_device_info(ludvm_ctx* c, int* cu_count, int* clock_khz, long long* hb
   return LUDVM_OK;
 }
 
-int ludvm_set_stream(ludvm_ctx* c, void* hip_stream) {
+int ludvm_set_stream(ludvm_ctx* c, void* hip_stream, int external) {
   if (!c) return LUDVM_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  hipStream_t next = external ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  if (next == c->stream) return LUDVM_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // nothing of ours may still be in flight on the old one
+  c->pin_off = 0;
+  c->stream = next;
   return LUDVM_OK;
 }
 
@@ -561,6 +564,13 @@ int ludvm_wake_clear(ludvm_ctx* c) {
 int ludvm_wake_size(ludvm_ctx* c, size_t* n) {
   if (!c || !n) return LUDVM_E_ARG;
   *n = c->wake_n;
+  return LUDVM_OK;
+}
+
+int ludvm_wake_truncate(ludvm_ctx* c, size_t n) {
+  if (!c) return LUDVM_E_ARG;
+  if (n > c->wake_n) return fail(c, LUDVM_E_ARG, "truncate beyond the wake size");
+  c->wake_n = n;
   return LUDVM_OK;
 }
 

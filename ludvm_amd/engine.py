@@ -1,0 +1,206 @@
+"""Thin Python handle on one libludvm_hip context (one GPU, one stream).
+
+Normalises what Python callers pass (any array-like, any dtype, any stride -- the reference's
+induced_velocity takes non-contiguous views and integer circulations, LUDVM.py:549-570, :751) into
+the contiguous float64 / float32 buffers the C ABI takes, and turns status codes into exceptions.
+"""
+import ctypes
+from ctypes import POINTER, byref, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import PREC_F32, PREC_F32X2, PREC_F64, LudvmHipError
+
+PRECISIONS = {"f32": PREC_F32, "f32x2": PREC_F32X2, "f64": PREC_F64}
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+
+
+def _pd(a):
+    return a.ctypes.data_as(POINTER(c_double)) if a is not None else None
+
+
+def _pf(a):
+    return a.ctypes.data_as(POINTER(c_float)) if a is not None else None
+
+
+def _prec(p):
+    if isinstance(p, str):
+        return PRECISIONS[p]
+    return int(p)
+
+
+class Engine:
+    """One HIP context.  Not thread-safe (one host thread at a time), like the reference."""
+
+    def __init__(self, device=0, lib_path=None):
+        self._lib = _ffi.load(lib_path)
+        self._ctx = c_void_p()
+        rc = self._lib.ludvm_create(int(device), byref(self._ctx))
+        if rc != _ffi.OK:
+            self._ctx = c_void_p()
+            raise LudvmHipError(rc, {_ffi.E_NODEVICE: "no usable gfx950 device (MI355X required)",
+                                     _ffi.E_ARG: "bad device ordinal"}.get(rc, "ludvm_create failed"))
+        self.device = int(device)
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != _ffi.OK:
+            msg = self._lib.ludvm_last_error(self._ctx)
+            raise LudvmHipError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.ludvm_destroy(self._ctx)
+            self._ctx = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_info(self):
+        cu, khz, mem = c_int(), c_int(), c_longlong()
+        name = ctypes.create_string_buffer(256)
+        self._check(self._lib.ludvm_device_info(self._ctx, byref(cu), byref(khz), byref(mem), name, 256))
+        return {"cu_count": cu.value, "clock_khz": khz.value, "hbm_bytes": mem.value, "name": name.value.decode()}
+
+    def set_stream(self, hip_stream):
+        """Adopt an external hipStream_t given as an int handle, e.g.
+        torch.cuda.current_stream().cuda_stream -- 0 is the device's default stream (torch's default).
+        None goes back to the context's own stream."""
+        if hip_stream is None:
+            self._check(self._lib.ludvm_set_stream(self._ctx, None, 0))
+        else:
+            self._check(self._lib.ludvm_set_stream(self._ctx, c_void_p(int(hip_stream)), 1))
+
+    def synchronize(self):
+        self._check(self._lib.ludvm_synchronize(self._ctx))
+
+    def set_tuning(self, targets_per_lane=0, source_splits=0):
+        self._check(self._lib.ludvm_set_tuning(self._ctx, int(targets_per_lane), int(source_splits)))
+
+    # -- stateless pair sum ----------------------------------------------------------------------
+    def induce(self, circulation, xw, zw, xp, zp, v_core, precision="f32"):
+        """(u, w) float64 arrays; host arrays in, host arrays out (LUDVM.py:549-570)."""
+        g, xs, zs, xt, zt = _f64(circulation), _f64(xw), _f64(zw), _f64(xp), _f64(zp)
+        if not (len(g) == len(xs) == len(zs)) or len(xt) != len(zt):
+            raise ValueError("induce: source arrays (and target arrays) must have equal lengths")
+        u, w = np.empty(len(xt)), np.empty(len(xt))
+        self._check(self._lib.ludvm_induce_f64(self._ctx, _pd(xs), _pd(zs), _pd(g), len(xs), _pd(xt), _pd(zt), len(xt),
+                                               float(v_core), _prec(precision), _pd(u), _pd(w)))
+        return u, w
+
+    def induce_f32(self, circulation, xw, zw, xp, zp, v_core):
+        g, xs, zs, xt, zt = _f32(circulation), _f32(xw), _f32(zw), _f32(xp), _f32(zp)
+        u, w = np.empty(len(xt), np.float32), np.empty(len(xt), np.float32)
+        self._check(self._lib.ludvm_induce_f32(self._ctx, _pf(xs), _pf(zs), _pf(g), len(xs), _pf(xt), _pf(zt), len(xt),
+                                               float(v_core), _pf(u), _pf(w)))
+        return u, w
+
+    def induce_dev(self, d_xs, d_zs, d_gs, ns, d_xt, d_zt, nt, v_core, d_u, d_w):
+        """Raw device pointers (ints), fp32 SoA; asynchronous on the context stream."""
+        self._check(self._lib.ludvm_induce_dev_f32(self._ctx, d_xs, d_zs, d_gs, ns, d_xt, d_zt, nt, float(v_core),
+                                                   d_u, d_w))
+
+    def advect_dev(self, d_xs, d_zs, d_gs, ns, t_first, nt, v_core, dt, d_x_out, d_z_out):
+        self._check(self._lib.ludvm_advect_dev_f32(self._ctx, d_xs, d_zs, d_gs, ns, t_first, nt, float(v_core),
+                                                   float(dt), d_x_out, d_z_out))
+
+    # -- resident wake ---------------------------------------------------------------------------
+    def wake_reserve(self, capacity):
+        self._check(self._lib.ludvm_wake_reserve(self._ctx, int(capacity)))
+
+    def wake_clear(self):
+        self._check(self._lib.ludvm_wake_clear(self._ctx))
+
+    def wake_size(self):
+        n = c_size_t()
+        self._check(self._lib.ludvm_wake_size(self._ctx, byref(n)))
+        return n.value
+
+    def wake_truncate(self, n):
+        self._check(self._lib.ludvm_wake_truncate(self._ctx, int(n)))
+
+    def wake_append(self, x, z, gamma):
+        x, z, g = _f64(x), _f64(z), _f64(gamma)
+        if not (len(x) == len(z) == len(g)):
+            raise ValueError("wake_append: x, z, gamma must have equal lengths")
+        self._check(self._lib.ludvm_wake_append(self._ctx, _pd(x), _pd(z), _pd(g), len(x)))
+
+    def wake_write(self, first, x=None, z=None, gamma=None):
+        arrs = [None if a is None else _f64(a) for a in (x, z, gamma)]
+        lens = {len(a) for a in arrs if a is not None}
+        if len(lens) != 1:
+            raise ValueError("wake_write: give at least one field; all given fields must have equal lengths")
+        self._check(self._lib.ludvm_wake_write(self._ctx, int(first), lens.pop(), _pd(arrs[0]), _pd(arrs[1]),
+                                               _pd(arrs[2])))
+
+    def wake_read(self, first, count, gamma=False):
+        x, z = np.empty(count), np.empty(count)
+        g = np.empty(count) if gamma else None
+        self._check(self._lib.ludvm_wake_read(self._ctx, int(first), int(count), _pd(x), _pd(z), _pd(g)))
+        return (x, z, g) if gamma else (x, z)
+
+    def wake_induce_on_points(self, src_first, src_count, xp, zp, v_core):
+        xt, zt = _f64(xp), _f64(zp)
+        u, w = np.empty(len(xt)), np.empty(len(xt))
+        self._check(self._lib.ludvm_wake_induce_on_points(self._ctx, int(src_first), int(src_count), _pd(xt), _pd(zt),
+                                                          len(xt), float(v_core), _pd(u), _pd(w)))
+        return u, w
+
+    def wake_advect(self, dt, foil_x, foil_z, foil_dgamma, v_core, precision="f32", return_velocity=False):
+        fx, fz, fg = _f64(foil_x), _f64(foil_z), _f64(foil_dgamma)
+        u = w = None
+        if return_velocity:
+            n = self.wake_size()
+            u, w = np.empty(n), np.empty(n)
+        self._check(self._lib.ludvm_wake_advect(self._ctx, float(dt), _pd(fx), _pd(fz), _pd(fg), len(fx),
+                                                float(v_core), _prec(precision), _pd(u), _pd(w)))
+        return (u, w) if return_velocity else None
+
+    # -- flow field ------------------------------------------------------------------------------
+    def flowfield(self, xmin, zmin, dr, nx, nz, circulation, xw, zw, v_core):
+        """(u, w) float32 [nx, nz] on the grid (xmin + i*dr, zmin + j*dr) (LUDVM.py:1193-1195)."""
+        g, xs, zs = _f64(circulation), _f64(xw), _f64(zw)
+        u, w = np.empty(nx * nz, np.float32), np.empty(nx * nz, np.float32)
+        self._check(self._lib.ludvm_flowfield_f32(self._ctx, float(xmin), float(zmin), float(dr), int(nx), int(nz),
+                                                  _pd(xs), _pd(zs), _pd(g), len(xs), float(v_core), _pf(u), _pf(w)))
+        return u.reshape(nx, nz), w.reshape(nx, nz)
+
+    def flowfield_dev(self, xmin, zmin, dr, nx, nz, d_xs, d_zs, d_gs, ns, v_core, d_u, d_w):
+        self._check(self._lib.ludvm_flowfield_dev_f32(self._ctx, float(xmin), float(zmin), float(dr), int(nx), int(nz),
+                                                      d_xs, d_zs, d_gs, int(ns), float(v_core), d_u, d_w))
+
+    def vorticity(self, u, w, dr):
+        nx, nz = u.shape
+        uu, ww = _f32(u), _f32(w)
+        ome = np.empty(nx * nz, np.float32)
+        self._check(self._lib.ludvm_vorticity_f32(self._ctx, _pf(uu), _pf(ww), nx, nz, float(dr), _pf(ome)))
+        return ome.reshape(nx, nz)
+
+    def vorticity_dev(self, d_u, d_w, nx, nz, dr, d_ome):
+        self._check(self._lib.ludvm_vorticity_dev_f32(self._ctx, d_u, d_w, int(nx), int(nz), float(dr), d_ome))
+
+    # -- measurement -----------------------------------------------------------------------------
+    def kernel_timing(self, enable=True):
+        self._check(self._lib.ludvm_kernel_timing(self._ctx, 1 if enable else 0))
+
+    def kernel_time_ms(self, reset=True):
+        ms, n = c_double(), c_longlong()
+        self._check(self._lib.ludvm_kernel_time_ms(self._ctx, 1 if reset else 0, byref(ms), byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,675 @@
+"""Drop-in `LUDVM` class: the reference's constructor keywords, methods and result attributes
+(jcatalang/LUDVM, LUDVM.py:132-1372), with the O(N^2) Vatistas-core Biot-Savart sums evaluated by
+the gfx950 engine (libludvm_hip.so through ludvm_amd.engine.Engine).
+
+What runs where
+  * device: every induced-velocity evaluation -- wake -> chord points, unit new TEV/LEV -> chord
+    points, wake+foil -> wake (fused with the explicit-Euler update), wake+foil -> flow-field grid,
+    the vorticity stencil;  the wake stays resident on the device across time steps;
+  * host (float64 NumPy, O(Npanels * Ncoeffs) per step): kinematics, vortex placement, the Gamma_TEV /
+    Gamma_LEV solve, Fourier projection A0..A_N, bound-vorticity reconstruction, loads.  These are
+    written as small matrix products (trapezoid weights, cos/sin tables) instead of the reference's
+    interpreted loops (LUDVM.py:770-773, :994-1010).
+
+There is no CPU implementation of the pair sum in this package: without the HIP library and an
+MI355X the constructor raises.
+
+Citations are file:line into the reference's LUDVM.py.
+"""
+import timeit
+
+import numpy as np
+
+from .engine import Engine
+
+__all__ = ["LUDVM", "SparseHistory"]
+
+_FULL_HISTORY_MAX_NT = 2001  # above this the [nt, 2, nt-1] trajectory arrays (LUDVM.py:615-616) are not allocated
+
+
+def naca4_mean_line(digits, x):
+    """NACA 4-digit mean line (m = d0/100 at p = d1/10), x in chord fractions."""
+    m, p = int(digits[0]) / 100.0, int(digits[1]) / 10.0
+    x = np.asarray(x, dtype=float)
+    if m == 0.0 or p == 0.0:
+        return np.zeros_like(x)
+    return np.where(x < p, m / p**2 * (2 * p * x - x**2), m / (1 - p) ** 2 * ((1 - 2 * p) + 2 * p * x - x**2))
+
+
+class SparseHistory:
+    """Trajectory rows kept only for selected time steps (the reference's dense [nt, 2, n] arrays are
+    O(nt^2): 2 x 40 GB at dt = 1e-3, t in [0, 50]).  Indexing follows the dense arrays for the rows
+    that exist: h[i] -> [2, n_i], h[i, 0, :k] -> view; other rows raise KeyError."""
+
+    def __init__(self, nt):
+        self.nt = nt
+        self.rows = {}
+
+    def store(self, i, row):
+        self.rows[int(i)] = row
+
+    def steps(self):
+        return sorted(self.rows)
+
+    def __contains__(self, i):
+        return int(i) in self.rows
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            i, rest = key[0], key[1:]
+        else:
+            i, rest = key, ()
+        i = int(i)
+        if i < 0:
+            i += self.nt
+        if i not in self.rows:
+            raise KeyError(f"time step {i} was not recorded (history='sparse'; recorded: {self.steps()[:8]}...)")
+        row = self.rows[i]
+        return row[rest] if rest else row
+
+
+class LUDVM:
+    """LESP-modulated unsteady discrete vortex method (see the reference's class docstring,
+    LUDVM.py:133-229) on an MI355X.
+
+    Same positional/keyword parameters as the reference constructor (LUDVM.py:231-236) and, like it,
+    the whole simulation runs inside the constructor.  Keyword-only extras:
+      engine     an existing ludvm_amd.engine.Engine to use (default: a new one on `device`)
+      device     HIP device ordinal
+      precision  'f32' (default), 'f32x2' (hi+lo fp32 positions) or 'f64': arithmetic of the
+                 wake-on-wake pair sums; the Npanels-target sums always run in fp64
+      history    'full' (dense path arrays as in the reference), 'sparse' (rows only at
+                 snapshot_steps + last step) or 'auto' (full up to nt = 2001)
+      snapshot_steps  iterable of time-step indices to record when history is sparse
+      run        False builds geometry and kinematics only
+    """
+
+    def __init__(self, t0=0, tf=12, dt=1.5e-2, chord=1, rho=1.225, Uinf=1,
+                 Npoints=80, Ncoeffs=30, LESPcrit=0.2, Naca='0012',
+                 foil_filename=None, G=1, T=2, alpha_m=0,
+                 alpha_max=10, k=0.2 * np.pi, phi=90, h_max=1,
+                 verbose=True, method='Faure',
+                 circulation_freevort=None, xy_freevort=None, *,
+                 engine=None, device=0, precision='f32', history='auto', snapshot_steps=(), run=True):
+        # parameters (LUDVM.py:237-263)
+        self.t0, self.tf, self.dt = t0, tf, dt
+        self.chord, self.rho, self.Uinf = chord, rho, Uinf
+        self.Npoints, self.Ncoeffs = Npoints, Ncoeffs
+        self.piv = 0.25 * chord
+        self.LESPcrit = LESPcrit
+        self.maxerror, self.maxiter, self.epsilon = 1e-10, 50, 1e-4
+        self.xgamma = 0.25
+        self.method = method
+        self.t = np.arange(t0, tf + dt, dt)
+        self.nt = len(self.t)
+        self.verbose = verbose
+        self.dt_star = dt * Uinf / chord
+        self.v_core = 1.3 * self.dt_star * chord
+        self.ilev2 = 0
+        self.alpha_m = alpha_m
+        # free vortices (LUDVM.py:268-277): default is one zero-strength vortex at the origin
+        if circulation_freevort is not None and xy_freevort is not None:
+            self.n_freevort = len(circulation_freevort)
+            self.circulation_freevort = circulation_freevort
+            self.xy_freevort = xy_freevort
+        else:
+            self.n_freevort = 1
+            self.circulation_freevort = np.array([0])
+            self.xy_freevort = np.array([0, 0])[:, np.newaxis]
+
+        if precision not in ('f32', 'f32x2', 'f64'):
+            raise ValueError("precision must be 'f32', 'f32x2' or 'f64'")
+        if history not in ('auto', 'full', 'sparse'):
+            raise ValueError("history must be 'auto', 'full' or 'sparse'")
+        self.precision = precision
+        self.history = ('full' if self.nt <= _FULL_HISTORY_MAX_NT else 'sparse') if history == 'auto' else history
+        self.snapshot_steps = {int(s) for s in snapshot_steps}
+        self.engine = engine if engine is not None else Engine(device)  # raises without the HIP library / GPU
+
+        self.start_time = timeit.default_timer()
+        if Naca is not None:
+            self.airfoil_generation(Naca=Naca)
+        else:
+            self.airfoil_generation(Naca=None, filename=foil_filename)
+        self.motion_sinusoidal(alpha_m=alpha_m, alpha_max=alpha_max, h_max=h_max, k=k, phi=phi, h0=0, x0=0,
+                               motion='cos')
+        if run:
+            self.time_loop()
+            self.compute_coefficients()
+            if self.verbose:
+                print('Elapsed time:', timeit.default_timer() - self.start_time)
+
+    # ------------------------------------------------------------------------------------------
+    # geometry and kinematics (host, run once)
+    # ------------------------------------------------------------------------------------------
+    def airfoil_generation(self, Naca='0012', filename=None, Npoints=None, uniform_spacing='theta'):
+        """Mean line on theta-uniform nodes, panel quarter points and slopes (LUDVM.py:299-380).
+        NACA 4-digit mean lines come from the published formula (the reference takes them from the
+        PyPI package `airfoils`); Selig-format .dat files are averaged upper/lower as at :316-324."""
+        if Npoints is None:
+            Npoints = self.Npoints
+        c = self.chord
+        if Naca is None and filename is not None:
+            xa, etaa = self._mean_line_from_dat(filename, Npoints)
+        else:
+            xs = np.linspace(0.0, 1.0, Npoints)
+            xa, etaa = c * xs, c * naca4_mean_line(Naca, xs)
+        if uniform_spacing == 'theta':
+            theta = np.linspace(0, np.pi, self.Npoints)
+            x = c / 2 * (1 - np.cos(theta))
+            eta = np.interp(x, xa, etaa)
+        else:
+            x, eta = xa, etaa
+            theta = np.arccos(1 - 2 * x / c)
+        x_panel = x[:-1] + self.xgamma * (x[1:] - x[:-1])
+        eta_panel = np.interp(x_panel, x, eta)
+        theta_panel = np.arccos(1 - 2 * x_panel / c)
+
+        def slope(f, s):  # one-sided at the ends; the reference's interior form divides by 2*(s[i+1]-s[i-1])
+            d = np.empty(len(f))
+            d[0] = (f[1] - f[0]) / (s[1] - s[0])
+            d[-1] = (f[-1] - f[-2]) / (s[-1] - s[-2])
+            d[1:-1] = (f[2:] - f[:-2]) / (2 * (s[2:] - s[:-2]))
+            return d
+
+        self.Npoints = len(eta)
+        self.airfoil = {'x': x, 'theta': theta, 'eta': eta,
+                        'detadx': slope(eta, x), 'detadtheta': slope(eta, theta),
+                        'x_panel': x_panel, 'theta_panel': theta_panel, 'eta_panel': eta_panel,
+                        'detadx_panel': slope(eta_panel, x_panel),
+                        'detadtheta_panel': slope(eta_panel, theta_panel)}
+        return None
+
+    def _mean_line_from_dat(self, filename, Npoints):
+        from scipy.interpolate import interp1d
+        pts = []
+        with open(filename) as fh:
+            for line in fh:
+                tok = line.split()
+                if len(tok) == 2:
+                    try:
+                        pts.append((float(tok[0]), float(tok[1])))
+                    except ValueError:
+                        pass
+        pts = np.array([p for p in pts if -0.01 <= p[0] <= 1.01])
+        ile = int(np.argmin(pts[:, 0]))
+        upper, lower = pts[: ile + 1][::-1], pts[ile:]
+        n = int(np.floor(Npoints / 2))
+        xs = np.linspace(0, 1, n)
+        yu = interp1d(upper[:, 0], upper[:, 1], kind='cubic', bounds_error=False, fill_value='extrapolate')(xs)
+        yl = interp1d(lower[:, 0], lower[:, 1], kind='cubic', bounds_error=False, fill_value='extrapolate')(xs)
+        return self.chord * xs, self.chord * 0.5 * (yu + yl)
+
+    def _rigid_body_path(self, xpiv, hpiv, alpha):
+        """Node positions under pitch about the pivot (LUDVM.py:431-448)."""
+        ca, sa = np.cos(-alpha)[:, None], np.sin(-alpha)[:, None]
+        path = np.zeros([self.nt, 2, self.Npoints])
+        path[:, 0, 0] = xpiv - self.piv * ca[:, 0]
+        path[:, 1, 0] = hpiv + self.piv * sa[:, 0]
+        xq, eq = self.airfoil['x'][1:], self.airfoil['eta'][1:]
+        path[:, 0, 1:] = path[:, 0, :1] + ca * xq - sa * eq
+        path[:, 1, 1:] = path[:, 1, :1] + sa * xq + ca * eq
+        gpts = path[:, :, :-1] + self.xgamma * (path[:, :, 1:] - path[:, :, :-1])
+        self.path = {'airfoil': path, 'airfoil_gamma_points': gpts}
+
+    def motion_sinusoidal(self, alpha_m=0, alpha_max=10, h_max=1, k=0.2 * np.pi, phi=90, h0=0, x0=0.25,
+                          motion='cos'):
+        """h(t) = h0 + h_max cos(2 pi f t), alpha(t) = alpha_m + alpha_max cos(2 pi f t + phi),
+        x(t) = x0 - Uinf t  (LUDVM.py:382-457); angles in degrees."""
+        pi, U, t = np.pi, self.Uinf, self.t
+        f = k * U / (2 * pi * self.chord)
+        self.f = f
+        alpha_m, alpha_max, phi = alpha_m * pi / 180, alpha_max * pi / 180, phi * pi / 180
+        wt = 2 * pi * f * t
+        if motion == 'cos':
+            alpha, alpha_dot = alpha_m + alpha_max * np.cos(wt + phi), -alpha_max * 2 * pi * f * np.sin(wt + phi)
+            h, h_dot = h0 + h_max * np.cos(wt), -h_max * 2 * pi * f * np.sin(wt)
+        elif motion == 'sin':
+            alpha, alpha_dot = alpha_m + alpha_max * np.sin(wt + phi), alpha_max * 2 * pi * f * np.cos(wt + phi)
+            h, h_dot = h0 + h_max * np.sin(wt), -h_max * 2 * pi * f * np.cos(wt)
+        else:
+            raise ValueError("motion must be 'cos' or 'sin'")
+        x = x0 - U * t
+        self._rigid_body_path(x, h, alpha)
+        self.phi, self.h_max = phi, h_max
+        self.alpha, self.alpha_dot = alpha, alpha_dot
+        self.alpha_e = alpha - np.arctan2(h_dot, U)
+        self.hpiv, self.h_dot = h, h_dot
+        self.xpiv, self.x_dot = x, -U * np.ones(self.nt)
+        return None
+
+    def motion_plunge(self, G=1, T=2, alpha_m=0, h0=0, x0=0.25):
+        """Plunge manoeuvre V(t) = -Vmax sin^2(pi t / T), constant pitch (LUDVM.py:459-547).  The
+        reference's one-argument np.arctan2 call (:520) raises; the effective angle of attack is
+        taken as alpha - atan2(h_dot, Uinf), as in motion_sinusoidal (:428)."""
+        pi, U, t = np.pi, self.Uinf, self.t
+        alpha_m = alpha_m * pi / 180
+        Vmax, T = G * U, T * self.chord / U
+        self.G, self.T = G, T
+        during = t <= T
+        h = np.where(during, h0 - Vmax * t / 2 + Vmax * T / (4 * pi) * np.sin(2 * pi * t / T), 0.0)
+        if (~during).any() and during.any():
+            h[~during] = h[during][-1]
+        h_dot = np.where(during, -Vmax * np.sin(pi * t / T) ** 2, 0.0)
+        alpha = alpha_m * np.ones(self.nt)
+        x = x0 - U * t
+        self._rigid_body_path(x, h, alpha)
+        self.alpha, self.alpha_dot = alpha, np.zeros(self.nt)
+        self.alpha_e = alpha - np.arctan2(h_dot, U)
+        self.hpiv, self.h_dot = h, h_dot
+        self.xpiv, self.x_dot = x, -U * np.ones(self.nt)
+        self.phi, self.h_max, self.f = 0.0, 0.0, 1.0 / T
+        return None
+
+    # ------------------------------------------------------------------------------------------
+    # the hot path
+    # ------------------------------------------------------------------------------------------
+    def induced_velocity(self, circulation, xw, zw, xp, zp, viscous=True):
+        """Velocity (u, w) induced at points (xp, zp) by vortices (circulation, xw, zw): Vatistas core
+        v_core when `viscous == True`, point vortices otherwise (LUDVM.py:549-570).  Any array-likes
+        in, two new float64 arrays out; evaluated on the GPU in `self.precision`."""
+        v_core = self.v_core if viscous == True else 0  # noqa: E712  (the reference's comparison, :562)
+        return self.engine.induce(circulation, xw, zw, xp, zp, v_core, precision=self.precision)
+
+    def _chord_frame(self, u1, w1, i):
+        a = self.alpha[i]
+        return u1 * np.cos(a) - w1 * np.sin(a), u1 * np.sin(a) + w1 * np.cos(a)
+
+    def _downwash_from(self, u1, w1, i):
+        """W(x, t) from global-frame induced velocities at the bound-vortex points (LUDVM.py:586-593)."""
+        a, ad, hd = self.alpha[i], self.alpha_dot[i], self.h_dot[i]
+        u, w = self._chord_frame(u1, w1, i)
+        af = self.airfoil
+        return af['detadx_panel'] * (self.Uinf * np.cos(a) + hd * np.sin(a) + u - ad * af['eta_panel']) \
+            - self.Uinf * np.sin(a) - ad * (af['x_panel'] - self.piv) + hd * np.cos(a) - w
+
+    def airfoil_downwash(self, circulation, xw, zw, i):
+        """Normal downwash W on the chord at time step i from the given vortices (LUDVM.py:572-595)."""
+        g = self.path['airfoil_gamma_points']
+        u1, w1 = self.induced_velocity(circulation, xw, zw, g[i, 0, :], g[i, 1, :])
+        return self._downwash_from(u1, w1, i)
+
+    # ------------------------------------------------------------------------------------------
+    # time loop
+    # ------------------------------------------------------------------------------------------
+    def _setup_projection(self):
+        """Trapezoid weights on theta_panel and the cos/sin tables: integral(y dtheta) = y @ wq,
+        A_n = Cproj[n] @ (W/U), sum_n A_n sin(n theta_j) = A[1:] @ Ssin."""
+        th = self.airfoil['theta_panel']
+        d = np.diff(th)
+        wq = np.zeros_like(th)
+        wq[:-1] += d / 2
+        wq[1:] += d / 2
+        n = np.arange(self.Ncoeffs)[:, None]
+        cproj = 2 / np.pi * np.cos(n * th[None, :]) * wq
+        cproj[0] = -1 / np.pi * wq
+        self._wq, self._cproj = wq, cproj
+        self._cm1 = (np.cos(th) - 1) * wq
+        self._ssin = np.sin(n[1:] * th[None, :])
+
+    def _record_row(self, i):
+        return self.history == 'full' or i in self.snapshot_steps or i == self.nt - 1
+
+    def time_loop(self, print_dt=50, BCcheck=False):
+        """Time marching (LUDVM.py:597-1171): per step place the new TEV, solve Gamma_TEV (and
+        Gamma_LEV when |A0| reaches LESPcrit), rebuild the bound vorticity, integrate the loads and
+        convect the wake.  `BCcheck` is accepted for signature compatibility; the reference's check
+        (:1144-1161) raises a shape error and has no effect on the results."""
+        pi, U, c, rho, dt = np.pi, self.Uinf, self.chord, self.rho, self.dt
+        eng, vc = self.engine, self.v_core
+        nt, nv, nf, npan = self.nt, self.nt - 1, self.n_freevort, self.Npoints - 1
+        th = self.airfoil['theta']
+        thp = self.airfoil['theta_panel']
+        x_gamma = self.airfoil['x_panel']
+        detadx = self.airfoil['detadx_panel']
+        gpts = self.path['airfoil_gamma_points']
+        foil = self.path['airfoil']
+        self._setup_projection()
+        wq, cproj, cm1, ssin = self._wq, self._cproj, self._cm1, self._ssin
+        dth = th[1:] - th[:-1]
+        one_plus_cos_over_sin = (1 + np.cos(thp)) / np.sin(thp)
+        half_c_sin_dth = c / 2 * np.sin(thp) * dth
+        wx = np.zeros(npan)                       # trapezoid weights on x_gamma (loads, :1071, :1090)
+        dxg = np.diff(x_gamma)
+        wx[:-1] += dxg / 2
+        wx[1:] += dxg / 2
+
+        full = self.history == 'full'
+        P = self.path
+        if full:
+            P['TEV'] = np.zeros([nt, 2, nv])
+            P['LEV'] = np.zeros([nt, 2, nv])
+            P['FREE'] = np.zeros([nt, 2, nf])
+        else:
+            P['TEV'], P['LEV'], P['FREE'] = SparseHistory(nt), SparseHistory(nt), SparseHistory(nt)
+        free0 = np.array(self.xy_freevort, dtype=float).reshape(2, nf)
+        if full:
+            P['FREE'][0] = free0
+        else:
+            P['TEV'].store(0, np.zeros([2, 0]))
+            P['LEV'].store(0, np.zeros([2, 0]))
+            P['FREE'].store(0, free0.copy())
+        C = self.circulation = {'TEV': np.zeros(nv), 'LEV': np.zeros(nv), 'FREE': self.circulation_freevort,
+                                'bound': np.zeros(nv), 'airfoil': np.zeros([nv, npan]),
+                                'gamma_airfoil': np.zeros([nv, npan]), 'Gamma_airfoil': np.zeros([nv, npan])}
+        self.BC = np.zeros([nv, self.Npoints])
+        self.dp = np.zeros([nt, npan])
+        self.Fn, self.Fs, self.L, self.D, self.T, self.M = (np.zeros(nt) for _ in range(6))
+        self.fourier = np.zeros([nt, 2, self.Ncoeffs])
+        self.LESP, self.LESP_prev = np.zeros(nt), np.zeros(nt)
+        A0, A1 = np.sin(self.alpha_m), 0
+        self.fourier[0, 0, :2] = A0, A1
+        g_free = np.asarray(self.circulation_freevort, dtype=float)
+        sum_free = np.sum(C['FREE'])
+        C['IC'] = sum_free + U * c * pi * (A0 + A1 / 2)
+
+        # device wake, in shedding order: FREE first, then each step's TEV (and LEV when shed)
+        eng.wake_clear()
+        eng.wake_reserve(nf + 2 * nv + npan + 2)
+        eng.wake_append(free0[0], free0[1], g_free)
+        tev_slot = np.zeros(nv, dtype=np.int64)
+        lev_slot = np.zeros(nv, dtype=np.int64)
+        sum_tev = sum_lev = 0.0                   # running Kelvin sums (:758-760)
+        last_tev = last_lev = None                # newest shed vortices after their convection
+        itev = ilev = 0
+        lesp_crit = self.LESPcrit
+        LEV_shed = -1 * np.ones(nt)
+
+        for i in range(1, nt):
+            if (i == 1 or i == nt - 1 or i / print_dt == int(i / print_dt)) and self.verbose == True:  # noqa: E712
+                print('Step {} out of {}. Elapsed time {}'.format(i, nt - 1, timeit.default_timer() - self.start_time))
+            xg, zg = gpts[i, 0, :], gpts[i, 1, :]
+            te, le = foil[i, :, -1], foil[i, :, 0]
+
+            # new TEV: first one half a step behind the initial trailing edge, then 1/3 of the way
+            # from the trailing edge to the previous TEV (:672-681)
+            tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
+
+            # existing wake -> chord (T1) and unit new TEV -> chord (T2)  (:743-754)
+            n_wake = nf + itev + ilev
+            u1, w1 = eng.wake_induce_on_points(0, n_wake, xg, zg, vc)
+            T1 = self._downwash_from(u1, w1, i)
+            ut1, wt1 = eng.induce([1.0], [tev_xy[0]], [tev_xy[1]], xg, zg, vc, precision='f64')
+            ut, un = self._chord_frame(ut1, wt1, i)
+            T2 = detadx * ut - un
+            I1, I2 = T1 @ cm1, T2 @ cm1
+            kelvin = sum_tev + sum_lev + sum_free - C['IC']
+            if self.method == 'Ramesh':
+                g_tev = self._newton_tev(T1, T2, kelvin)                         # :683-739
+            elif self.method == 'Faure':
+                g_tev = -(I1 + kelvin) / (1 + I2)                                # :758-760
+            else:
+                raise ValueError("method must be 'Faure' or 'Ramesh'")
+            g_lev = 0.0
+            W = T1 + g_tev * T2
+            A = cproj @ (W / U)
+            C['bound'][itev] = I1 + g_tev * I2 if self.method == 'Faure' else U * c * pi * (A[0] + A[1] / 2)
+            self.fourier[i, 0, :] = A
+            self.fourier[i, 1, :] = (A - self.fourier[i - 1, 0, :]) / dt          # :772-773
+            self.LESP_prev[itev] = A[0]
+
+            shed = abs(A[0]) >= abs(lesp_crit)                                    # :781
+            ul1 = wl1 = None
+            if shed:
+                LEV_shed[i] = ilev
+                lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()  # :788-800
+                lesp_crit = -abs(lesp_crit) if A[0] < 0 else abs(lesp_crit)       # :802-805
+                ul1, wl1 = eng.induce([1.0], [lev_xy[0]], [lev_xy[1]], xg, zg, vc, precision='f64')
+                ult, uln = self._chord_frame(ul1, wl1, i)
+                T3 = detadx * ult - uln
+                I3 = T3 @ cm1
+                J1, J2, J3 = (-1 / pi * (T @ wq) for T in (T1, T2, T3))
+                if self.method == 'Ramesh':
+                    g_tev, g_lev = self._newton_tev_lev(T1, T2, T3, kelvin, lesp_crit, g_tev)   # :807-914
+                else:
+                    g_tev, g_lev = np.linalg.solve(np.array([[1 + I2, 1 + I3], [J2, J3]]),
+                                                   np.array([-(I1 + kelvin), lesp_crit - J1]))  # :944-954
+                W = T1 + g_tev * T2 + g_lev * T3
+                A = cproj @ (W / U)
+                if self.method == 'Faure':
+                    C['bound'][itev] = I1 + g_tev * I2 + g_lev * I3
+                    A[0] = J1 + g_tev * J2 + g_lev * J3                           # :959
+                else:
+                    C['bound'][itev] = U * c * pi * (A[0] + A[1] / 2)
+                self.fourier[i, 0, :] = A       # derivatives keep their pre-LEV values (:963-966)
+                C['LEV'][ilev] = g_lev
+            C['TEV'][itev] = g_tev
+            self.LESP[itev] = A[0]
+
+            # bound vorticity per panel (:987-1010)
+            A0, A1, A2 = A[0], A[1], A[2]
+            A0d, A1d, A2d, A3d = self.fourier[i, 1, :4]
+            gamma = 2 * U * (A0 * one_plus_cos_over_sin + A[1:] @ ssin)
+            dGamma = gamma * half_c_sin_dth
+            C['airfoil'][itev], C['gamma_airfoil'][itev] = dGamma, gamma
+            C['Gamma_airfoil'][itev] = np.cumsum(dGamma)
+
+            # loads (:1035-1090).  The tangential velocity on the chord from the full wake (incl. the
+            # new TEV/LEV with their solved circulations) follows by linearity from u1 and the unit
+            # influences already evaluated: no further pair sum.
+            uc1, wc1 = u1 + g_tev * ut1, w1 + g_tev * wt1
+            if shed:
+                uc1, wc1 = uc1 + g_lev * ul1, wc1 + g_lev * wl1
+            u, _ = self._chord_frame(uc1, wc1, i)
+            a, hd = self.alpha[i], self.h_dot[i]
+            Ueff = U * np.cos(a) + hd * np.sin(a)
+            self.Fn[i] = rho * pi * c * U * (Ueff * (A0 + 0.5 * A1) + c * (3 / 4 * A0d + 1 / 4 * A1d + 1 / 8 * A2d)) \
+                + rho * ((u * gamma) @ wx)
+            self.Fs[i] = rho * pi * c * U**2 * A0**2
+            self.L[i] = self.Fn[i] * np.cos(a) + self.Fs[i] * np.sin(a)
+            self.D[i] = self.Fn[i] * np.sin(a) - self.Fs[i] * np.cos(a)
+            self.T[i] = -self.D[i]
+            self.M[i] = self.piv * self.Fn[i] - rho * pi * c**2 * U * (
+                Ueff * (1 / 4 * A0 + 1 / 4 * A1 - 1 / 8 * A2)
+                + c * (7 / 16 * A0d + 3 / 16 * A1d + 1 / 16 * A2d - 1 / 64 * A3d)) \
+                - rho * ((u * gamma * x_gamma) @ wx)
+
+            # wake roll-up (:1095-1127): shed vortices join the resident wake, then one fused launch
+            # (wake + bound vortices -> every wake vortex, explicit Euler update on the device)
+            record = self._record_row(i)
+            new_x, new_z, new_g = [tev_xy[0]], [tev_xy[1]], [g_tev]
+            tev_slot[itev] = n_wake
+            if shed:
+                lev_slot[ilev] = n_wake + 1
+                new_x.append(lev_xy[0]); new_z.append(lev_xy[1]); new_g.append(g_lev)
+            elif record:
+                # the reference also convects LEV slot `ilev` (zero strength, at the origin) on a
+                # non-shedding step and stores it in path['LEV'][i]; reproduce that row entry
+                new_x.append(0.0); new_z.append(0.0); new_g.append(0.0)
+            eng.wake_append(new_x, new_z, new_g)
+            n_after = n_wake + len(new_x)
+            eng.wake_advect(dt, xg, zg, dGamma, vc, precision=self.precision)
+
+            if record:
+                xs, zs = eng.wake_read(0, n_after)
+                row_t = np.stack([xs[tev_slot[:itev + 1]], zs[tev_slot[:itev + 1]]])
+                lslots = lev_slot[:ilev + 1] if shed else np.append(lev_slot[:ilev], n_after - 1)
+                row_l = np.stack([xs[lslots], zs[lslots]])
+                row_f = np.stack([xs[:nf], zs[:nf]])
+                if full:
+                    P['TEV'][i, :, :itev + 1] = row_t
+                    P['LEV'][i, :, :ilev + 1] = row_l
+                    P['FREE'][i] = row_f
+                else:
+                    P['TEV'].store(i, row_t)
+                    P['LEV'].store(i, row_l)
+                    P['FREE'].store(i, row_f)
+                last_tev = row_t[:, -1].copy()
+                if shed:
+                    last_lev = row_l[:, -1].copy()
+                elif len(new_x) == 2:
+                    eng.wake_truncate(n_after - 1)   # drop the phantom LEV slot
+            else:
+                k = 2 if shed else 1
+                xs, zs = eng.wake_read(n_after - k, k)
+                last_tev = np.array([xs[0], zs[0]])
+                if shed:
+                    last_lev = np.array([xs[1], zs[1]])
+
+            sum_tev += g_tev
+            self.ilev, self.itev, self.LEV_shed = ilev, itev, LEV_shed
+            if shed:
+                sum_lev += g_lev
+                ilev += 1
+            itev += 1
+        return None
+
+    # Newton variants of the reference's 'Ramesh' method.  The downwash is linear in the circulations
+    # of the vortices being shed, W = T1 + G_tev T2 + G_lev T3, so the reference's repeated
+    # airfoil_downwash evaluations (:692, :707, :820, :837, :852) need no further pair sums here.
+    def _kelvin_residual(self, W, kelvin, g_new):
+        A0 = self._cproj[0] @ (W / self.Uinf)
+        A1 = self._cproj[1] @ (W / self.Uinf)
+        return self.Uinf * self.chord * np.pi * (A0 + A1 / 2) + kelvin + g_new, A0
+
+    def _newton_tev(self, T1, T2, kelvin):
+        eps = self.epsilon
+        f, niter, g = 1.0, 1, -1.0
+        while abs(f) > self.maxerror and niter < self.maxiter:
+            f, _ = self._kelvin_residual(T1 + g * T2, kelvin, g)
+            fd, _ = self._kelvin_residual(T1 + (g + eps) * T2, kelvin, g + eps)
+            g = g - f / ((fd - f) / eps)
+            niter += 1
+        if niter >= self.maxiter:
+            print('The solution did not converge during the Newton-Raphson iteration')
+        return g
+
+    def _newton_tev_lev(self, T1, T2, T3, kelvin, lesp_crit, guess):
+        eps = self.epsilon
+        g_tev = g_lev = guess
+        f1 = f2 = 0.1
+        niter = 1
+
+        def res(gt, gl):
+            f, A0 = self._kelvin_residual(T1 + gt * T2 + gl * T3, kelvin, gt + gl)
+            return f, lesp_crit - A0
+
+        while (abs(f1) > self.maxerror or abs(f2) > self.maxerror) and niter < self.maxiter:
+            f1, f2 = res(g_tev, g_lev)
+            f1t, f2t = res(g_tev + eps, g_lev)
+            f1l, f2l = res(g_tev, g_lev + eps)
+            J = np.array([[(f1l - f1) / eps, (f1t - f1) / eps], [(f2l - f2) / eps, (f2t - f2) / eps]])
+            g_lev, g_tev = np.array([g_lev, g_tev]) - np.linalg.solve(J, np.array([f1, f2]))
+            niter += 1
+        if niter >= self.maxiter:
+            print('The solution did not converge when solving the LEV-TEV nonlinear system')
+        return g_tev, g_lev
+
+    def compute_coefficients(self):
+        """Force and moment coefficients (LUDVM.py:1173-1184)."""
+        q = 0.5 * self.rho * self.Uinf**2
+        qc = q * self.chord
+        self.Cp = self.dp / q
+        self.Cn, self.Cs = self.Fn / qc, self.Fs / qc
+        self.Cl, self.Cd, self.Ct = self.L / qc, self.D / qc, self.T / qc
+        self.Cm = self.M / (qc * self.chord)
+        return None
+
+    # ------------------------------------------------------------------------------------------
+    # flow field
+    # ------------------------------------------------------------------------------------------
+    def _flowfield_sources(self, s):
+        """Sources the reference gathers for time step s (LUDVM.py:1202-1215), index quirks kept:
+        TEV/LEV positions from row s-1 with slots [:s+1] / [:ilev+1] (not-yet-shed slots sit at the
+        origin but carry their final circulation), FREE from row s, every LEV dropped when
+        LEV_shed[s] == -1; bound vortices of step s-1."""
+        C, P = self.circulation, self.path
+        g_free = np.asarray(C['FREE'], dtype=float)
+        if s == 0:
+            f0 = P['FREE'][0]
+            return g_free, f0[0], f0[1]
+        ilev = int(self.LEV_shed[s])
+
+        def padded(row, n):
+            out = np.zeros([2, n])
+            m = min(n, row.shape[1])
+            out[:, :m] = row[:, :m]
+            return out
+        tev = padded(P['TEV'][s - 1], s + 1)
+        lev = padded(P['LEV'][s - 1], ilev + 1)
+        free = P['FREE'][s]
+        gp = self.path['airfoil_gamma_points'][s - 1]
+        g = np.concatenate([C['TEV'][:s + 1], C['LEV'][:ilev + 1], g_free, C['airfoil'][s - 1, :]])
+        xw = np.concatenate([tev[0], lev[0], free[0], gp[0]])
+        zw = np.concatenate([tev[1], lev[1], free[1], gp[1]])
+        return g, xw, zw
+
+    def flowfield(self, xmin=-10, xmax=0, zmin=-4, zmax=4, dr=0.02, tsteps=[0, 1, 2]):
+        """Velocity and vorticity on the uniform mesh arange(xmin, xmax, dr) x arange(zmin, zmax, dr)
+        at the requested time steps (LUDVM.py:1186-1298).  The mesh points are generated on the
+        device (x-major, as meshgrid(indexing='ij') ravels, :1194-1195); wake and bound vortices go in
+        one launch; the vorticity stencil (:1224-1292) is a device kernel."""
+        x1, z1 = np.arange(xmin, xmax, dr), np.arange(zmin, zmax, dr)
+        nx, nz = len(x1), len(z1)
+        x, z = np.meshgrid(x1, z1, indexing='ij')
+        nsteps = len(tsteps)
+        u = np.zeros([nsteps, nx, nz])
+        w = np.zeros([nsteps, nx, nz])
+        ome = np.zeros([nsteps, nx, nz])
+        for ii, s in enumerate(tsteps):
+            if self.verbose:
+                print('Flowfield tstep =', s)
+            g, xw, zw = self._flowfield_sources(int(s))
+            uf, wf = self.engine.flowfield(xmin, zmin, dr, nx, nz, g, xw, zw, self.v_core)
+            u[ii], w[ii] = uf, wf
+            ome[ii] = self.engine.vorticity(uf, wf, dr)
+        self.x_ff, self.z_ff = x, z
+        self.u_ff, self.w_ff = u, w
+        self.ome_ff = ome
+        return None
+
+    # ------------------------------------------------------------------------------------------
+    # post-processing
+    # ------------------------------------------------------------------------------------------
+    def animation(self, step=1, ani_interval=10):
+        """Matplotlib animation of airfoil, TEVs, LEVs and free vortices (LUDVM.py:1301-1351); needs
+        history='full'.  matplotlib is imported here, not at module import."""
+        import matplotlib.pyplot as plt
+        from matplotlib.animation import FuncAnimation
+        if self.history != 'full':
+            raise RuntimeError("animation needs history='full'")
+        fig, ax = plt.subplots()
+        ln, = plt.plot([], [], 'k.', animated=True, markersize=2)
+        ln_tev, = plt.plot([], [], 'r*', markersize=1, animated=True)
+        ln_lev, = plt.plot([], [], 'b*', markersize=1, animated=True)
+        ln_free, = plt.plot([], [], 'g*', markersize=1, animated=True)
+        P = self.path
+
+        def init():
+            ax.set_xlim(P['airfoil'][-1, 0, 0], 2)
+            ax.set_ylim(-3, 3)
+            ax.set_aspect('equal')
+            return ln,
+
+        def update(i):
+            ln.set_data(P['airfoil_gamma_points'][i + 1, 0, :], P['airfoil_gamma_points'][i + 1, 1, :])
+            ln_tev.set_data(P['TEV'][i + 1, 0, :i + 1], P['TEV'][i + 1, 1, :i + 1])
+            if self.LEV_shed[i] != -1:
+                self.ilev2 = int(self.LEV_shed[i])
+            if self.ilev2 > 0:
+                ln_lev.set_data(P['LEV'][i + 1, 0, :self.ilev2 + 1], P['LEV'][i + 1, 1, :self.ilev2 + 1])
+            if self.n_freevort != 1:
+                ln_free.set_data(P['FREE'][i + 1, 0, :], P['FREE'][i + 1, 1, :])
+            return ln, ln_tev, ln_lev, ln_free
+
+        ani = FuncAnimation(fig, func=update, frames=np.arange(0, self.nt - 1, step), init_func=init, blit=True,
+                            interval=ani_interval, repeat=False)
+        plt.show()
+        return ani
+
+    def propulsive_efficiency(self, T=None):
+        """Per-period mean thrust over mean power coefficient (LUDVM.py:1353-1372; the reference's bare
+        `Uinf` at :1367 is self.Uinf here)."""
+        if T is None:
+            T = 1 / self.f
+        tt = self.t / T
+        Nt = int(np.floor(tt[-1]))
+        Ctm, Cpm = np.zeros(Nt), np.zeros(Nt)
+        for ii in range(Nt):
+            ind = np.where(np.logical_and(tt >= ii - 1, tt < ii))
+            Ctm[ii] = np.mean(self.Ct[ind])
+            Cpm[ii] = np.mean(abs(self.h_dot[ind] / self.Uinf * self.Cl[ind])
+                              + abs(self.alpha_dot[ind] * self.Cm[ind] * self.chord / self.Uinf))
+        self.tt = tt
+        self.etap = Ctm / Cpm
+        return None

@@ -1,0 +1,80 @@
+"""TEST-ONLY stand-in for ludvm_amd.engine.Engine: same method surface, pair sums by the CPU oracle.
+
+Lets the CPU test tier pin the *host logic* of the drop-in class (vortex placement, Gamma solve,
+Fourier projection, loads, history bookkeeping, flow-field gathers) against the golden vectors
+without a GPU.  It lives under tests/ and is never importable from the product package.
+"""
+import numpy as np
+
+from oracle import ludvm_oracle as O
+
+
+class FakeEngine:
+    def __init__(self):
+        self.x = np.zeros(0)
+        self.z = np.zeros(0)
+        self.g = np.zeros(0)
+        self.calls = {"induce": 0, "points": 0, "advect": 0}
+
+    # stateless
+    def induce(self, circulation, xw, zw, xp, zp, v_core, precision="f32"):
+        self.calls["induce"] += 1
+        with np.errstate(all="ignore"):
+            return O.induced_velocity(np.asarray(circulation, float), xw, zw, xp, zp, v_core)
+
+    # resident wake
+    def wake_clear(self):
+        self.x, self.z, self.g = np.zeros(0), np.zeros(0), np.zeros(0)
+
+    def wake_reserve(self, capacity):
+        pass
+
+    def wake_size(self):
+        return len(self.x)
+
+    def wake_truncate(self, n):
+        assert n <= len(self.x)
+        self.x, self.z, self.g = self.x[:n], self.z[:n], self.g[:n]
+
+    def wake_append(self, x, z, gamma):
+        self.x = np.concatenate([self.x, np.asarray(x, float).reshape(-1)])
+        self.z = np.concatenate([self.z, np.asarray(z, float).reshape(-1)])
+        self.g = np.concatenate([self.g, np.asarray(gamma, float).reshape(-1)])
+
+    def wake_write(self, first, x=None, z=None, gamma=None):
+        for dst, src in ((self.x, x), (self.z, z), (self.g, gamma)):
+            if src is not None:
+                src = np.asarray(src, float).reshape(-1)
+                dst[first:first + len(src)] = src
+
+    def wake_read(self, first, count, gamma=False):
+        s = slice(first, first + count)
+        return (self.x[s].copy(), self.z[s].copy(), self.g[s].copy()) if gamma else (self.x[s].copy(), self.z[s].copy())
+
+    def wake_induce_on_points(self, src_first, src_count, xp, zp, v_core):
+        self.calls["points"] += 1
+        s = slice(src_first, src_first + src_count)
+        return O.induced_velocity(self.g[s], self.x[s], self.z[s], xp, zp, v_core)
+
+    def wake_advect(self, dt, foil_x, foil_z, foil_dgamma, v_core, precision="f32", return_velocity=False):
+        self.calls["advect"] += 1
+        g = np.concatenate([self.g, np.asarray(foil_dgamma, float)])
+        xs = np.concatenate([self.x, np.asarray(foil_x, float)])
+        zs = np.concatenate([self.z, np.asarray(foil_z, float)])
+        u, w = O.induced_velocity(g, xs, zs, self.x, self.z, v_core)
+        self.x = self.x + dt * u
+        self.z = self.z + dt * w
+        return (u, w) if return_velocity else None
+
+    # flow field
+    def flowfield(self, xmin, zmin, dr, nx, nz, circulation, xw, zw, v_core):
+        xg = xmin + np.arange(nx) * dr
+        zg = zmin + np.arange(nz) * dr
+        X, Z = np.meshgrid(xg, zg, indexing="ij")
+        u, w = O.induced_velocity(circulation, xw, zw, X.ravel(), Z.ravel(), v_core, rows_per_chunk=4096)
+        return u.reshape(nx, nz), w.reshape(nx, nz)
+
+    def vorticity(self, u, w, dr):
+        nx, nz = u.shape
+        X, Z = np.meshgrid(np.arange(nx) * dr, np.arange(nz) * dr, indexing="ij")
+        return O.vorticity(u[None], w[None], X, Z)[0]

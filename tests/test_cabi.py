@@ -1,0 +1,61 @@
+"""CPU tier: the C-ABI library loads, exports every symbol include/ludvm_hip.h declares, and the
+ctypes table binds exactly that set.  No compute calls (there is no GPU in this tier)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from ludvm_amd import _ffi
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ludvm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(ludvm_[a-z0-9_]+)\s*\(", text))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(_ffi.LIB_PATH), "run __graft_entry__.build() (make -C ludvm_amd/csrc)"
+    assert os.path.dirname(_ffi.LIB_PATH).endswith(os.path.join("ludvm_amd", "csrc"))
+
+
+def test_header_library_and_binding_agree():
+    declared = _declared_symbols()
+    assert len(declared) >= 27
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    lib = _ffi.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in ludvm_hip.h but not exported"
+    assert lib.ludvm_abi_version() == _ffi.ABI_VERSION
+
+
+def test_every_entry_point_cites_the_reference():
+    text = open(os.path.join(ROOT, "include", "ludvm_hip.h")).read()
+    assert text.count("LUDVM.py:") >= 15
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ludvm_amd import Engine, LUDVM, LudvmHipError
+    with pytest.raises(LudvmHipError):
+        Engine(0)
+    with pytest.raises(LudvmHipError):
+        LUDVM(tf=0.1, verbose=False)   # the product constructor needs the HIP engine
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(OSError):
+        _ffi.load(str(tmp_path / "libludvm_hip.so"))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ludvm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("oracle to cover", "") or f == "sharded.py", f
+                assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,254 @@
+"""GPU tier: parity of the HIP pair kernels with the oracle, through the C ABI (ctypes)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import c_oracle
+from oracle import ludvm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from ludvm_amd import Engine
+    e = Engine(0)
+    assert "gfx950" in e.device_info()["name"]
+    yield e
+    e.close()
+
+
+def _rel(u, w, ur, wr):
+    scale = max(np.abs(ur).max(), np.abs(wr).max(), 1e-300)
+    return max(np.abs(u - ur).max(), np.abs(w - wr).max()) / scale
+
+
+def _kernel_mass(g, xw, zw, xp, zp, vc):
+    """sum_w |Gamma_w K_pw| per target: the natural error scale of an fp32 sum (tier T1)."""
+    dx = xp[:, None] - xw[None, :]
+    dz = zp[:, None] - zw[None, :]
+    k = np.abs(g)[None, :] / (2 * np.pi * np.sqrt((dx * dx + dz * dz) ** 2 + vc**4))
+    return (k * np.abs(dz)).sum(1), (k * np.abs(dx)).sum(1)
+
+
+# tier T1 tolerances, relative to max|u| of the call.  "off50": coordinates offset by -50
+# with separations ~1e-3 -- plain fp32 positions lose the difference there, which is what
+# the hi+lo mode is for; it must meet the O(1)-coordinate tolerance.
+TOL = {"f32": {"vc065": 1e-5, "vc0013": 5e-4, "off50": 2e-3},
+       "f32x2": {"vc065": 1e-5, "vc0013": 1e-5, "off50": 1e-5},
+       "f64": {"vc065": 1e-12, "vc0013": 1e-12, "off50": 1e-12}}
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x2", "f64"])
+def test_g1_golden_kats(eng, g1_cases, precision):
+    for name, c in g1_cases.items():
+        if "inviscid" in name:
+            continue
+        tag = "off50" if "off50" in name else ("vc0013" if name.endswith("vc0013") else "vc065")
+        u, w = eng.induce(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], float(c["v_core"]), precision=precision)
+        assert u.dtype == np.float64 and u.shape == c["u"].shape
+        err = _rel(u, w, c["u"], c["w"])
+        assert err <= TOL[precision][tag], (name, precision, err)
+        if precision != "f64" and not (tag == "off50" and precision == "f32"):
+            mu, mw = _kernel_mass(c["g"].astype(float), c["xw"], c["zw"], c["xp"], c["zp"], float(c["v_core"]))
+            lim = 1e-4 if precision == "f32" else 2e-6
+            assert np.all(np.abs(u - c["u"]) <= lim * mu + 1e-30), name
+            assert np.all(np.abs(w - c["w"]) <= lim * mw + 1e-30), name
+
+
+def test_hilo_positions_remove_the_offset_cancellation(eng, g1_cases):
+    c = g1_cases["p257x1023_off50_vc0013"]   # |x| ~ 55, separations ~ 1e-3, v_core = 1.3e-3
+    e32 = _rel(*eng.induce(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], 1.3e-3, precision="f32"), c["u"], c["w"])
+    e2 = _rel(*eng.induce(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], 1.3e-3, precision="f32x2"), c["u"], c["w"])
+    assert e2 < 1e-5 and e2 < e32
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x2", "f64"])
+def test_inviscid(eng, g1_cases, precision):
+    c = g1_cases["p129x333_inviscid"]
+    u, w = eng.induce(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], 0.0, precision=precision)
+    assert _rel(u, w, c["u"], c["w"]) <= (1e-12 if precision == "f64" else 2e-5)
+    # coincident source/target with v_core = 0: NaN exactly where the reference's 0/0 gives NaN
+    c = g1_cases["p3x3_inviscid_self"]
+    u, w = eng.induce(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], 0.0, precision=precision)
+    assert np.array_equal(np.isnan(u), np.isnan(c["u"])) and np.array_equal(np.isnan(w), np.isnan(c["w"]))
+    ok = ~np.isnan(c["u"])
+    np.testing.assert_allclose(u[ok], c["u"][ok], rtol=1e-5, atol=1e-7)
+
+
+def test_empty_and_ragged_shapes(eng):
+    rng = np.random.default_rng(3)
+    u, w = eng.induce([], [], [], [0.0, 1.0], [0.0, 1.0], 0.065)
+    assert np.array_equal(u, [0, 0]) and np.array_equal(w, [0, 0])
+    u, w = eng.induce([1.0], [0.0], [0.0], [], [], 0.065)
+    assert u.shape == (0,) and w.shape == (0,)
+    for ns in (1, 3, 1023, 1024, 1025, 4097):
+        for nt in (1, 63, 255, 256, 257, 513, 1025):
+            xs, zs, g = rng.uniform(-3, 0, ns), rng.uniform(-1, 1, ns), rng.standard_normal(ns)
+            xt, zt = rng.uniform(-3, 0, nt), rng.uniform(-1, 1, nt)
+            ur, wr = O.induced_velocity(g, xs, zs, xt, zt, 0.065)
+            for prec, tol in (("f32", 2e-5), ("f64", 1e-12)):
+                u, w = eng.induce(g, xs, zs, xt, zt, 0.065, precision=prec)
+                assert _rel(u, w, ur, wr) <= tol, (ns, nt, prec)
+
+
+def test_strided_and_integer_inputs(eng, g1_cases):
+    c = g1_cases["p80x1_int_vc065"]       # circulation = np.array([1]) (int64), LUDVM.py:751
+    assert c["g"].dtype.kind == "i"
+    u, w = eng.induce(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], 0.065, precision="f64")
+    assert _rel(u, w, c["u"], c["w"]) < 1e-12
+    big = np.random.default_rng(1).uniform(-5, 0, (3, 2, 700))
+    gam = np.random.default_rng(2).standard_normal(700)
+    args = (gam[:650], big[1, 0, :650], big[1, 1, :650], big[2, 0, :300], big[2, 1, :300])
+    assert not args[1].flags["C_CONTIGUOUS"] or args[1].base is not None
+    ur, wr = O.induced_velocity(*args, 0.065)
+    assert _rel(*eng.induce(*args, 0.065, precision="f64"), ur, wr) < 1e-12
+
+
+def test_launch_shapes_agree_and_are_reproducible(eng):
+    rng = np.random.default_rng(11)
+    n = 20000
+    xs, zs, g = rng.uniform(-10, 0, n), rng.uniform(-2, 2, n), rng.standard_normal(n) / n
+    ur, wr = c_oracle.induced_velocity(g, xs, zs, xs, zs, 0.065)
+    results = {}
+    try:
+        for tpl in (1, 2, 4):
+            for splits in (1, 3, 16):
+                eng.set_tuning(tpl, splits)
+                u, w = eng.induce(g, xs, zs, xs, zs, 0.065, precision="f32")
+                assert _rel(u, w, ur, wr) < 1e-5, (tpl, splits)
+                u2, w2 = eng.induce(g, xs, zs, xs, zs, 0.065, precision="f32")
+                assert np.array_equal(u, u2) and np.array_equal(w, w2)   # no atomics: bitwise reproducible
+                results[(tpl, splits)] = u
+    finally:
+        eng.set_tuning(0, 0)
+
+
+def test_linearity_and_antisymmetry(eng):
+    rng = np.random.default_rng(21)
+    n = 5000
+    xs, zs = rng.uniform(-10, 0, n), rng.uniform(-2, 2, n)
+    g1, g2 = rng.standard_normal(n), rng.standard_normal(n)
+    u1, w1 = eng.induce(g1, xs, zs, xs, zs, 0.065)
+    u2, w2 = eng.induce(2.0 * g1, xs, zs, xs, zs, 0.065)
+    assert np.array_equal(2.0 * u1, u2) and np.array_equal(2.0 * w1, w2)   # power-of-two scaling is exact
+    ua, wa = eng.induce(g1 + g2, xs, zs, xs, zs, 0.065)
+    ub, wb = eng.induce(g2, xs, zs, xs, zs, 0.065)
+    assert np.abs(ua - (u1 + ub)).max() < 1e-4 * np.abs(ua).max()
+    # K(i->j) = -K(j->i): the linear impulse of self-induction vanishes, sum_i G_i u_i = 0
+    assert abs(np.sum(g1 * u1)) < 1e-5 * np.sum(np.abs(g1 * u1))
+    assert abs(np.sum(g1 * w1)) < 1e-5 * np.sum(np.abs(g1 * w1))
+    # a single vortex induces nothing on itself
+    u, w = eng.induce([3.0], [0.5], [0.25], [0.5], [0.25], 0.065)
+    assert u[0] == 0.0 and w[0] == 0.0
+
+
+def test_host_float32_entry(eng):
+    rng = np.random.default_rng(4)
+    xs, zs, g = rng.uniform(-10, 0, 3000), rng.uniform(-2, 2, 3000), rng.standard_normal(3000)
+    xt, zt = rng.uniform(-10, 0, 700), rng.uniform(-2, 2, 700)
+    u, w = eng.induce_f32(g, xs, zs, xt, zt, 0.065)
+    assert u.dtype == np.float32
+    ur, wr = O.induced_velocity(g.astype(np.float32).astype(float), xs.astype(np.float32).astype(float),
+                                zs.astype(np.float32).astype(float), xt.astype(np.float32).astype(float),
+                                zt.astype(np.float32).astype(float), 0.065)
+    assert _rel(u, w, ur, wr) < 1e-5
+
+
+def test_device_pointer_entries_with_torch(eng):
+    import torch
+    rng = np.random.default_rng(8)
+    n = 30000
+    x, z, g = (rng.uniform(-10, 0, n).astype(np.float32), rng.uniform(-2, 2, n).astype(np.float32),
+               (rng.standard_normal(n) / n).astype(np.float32))
+    dev = torch.device("cuda", 0)
+    dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
+    du, dw = torch.empty_like(dx), torch.empty_like(dx)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, dx.data_ptr(), dz.data_ptr(), n, 0.065,
+                       du.data_ptr(), dw.data_ptr())
+        torch.cuda.synchronize()
+        ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float), x.astype(float),
+                                           z.astype(float), 0.065)
+        assert _rel(du.cpu().numpy(), dw.cpu().numpy(), ur, wr) < 1e-5
+        # fused Euler step on a target sub-range
+        lo, cnt = 1000, 12345
+        xo, zo = torch.empty(cnt, device=dev), torch.empty(cnt, device=dev)
+        eng.advect_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, lo, cnt, 0.065, 0.05, xo.data_ptr(), zo.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(xo.cpu().numpy(), x[lo:lo + cnt] + 0.05 * ur[lo:lo + cnt], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(zo.cpu().numpy(), z[lo:lo + cnt] + 0.05 * wr[lo:lo + cnt], rtol=0, atol=2e-6)
+        # the shard step with a world of one is the same thing
+        from ludvm_amd.sharded import HipShardKernel, ShardedWake
+        wake = ShardedWake(x, z, g, 0.065, 0.05, HipShardKernel(eng), dev)
+        wake.step()
+        xs1, zs1 = wake.positions()
+        np.testing.assert_allclose(xs1, x + 0.05 * ur, rtol=0, atol=2e-6)
+    finally:
+        eng.set_stream(None)
+
+
+def test_flowfield_grid_and_vorticity(eng):
+    rng = np.random.default_rng(13)
+    ns = 2000
+    xs, zs, g = rng.uniform(-10, 0, ns), rng.uniform(-2, 2, ns), rng.standard_normal(ns) / 50
+    xmin, zmin, dr, nx, nz = -10.0, -4.0, 0.125, 80, 64
+    u, w = eng.flowfield(xmin, zmin, dr, nx, nz, g, xs, zs, 0.065)
+    assert u.shape == (nx, nz) and u.dtype == np.float32
+    X, Z = np.meshgrid(np.arange(xmin, 0, dr), np.arange(zmin, 4, dr), indexing="ij")
+    assert X.shape == (nx, nz)
+    ur, wr = O.induced_velocity(g, xs, zs, X.ravel(), Z.ravel(), 0.065, rows_per_chunk=1024)
+    assert _rel(u.ravel(), w.ravel(), ur, wr) < 1e-5
+    ome = eng.vorticity(u, w, dr)
+    omr = O.vorticity(u[None].astype(float), w[None].astype(float), X, Z)[0]
+    np.testing.assert_allclose(ome, omr, rtol=0, atol=1e-4 * np.abs(omr).max())
+    with pytest.raises(Exception):
+        eng.vorticity(u[:1], w[:1], dr)
+
+
+def test_error_reporting(eng):
+    from ludvm_amd import LudvmHipError
+    eng.wake_clear()
+    with pytest.raises(LudvmHipError) as ei:
+        eng.wake_read(0, 5)
+    assert ei.value.code == 1 and "wake" in str(ei.value)
+    with pytest.raises(LudvmHipError):
+        eng.set_tuning(3, 0)
+    with pytest.raises(ValueError):
+        eng.induce([1.0, 2.0], [0.0], [0.0], [0.0], [0.0], 0.065)
+
+
+def test_full_size_config3_properties(eng):
+    """N = 1e6 all-pairs (BASELINE config 3): sampled targets against the C oracle, impulse invariant,
+    exact power-of-two linearity, reproducibility."""
+    import torch
+    n = 1_000_000
+    rng = np.random.default_rng(20260101)
+    x = rng.uniform(-10, 0, n).astype(np.float32)
+    z = rng.uniform(-2, 2, n).astype(np.float32)
+    g = (rng.standard_normal(n) / n).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
+    du, dw = torch.empty_like(dx), torch.empty_like(dx)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        def run(gam):
+            eng.induce_dev(dx.data_ptr(), dz.data_ptr(), gam.data_ptr(), n, dx.data_ptr(), dz.data_ptr(), n, 0.065,
+                           du.data_ptr(), dw.data_ptr())
+            torch.cuda.synchronize()
+            return du.cpu().numpy().copy(), dw.cpu().numpy().copy()
+        u, w = run(dg)
+        u2, w2 = run(dg)
+        assert np.array_equal(u, u2) and np.array_equal(w, w2)
+        sel = rng.choice(n, 1024, replace=False)
+        ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float),
+                                           x[sel].astype(float), z[sel].astype(float), 0.065)
+        assert _rel(u[sel], w[sel], ur, wr) < 1e-5
+        gd = g.astype(float)
+        assert abs(np.sum(gd * u)) < 1e-4 * np.sum(np.abs(gd * u))
+        assert abs(np.sum(gd * w)) < 1e-4 * np.sum(np.abs(gd * w))
+        u4, w4 = run(dg * 4.0)
+        assert np.array_equal(u4, 4.0 * u) and np.array_equal(w4, 4.0 * w)
+    finally:
+        eng.set_stream(None)

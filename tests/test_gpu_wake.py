@@ -1,0 +1,179 @@
+"""GPU tier: resident-wake entry points (backing time_loop) against the oracle, and the drop-in
+LUDVM class end to end against the golden runs."""
+import numpy as np
+import pytest
+
+from conftest import CONFIG1, load_golden
+from oracle import ludvm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from ludvm_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def test_wake_bookkeeping_round_trip(eng):
+    rng = np.random.default_rng(0)
+    eng.wake_clear()
+    assert eng.wake_size() == 0
+    x, z, g = rng.uniform(-60, 0, 5000), rng.uniform(-2, 2, 5000), rng.standard_normal(5000)
+    eng.wake_append(x[:10], z[:10], g[:10])
+    eng.wake_append(x[10:], z[10:], g[10:])          # forces a capacity grow that must keep contents
+    assert eng.wake_size() == 5000
+    xr, zr, gr = eng.wake_read(0, 5000, gamma=True)
+    assert np.array_equal(xr, x) and np.array_equal(zr, z) and np.array_equal(gr, g)   # float64 master: exact
+    eng.wake_write(7, gamma=[42.0])
+    eng.wake_write(100, x=[1.0, 2.0], z=[3.0, 4.0])
+    xr, zr, gr = eng.wake_read(0, 5000, gamma=True)
+    assert gr[7] == 42.0 and list(xr[100:102]) == [1.0, 2.0] and list(zr[100:102]) == [3.0, 4.0]
+    eng.wake_truncate(4000)
+    assert eng.wake_size() == 4000
+    eng.wake_clear()
+
+
+@pytest.mark.parametrize("offset", [0.0, -50.0])
+def test_wake_induce_on_points_is_fp64(eng, offset):
+    rng = np.random.default_rng(1)
+    n = 7001
+    x, z, g = rng.uniform(-10, 0, n) + offset, rng.uniform(-2, 2, n), rng.standard_normal(n)
+    xt = np.linspace(-1, 0, 80) + offset
+    zt = 0.05 * np.sin(np.linspace(0, 3, 80))
+    eng.wake_clear()
+    eng.wake_append(x, z, g)
+    for first, count in ((0, n), (0, n - 1), (5, 1000), (0, 0)):
+        u, w = eng.wake_induce_on_points(first, count, xt, zt, 1.3e-3)
+        ur, wr = O.induced_velocity(g[first:first + count], x[first:first + count], z[first:first + count], xt, zt, 1.3e-3)
+        np.testing.assert_allclose(u, ur, rtol=0, atol=1e-11 * max(1.0, np.abs(ur).max()))
+        np.testing.assert_allclose(w, wr, rtol=0, atol=1e-11 * max(1.0, np.abs(wr).max()))
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 3e-5), ("f32x2", 3e-6), ("f64", 1e-12)])
+def test_wake_advect_is_one_reference_roll_up_step(eng, precision, tol):
+    """wake + bound vortices -> every wake vortex, explicit Euler (LUDVM.py:1095-1127)."""
+    rng = np.random.default_rng(2)
+    n, nf = 3000, 80
+    x, z, g = rng.uniform(-10, 0, n), rng.uniform(-2, 2, n), rng.standard_normal(n) / 30
+    fx, fz, fg = np.linspace(-10.9, -10.0, nf), 0.02 * np.cos(np.linspace(0, 2, nf)), rng.standard_normal(nf) / 100
+    dt, vc = 5e-2, 0.065
+    uw, ww = O.induced_velocity(g, x, z, x, z, vc)
+    uf, wf = O.induced_velocity(fg, fx, fz, x, z, vc)
+    eng.wake_clear()
+    eng.wake_append(x, z, g)
+    u, w = eng.wake_advect(dt, fx, fz, fg, vc, precision=precision, return_velocity=True)
+    scale = max(np.abs(uw + uf).max(), np.abs(ww + wf).max())
+    assert np.abs(u - (uw + uf)).max() <= tol * scale and np.abs(w - (ww + wf)).max() <= tol * scale
+    xn, zn, gn = eng.wake_read(0, n, gamma=True)
+    assert eng.wake_size() == n and np.array_equal(gn, g)      # the foil sources do not stay in the wake
+    np.testing.assert_allclose(xn, x + dt * (uw + uf), rtol=0, atol=tol * scale * dt + 1e-15)
+    np.testing.assert_allclose(zn, z + dt * (ww + wf), rtol=0, atol=tol * scale * dt + 1e-15)
+    # second step without asking for velocities (asynchronous path) continues from the updated state
+    eng.wake_advect(dt, fx, fz, fg, vc, precision=precision)
+    x2, z2 = eng.wake_read(0, n)
+    u2, w2 = O.induced_velocity(np.r_[g, fg], np.r_[xn, fx], np.r_[zn, fz], xn, zn, vc)
+    np.testing.assert_allclose(x2, xn + dt * u2, rtol=0, atol=tol * scale * dt + 1e-15)
+
+
+# ---------------------------------------------------------------------------------------------
+# the drop-in class, end to end
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def g2():
+    return load_golden("g2_config1.npz")
+
+
+def test_time_loop_config1_fp64_mode_tier_T3(eng, g2):
+    """fp64 parity mode: loads within 1e-5 of the reference over all 400 steps of the README case,
+    identical LEV shedding pattern, early wake positions to 1e-9."""
+    from ludvm_amd import LUDVM
+    sim = LUDVM(**CONFIG1, verbose=False, engine=eng, precision="f64")
+    assert (sim.nt, sim.itev, sim.ilev) == (401, 399, 202)
+    assert np.array_equal(sim.LEV_shed, g2["LEV_shed"])
+    for name in ("Cl", "Cd", "Cm"):
+        assert np.abs(getattr(sim, name) - g2[name]).max() <= 1e-5, name
+    np.testing.assert_allclose(sim.circulation["TEV"], g2["circ_TEV"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(sim.fourier, g2["fourier"], rtol=0, atol=1e-4)
+    for s in (1, 2, 10, 50):
+        for key in ("TEV", "LEV", "FREE"):
+            np.testing.assert_allclose(sim.path[key][s], g2[f"{key}_{s}"], rtol=0, atol=1e-9, err_msg=f"{key}@{s}")
+    c = sim.circulation
+    assert abs(c["bound"][399] + c["TEV"].sum() + c["LEV"].sum() - c["IC"]) < 1e-9      # Kelvin
+    assert np.abs(sim.LESP).max() <= 0.2 + 1e-9
+
+
+@pytest.mark.parametrize("precision,win", [
+    ("f32", {50: 1e-5, 75: 1e-3, 100: 1e-1}),
+    ("f32x2", {50: 1e-6, 75: 1e-4, 100: 1e-2}),
+])
+def test_time_loop_config1_fp32_tier_T2(eng, g2, precision, win):
+    """fp32 wake roll-up (chord sums stay fp64): wake positions to 1e-5 through step 50, identical LEV
+    shedding pattern over all 400 steps, loads inside windows that widen with time -- the wake is
+    chaotic, a rounding-level difference grows ~10x every ~12 steps once it rolls up
+    (measured on MI355X: fp32 3.6e-7 / 1.8e-4 / 2.6e-2 and hi+lo 5e-8 / 1.5e-5 / 1.8e-3 for steps
+    < 50 / 75 / 100) -- and late times are compared on the period average only."""
+    from ludvm_amd import LUDVM
+    sim = LUDVM(**CONFIG1, verbose=False, engine=eng, precision=precision)
+    assert np.array_equal(sim.LEV_shed, g2["LEV_shed"])
+    for s in (1, 2, 10, 50):
+        np.testing.assert_allclose(sim.path["TEV"][s], g2[f"TEV_{s}"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(sim.path["LEV"][s], g2[f"LEV_{s}"], rtol=0, atol=1e-5)
+    for name in ("Cl", "Cd", "Cm"):
+        for hi, tol in win.items():
+            assert np.abs(getattr(sim, name)[:hi] - g2[name][:hi]).max() <= tol, (name, hi)
+        assert abs(np.mean(getattr(sim, name)[200:]) - np.mean(g2[name][200:])) <= 5e-2, name
+
+
+def test_flowfield_through_the_class(eng):
+    from ludvm_amd import LUDVM
+    g4 = load_golden("g4_flowfield.npz")
+    sim = LUDVM(**CONFIG1, verbose=False, engine=eng, precision="f64")
+    xmin, xmax, zmin, zmax = g4["box"]
+    sim.flowfield(xmin=xmin, xmax=xmax, zmin=zmin, zmax=zmax, dr=float(g4["dr"]), tsteps=list(g4["tsteps"]))
+    assert np.array_equal(sim.x_ff, g4["x_ff"]) and sim.u_ff.shape == g4["u_ff"].shape
+    for k in (0, 1):      # grid sums run in fp32
+        scale = max(np.abs(g4["u_ff"][k]).max(), np.abs(g4["w_ff"][k]).max(), 1e-12)
+        assert np.abs(sim.u_ff[k] - g4["u_ff"][k]).max() <= 2e-5 * scale + 1e-7
+        assert np.abs(sim.w_ff[k] - g4["w_ff"][k]).max() <= 2e-5 * scale + 1e-7
+        assert np.abs(sim.ome_ff[k] - g4["ome_ff"][k]).max() <= 1e-3 * max(np.abs(g4["ome_ff"][k]).max(), 1e-9) + 1e-6
+
+
+@pytest.mark.parametrize("fixture,kwargs,tol", [
+    ("g5_ramesh.npz", dict(tf=2, method="Ramesh"), 1e-7),
+    ("g5_alpham.npz", dict(tf=5, alpha_m=5, alpha_max=15), 1e-7),
+])
+def test_variants_fp64(eng, fixture, kwargs, tol):
+    from ludvm_amd import LUDVM
+    g = load_golden(fixture)
+    sim = LUDVM(**dict(CONFIG1, **kwargs), verbose=False, engine=eng, precision="f64")
+    assert np.array_equal(sim.LEV_shed, g["LEV_shed"])
+    for name in ("Cl", "Cd", "Cm", "LESP"):
+        assert np.abs(getattr(sim, name) - g[name]).max() <= tol, name
+
+
+def test_free_vortices_fp64(eng):
+    from ludvm_amd import LUDVM
+    g = load_golden("g5_freevort.npz")
+    sim = LUDVM(**dict(CONFIG1, tf=5, circulation_freevort=g["gamma_freevort"], xy_freevort=g["xy_freevort"]),
+                verbose=False, engine=eng, precision="f64")
+    assert np.array_equal(sim.LEV_shed, g["LEV_shed"])
+    for name in ("Cl", "Cd", "Cm"):
+        assert np.abs(getattr(sim, name) - g[name]).max() <= 1e-6, name
+    np.testing.assert_allclose(sim.path["FREE"][10], g["FREE_10"], rtol=0, atol=1e-9)
+
+
+def test_public_induced_velocity_and_downwash(eng, g1_cases):
+    from ludvm_amd import LUDVM
+    sim = LUDVM(**dict(CONFIG1, tf=0.5), verbose=False, engine=eng, precision="f64")
+    c = g1_cases["p80x603_vc065"]
+    u, w = sim.induced_velocity(c["g"], c["xw"], c["zw"], c["xp"], c["zp"])
+    np.testing.assert_allclose(u, c["u"], rtol=0, atol=1e-12)
+    ref = O.OracleLUDVM(**dict(CONFIG1, tf=0.5))
+    W = sim.airfoil_downwash(c["g"], c["xw"], c["zw"], 5)
+    np.testing.assert_allclose(W, ref.airfoil_downwash(c["g"], c["xw"], c["zw"], 5), rtol=0, atol=1e-11)
+    c2 = g1_cases["p129x333_inviscid"]
+    u, w = sim.induced_velocity(c2["g"], c2["xw"], c2["zw"], c2["xp"], c2["zp"], viscous=False)
+    np.testing.assert_allclose(u, c2["u"], rtol=1e-10, atol=1e-12)

@@ -1,0 +1,129 @@
+"""CPU tier: host logic of the drop-in LUDVM class (ludvm_amd/ludvm.py) against the golden vectors,
+with the pair sums served by tests/fake_engine.FakeEngine (oracle arithmetic, float64).  The GPU
+tier (tests/test_gpu_*.py) repeats these comparisons through the real HIP engine."""
+import numpy as np
+import pytest
+
+from conftest import CONFIG1, load_golden
+from fake_engine import FakeEngine
+from ludvm_amd.ludvm import LUDVM, SparseHistory
+
+
+@pytest.fixture(scope="module")
+def sim1():
+    return LUDVM(**CONFIG1, verbose=False, engine=FakeEngine())
+
+
+def _compare(sim, g, tol_loads, tol_early_pos, early_steps):
+    assert sim.nt == int(g["nt"]) and sim.itev == int(g["itev"]) and sim.ilev == int(g["ilev"])
+    np.testing.assert_array_equal(sim.LEV_shed, g["LEV_shed"])
+    for name in ("Cl", "Cd", "Cm", "Fn", "Fs", "M", "LESP", "LESP_prev"):
+        np.testing.assert_allclose(getattr(sim, name), g[name], rtol=0, atol=tol_loads, err_msg=name)
+    np.testing.assert_allclose(sim.circulation["TEV"], g["circ_TEV"], rtol=0, atol=tol_loads)
+    np.testing.assert_allclose(sim.circulation["LEV"], g["circ_LEV"], rtol=0, atol=tol_loads)
+    np.testing.assert_allclose(sim.circulation["bound"], g["circ_bound"], rtol=0, atol=tol_loads)
+    np.testing.assert_allclose(sim.fourier, g["fourier"], rtol=0, atol=10 * tol_loads)
+    for s in g["snap_steps"]:
+        if s <= early_steps:
+            for key in ("TEV", "LEV", "FREE"):
+                np.testing.assert_allclose(sim.path[key][s], g[f"{key}_{s}"], rtol=0, atol=tol_early_pos,
+                                           err_msg=f"{key}@{s}")
+
+
+def test_config1_matches_reference(sim1, g2):
+    # The host side uses matrix forms (trapezoid weights, cumsum) instead of the reference's loops, so
+    # results differ from it by rounding only; the run is chaotic, which turns 1e-16 into
+    # ~1e-6 on the loads by step 400 and O(0.1) on late wake positions.  Tier T3 tolerance: 1e-5.
+    _compare(sim1, g2, tol_loads=1e-5, tol_early_pos=1e-9, early_steps=100)
+    # rows of the dense history include the phantom LEV slot of non-shedding steps
+    np.testing.assert_allclose(sim1.path["LEV"][2], g2["LEV_2"], rtol=0, atol=1e-12)
+
+
+def test_config1_uses_one_point_sum_per_step(sim1):
+    # 400 steps: one wake->chord sum and one fused roll-up per step; unit TEV (+ LEV on 202 steps)
+    eng = sim1.engine
+    assert eng.calls["points"] == 400 and eng.calls["advect"] == 400
+    assert eng.calls["induce"] == 400 + 202
+
+
+def test_public_methods_match_reference_signatures(sim1, g1_cases):
+    c = g1_cases["p80x603_vc065"]
+    sim1_v = sim1.v_core
+    assert sim1_v == 0.065
+    u, w = sim1.induced_velocity(c["g"], c["xw"], c["zw"], c["xp"], c["zp"])
+    np.testing.assert_array_equal(u, c["u"])
+    assert u.dtype == np.float64 and u.shape == (80,)
+    # airfoil_downwash(circulation, xw, zw, i) -> W[Npoints-1]
+    W = sim1.airfoil_downwash(c["g"], c["xw"], c["zw"], 5)
+    assert W.shape == (80,)
+
+
+def test_flowfield_matches_reference(sim1):
+    g4 = load_golden("g4_flowfield.npz")
+    xmin, xmax, zmin, zmax = g4["box"]
+    sim1.flowfield(xmin=xmin, xmax=xmax, zmin=zmin, zmax=zmax, dr=float(g4["dr"]), tsteps=list(g4["tsteps"]))
+    np.testing.assert_array_equal(sim1.x_ff, g4["x_ff"])
+    np.testing.assert_array_equal(sim1.z_ff, g4["z_ff"])
+    # step 0 and 50 are before the chaotic divergence bites; step 200 is compared loosely
+    for k, tol in ((0, 1e-10), (1, 1e-6)):
+        np.testing.assert_allclose(sim1.u_ff[k], g4["u_ff"][k], rtol=0, atol=tol)
+        np.testing.assert_allclose(sim1.w_ff[k], g4["w_ff"][k], rtol=0, atol=tol)
+        np.testing.assert_allclose(sim1.ome_ff[k], g4["ome_ff"][k], rtol=0, atol=100 * tol)
+    assert sim1.u_ff.shape == g4["u_ff"].shape
+
+
+@pytest.mark.parametrize("fixture,kwargs", [
+    ("g5_ramesh.npz", dict(tf=2, method="Ramesh")),
+    ("g5_alpham.npz", dict(tf=5, alpha_m=5, alpha_max=15)),
+])
+def test_variants(fixture, kwargs):
+    g = load_golden(fixture)
+    sim = LUDVM(**dict(CONFIG1, **kwargs), verbose=False, engine=FakeEngine())
+    _compare(sim, g, tol_loads=1e-7, tol_early_pos=1e-9, early_steps=10)
+
+
+def test_free_vortices():
+    g = load_golden("g5_freevort.npz")
+    sim = LUDVM(**dict(CONFIG1, tf=5, circulation_freevort=g["gamma_freevort"], xy_freevort=g["xy_freevort"]),
+                verbose=False, engine=FakeEngine())
+    assert sim.n_freevort == 61
+    _compare(sim, g, tol_loads=1e-6, tol_early_pos=1e-9, early_steps=10)
+
+
+def test_sparse_history_rows_equal_dense_rows(sim1):
+    sp = LUDVM(**CONFIG1, verbose=False, engine=FakeEngine(), history="sparse", snapshot_steps=[1, 10, 49, 50])
+    assert isinstance(sp.path["TEV"], SparseHistory)
+    assert sp.path["TEV"].steps() == [0, 1, 10, 49, 50, 400]
+    for s in (1, 10, 50):
+        np.testing.assert_allclose(sp.path["TEV"][s], sim1.path["TEV"][s, :, :s], rtol=0, atol=1e-9)
+        k = min(3, s)
+        np.testing.assert_allclose(sp.path["TEV"][s, 0, :k], sim1.path["TEV"][s, 0, :k], rtol=0, atol=1e-9)
+    with pytest.raises(KeyError):
+        sp.path["TEV"][7]
+    np.testing.assert_allclose(sp.Cl[:100], sim1.Cl[:100], rtol=0, atol=1e-9)
+    # flow field from sparse rows needs rows s-1 and s
+    sp.verbose = False
+    sp.flowfield(dr=0.5, tsteps=[0, 50])
+    sim1.flowfield(dr=0.5, tsteps=[0, 50])
+    np.testing.assert_allclose(sp.u_ff, sim1.u_ff, rtol=0, atol=1e-8)
+    with pytest.raises(KeyError):
+        sp.flowfield(dr=0.5, tsteps=[30])
+
+
+def test_constructor_validation():
+    with pytest.raises(ValueError):
+        LUDVM(**CONFIG1, engine=FakeEngine(), precision="bf16")
+    with pytest.raises(ValueError):
+        LUDVM(**CONFIG1, engine=FakeEngine(), history="ring")
+    s = LUDVM(**CONFIG1, engine=FakeEngine(), verbose=False, run=False)
+    assert s.nt == 401 and s.history == "full" and s.path["airfoil"].shape == (401, 2, 81)
+    with pytest.raises(ValueError):
+        LUDVM(**dict(CONFIG1, method="Newton", tf=0.2), engine=FakeEngine(), verbose=False)
+
+
+def test_plunge_and_efficiency_run():
+    s = LUDVM(**dict(CONFIG1, tf=1), engine=FakeEngine(), verbose=False)
+    s.propulsive_efficiency(T=0.5)          # the reference raises NameError here (LUDVM.py:1367)
+    assert s.etap.shape == (2,)
+    s.motion_plunge(G=1, T=2, alpha_m=4)    # the reference raises TypeError here (LUDVM.py:520)
+    assert s.alpha_e.shape == (s.nt,) and np.all(np.isfinite(s.alpha_e))
