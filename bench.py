@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["auto", "cfg3", "cfg4"], default="auto")
-    ap.add_argument("--n", type=int, default=0, help="override the number of vortices")
+    ap.add_argument("--vortices", type=int, default=0, help="override the number of vortices")
     ap.add_argument("--tpl", type=int, default=0, help="targets per lane (0 = engine heuristic)")
     ap.add_argument("--splits", type=int, default=0, help="source splits (0 = engine heuristic)")
     ap.add_argument("--cpu-rows", type=int, default=2048, help="targets in the CPU baseline sample (0 = skip)")
@@ -95,16 +95,23 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal on a one-GPU box (not a measurement): LUDVM_BENCH_BACKEND=gloo lets several ranks share
+    # a card so the multi-rank control flow can be exercised; the driver's runs use RCCL, one GPU each.
+    backend = os.environ.get("LUDVM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     workload = args.workload if args.workload != "auto" else ("cfg3" if world == 1 else "cfg4")
-    n = args.n or (1_000_000 if workload == "cfg3" else 8_000_000)
+    n = args.vortices or (1_000_000 if workload == "cfg3" else 8_000_000)
     x, z, g = synthetic_wake(n)
 
-    eng = Engine(local_rank)
+    eng = Engine(dev_index)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_tuning(args.tpl, args.splits)
     info = eng.device_info()
@@ -165,7 +172,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "n_vortices": n, "v_core": V_CORE, "device": info["name"],
+            "config": {"workload": desc, "collective_backend": backend if world > 1 else None, "n_vortices": n, "v_core": V_CORE, "device": info["name"],
                        "cu_count": info["cu_count"], "targets_per_lane": args.tpl or "auto",
                        "source_splits": args.splits or "auto"},
             "roofline": {
