@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--vortices", type=int, default=0, help="override the number of vortices")
     ap.add_argument("--tpl", type=int, default=0, help="targets per lane (0 = engine heuristic)")
     ap.add_argument("--splits", type=int, default=0, help="source splits (0 = engine heuristic)")
+    ap.add_argument("--symmetric", type=int, choices=[0, 1], default=1,
+                    help="1: self-interaction launches use the symmetric kernel (each unordered pair once); 0: direct")
     ap.add_argument("--cpu-rows", type=int, default=2048, help="targets in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work at most")
     args = ap.parse_args()
@@ -114,8 +116,11 @@ def main():
     eng = Engine(dev_index)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_tuning(args.tpl, args.splits)
+    eng.set_symmetric(args.symmetric)
     info = eng.device_info()
 
+    # the symmetric kernel serves launches whose targets are exactly the sources (1-GPU configs)
+    symmetric = bool(args.symmetric) and world == 1 and n >= 16384
     if workload == "cfg3":
         dx, dz, dg = (torch.from_numpy(a).to(device) for a in (x, z, g))
         du, dw = torch.empty_like(dx), torch.empty_like(dx)
@@ -173,10 +178,14 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "collective_backend": backend if world > 1 else None, "n_vortices": n, "v_core": V_CORE, "device": info["name"],
-                       "cu_count": info["cu_count"], "targets_per_lane": args.tpl or "auto",
+                       "cu_count": info["cu_count"], "kernel_variant": "symmetric" if symmetric else "direct", "targets_per_lane": args.tpl or "auto",
                        "source_splits": args.splits or "auto"},
             "roofline": {
-                "bound": "valu", "kernel": "ludvm::pair_f32 (packed fp32 vector ALU; no MFMA, not HBM-bound)",
+                "bound": "valu",
+                "kernel": ("ludvm::pair_sym_f32 (each unordered pair once: 9 executed FLOP per ordered pair; "
+                           "packed fp32 vector ALU; no MFMA, not HBM-bound)") if symmetric else
+                          "ludvm::pair_f32 (direct, packed fp32 vector ALU; no MFMA, not HBM-bound)",
+                "executed_flop_per_pair": 9 if symmetric else 13,
                 "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
                 "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": pairs_per_launch,

@@ -73,6 +73,12 @@ int ludvm_synchronize(ludvm_ctx* ctx);
 /* Launch shape knobs (0 keeps the built-in heuristic): targets per lane {1,2,4}, source splits. */
 int ludvm_set_tuning(ludvm_ctx* ctx, int targets_per_lane, int source_splits);
 
+/* Self-interaction launches (targets are exactly the sources: wake roll-up, all-pairs calls on one
+ * array) may use the symmetric kernel, which evaluates each unordered pair once (K(i->j) = -K(j->i))
+ * and accumulates with float atomics: ~1.4x faster, reproducible to rounding but not bitwise.
+ * mode 0 = never (direct kernel, bitwise reproducible), 1 = automatic (default; fp32, N >= 16384). */
+int ludvm_set_symmetric(ludvm_ctx* ctx, int mode);
+
 /* ---- stateless pair sum: backs LUDVM.induced_velocity (LUDVM.py:549-570) ------------------ */
 
 /* u[p] =  sum_w g[w]*(zt[p]-zs[w]) / (2 pi sqrt(r^4 + vcore^4))
@@ -155,8 +161,8 @@ int ludvm_vorticity_dev_f32(ludvm_ctx* ctx, const float* d_u, const float* d_w, 
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 
-/* Average device time (ms) of the pair kernel launches (main kernel only, not the split
- * reduction) issued since the last call with reset != 0, measured with HIP events on the stream the
+/* Average device time (ms) of the pair kernel launches (main kernel only -- direct or symmetric --
+ * not the split reduction / finisher) issued since the last call with reset != 0, measured with HIP events on the stream the
  * kernel is launched on; *launches = number of launches averaged.  Timing is off until
  * ludvm_kernel_timing(ctx, 1). */
 int ludvm_kernel_timing(ludvm_ctx* ctx, int enable);

@@ -3,6 +3,7 @@
 // either runs the HIP kernels or returns an error code.
 #include "../../include/ludvm_hip.h"
 #include "pair_kernels.hpp"
+#include "pair_sym_kernels.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -37,8 +38,10 @@ struct ludvm_ctx {
 
   int tune_tpl = 0;
   int tune_split = 0;
+  int sym_mode = 1;
 
   Buf part;   // partial slabs of the split reduction
+  Buf acc;    // raw (u, w) sums of the symmetric kernel: [2][nt_pad] floats
   Buf arena;  // staging for the host-pointer entry points
   char* pin = nullptr;  // pinned host ring for small uploads from entry points that do not synchronize
   size_t pin_off = 0;
@@ -274,6 +277,41 @@ int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, i
   return LUDVM_OK;
 }
 
+constexpr long long kSymMinN = 16384;   // below this the direct kernel's launch is as fast
+constexpr int kSymT = 4;                // vortices per lane of the symmetric kernel (tile = 256)
+constexpr long long kSymTargetWaves = 65536;
+
+bool use_symmetric(const ludvm_ctx* c, long long n) { return c->sym_mode == 1 && n >= kSymMinN; }
+
+// Symmetric self-interaction of (x, z, g)[0, n): zero the accumulators, run the kernel.  The raw sums
+// are left in c->acc as [acc_u | acc_w], each nt_pad floats.
+int launch_sym(ludvm_ctx* c, const float* x, const float* z, const float* g, long long n, double vc4, long long* nt_pad_out) {
+  const long long nt_pad = (n + 63) / 64 * 64;
+  CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(float)));
+  HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(float), c->stream));
+  SymArgs a{};
+  a.x = x; a.z = z; a.g = g; a.n = n;
+  const long long W = 64LL * kSymT;
+  a.ntiles = (n + W - 1) / W;
+  a.dmax = (a.ntiles - 1) / 2;
+  const long long dtot = a.dmax + ((a.ntiles % 2 == 0 && a.ntiles > 1) ? 1 : 0);
+  long long ys = c->tune_split > 0 ? c->tune_split : (kSymTargetWaves + a.ntiles - 1) / a.ntiles;
+  ys = std::max<long long>(1, std::min<long long>(std::min<long long>(ys, 64), std::max<long long>(dtot, 1)));
+  a.ysplit = (int)ys;
+  a.acc_u = static_cast<float*>(c->acc.p);
+  a.acc_w = a.acc_u + nt_pad;
+  a.vc4 = (float)vc4;
+  const long long waves = a.ntiles * ys;
+  TimedLaunch t{};
+  bool active = false;
+  CHK(timed_begin(c, t, active));
+  hipLaunchKernelGGL((pair_sym_f32<kSymT>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  CHK(timed_end(c, t, active));
+  *nt_pad_out = nt_pad;
+  return LUDVM_OK;
+}
+
 bool valid_precision(int p) { return p == LUDVM_PREC_F32 || p == LUDVM_PREC_F32X2 || p == LUDVM_PREC_F64; }
 
 int wake_grow(ludvm_ctx* c, size_t capacity) {
@@ -358,7 +396,7 @@ int ludvm_destroy(ludvm_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& t : c->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   for (auto& t : c->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
-  void* bufs[] = {c->part.p, c->arena.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32};
+  void* bufs[] = {c->part.p, c->acc.p, c->arena.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
@@ -405,6 +443,13 @@ int ludvm_set_tuning(ludvm_ctx* c, int targets_per_lane, int source_splits) {
   if (source_splits < 0 || source_splits > kMaxSplit) return fail(c, LUDVM_E_ARG, "source_splits out of range");
   c->tune_tpl = targets_per_lane;
   c->tune_split = source_splits;
+  return LUDVM_OK;
+}
+
+int ludvm_set_symmetric(ludvm_ctx* c, int mode) {
+  if (!c) return LUDVM_E_ARG;
+  if (mode != 0 && mode != 1) return fail(c, LUDVM_E_ARG, "symmetric mode must be 0 or 1");
+  c->sym_mode = mode;
   return LUDVM_OK;
 }
 
@@ -518,10 +563,19 @@ int ludvm_induce_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, con
   if ((ns && (!d_xs || !d_zs || !d_gs)) || (nt && (!d_xt || !d_zt || !d_u || !d_w)))
     return fail(c, LUDVM_E_ARG, "null array");
   HIPCHK(c, hipSetDevice(c->device));
+  const double v2 = (double)vcore * (double)vcore;
+  if (d_xt == d_xs && d_zt == d_zs && nt == ns && use_symmetric(c, (long long)ns)) {
+    long long nt_pad = 0;
+    CHK(launch_sym(c, d_xs, d_zs, d_gs, (long long)ns, v2 * v2, &nt_pad));
+    const float* acc = static_cast<const float*>(c->acc.p);
+    hipLaunchKernelGGL(finish_sym, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad,
+                       (long long)nt, d_u, d_w);
+    HIPCHK(c, hipGetLastError());
+    return LUDVM_OK;
+  }
   PairArgs a{};
   a.xs = d_xs; a.zs = d_zs; a.gs = d_gs; a.ns = (long long)ns;
   a.xt = d_xt; a.zt = d_zt; a.nt = (long long)nt;
-  const double v2 = (double)vcore * (double)vcore;
   a.vc4 = v2 * v2;
   return induce_device(c, a, (long long)nt, (long long)ns, LUDVM_PREC_F32, d_u, d_w);
 }
@@ -533,10 +587,19 @@ int ludvm_advect_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, con
   if (t_first + nt > ns) return fail(c, LUDVM_E_ARG, "target range outside the source arrays");
   if (nt == 0) return LUDVM_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  const double v2 = (double)vcore * (double)vcore;
+  if (t_first == 0 && nt == ns && use_symmetric(c, (long long)ns)) {
+    long long nt_pad = 0;
+    CHK(launch_sym(c, d_xs, d_zs, d_gs, (long long)ns, v2 * v2, &nt_pad));
+    const float* acc = static_cast<const float*>(c->acc.p);
+    hipLaunchKernelGGL(finish_sym_advect, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad,
+                       d_xs, d_zs, 0LL, (long long)nt, dt, d_x_out, d_z_out);
+    HIPCHK(c, hipGetLastError());
+    return LUDVM_OK;
+  }
   PairArgs a{};
   a.xs = d_xs; a.zs = d_zs; a.gs = d_gs; a.ns = (long long)ns;
   a.xt = d_xs + t_first; a.zt = d_zs + t_first; a.nt = (long long)nt;
-  const double v2 = (double)vcore * (double)vcore;
   a.vc4 = v2 * v2;
   Plan p = make_plan(c, (long long)nt, (long long)ns, LUDVM_PREC_F32);
   CHK(launch_pair(c, a, p, LUDVM_PREC_F32, nullptr, nullptr));  // results stay in the slab
@@ -663,10 +726,48 @@ int ludvm_wake_advect(ludvm_ctx* c, double dt, const double* foil_x, const doubl
     CHK(wake_refresh(c, n, nfoil));
   }
   const long long ns = (long long)(n + nfoil), nt = (long long)n;
+  const double v2 = vcore * vcore;
+  if (precision == LUDVM_PREC_F32 && use_symmetric(c, nt)) {
+    // wake x wake: each unordered pair once; bound vortices -> wake: direct kernel into slab row 0
+    long long nt_pad = 0;
+    CHK(launch_sym(c, c->xh, c->zh, c->g32, nt, v2 * v2, &nt_pad));
+    const float* foil_part = nullptr;
+    Plan pf{};
+    if (nfoil) {
+      PairArgs af{};
+      af.xs = c->xh + n; af.zs = c->zh + n; af.gs = c->g32 + n; af.ns = (long long)nfoil;
+      af.xt = c->xh; af.zt = c->zh; af.nt = nt;
+      af.vc4 = v2 * v2;
+      pf = make_plan(c, nt, (long long)nfoil, LUDVM_PREC_F32);   // nfoil <= one LDS tile: a single split
+      if (pf.nsplit != 1) return fail(c, LUDVM_E_ARG, "too many bound vortices for the fused roll-up");
+      const bool was = c->timing;
+      c->timing = false;   // the O(N * Npanels) launch is not the dominant kernel
+      int rc = launch_pair(c, af, pf, LUDVM_PREC_F32, nullptr, nullptr);
+      c->timing = was;
+      CHK(rc);
+      foil_part = static_cast<const float*>(c->part.p);
+    }
+    double *du = nullptr, *dw = nullptr;
+    if (u_out) {
+      CHK(ensure(c, c->arena, 2 * Arena::need(n, 8)));
+      Arena ar(c->arena.p);
+      du = ar.take<double>(n);
+      dw = ar.take<double>(n);
+    }
+    const float* acc = static_cast<const float*>(c->acc.p);
+    hipLaunchKernelGGL(finish_wake_advect_sym, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad,
+                       foil_part, nt, nfoil ? pf.nt_pad : 0, dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, du, dw);
+    HIPCHK(c, hipGetLastError());
+    if (u_out) {
+      HIPCHK(c, hipMemcpyAsync(u_out, du, n * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(w_out, dw, n * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return LUDVM_OK;
+  }
   PairArgs a{};
   a.ns = ns;
   a.nt = nt;
-  const double v2 = vcore * vcore;
   a.vc4 = v2 * v2;
   if (precision == LUDVM_PREC_F64) {
     a.xs = c->x64; a.zs = c->z64; a.gs = c->g64; a.xt = c->x64; a.zt = c->z64;

@@ -1,0 +1,246 @@
+// Symmetric ("Newton's third law") Vatistas-core Biot-Savart kernel for SELF-interaction launches
+// (targets == sources: wake roll-up LUDVM.py:1105-1124, BASELINE configs 3 and 4) on gfx950.
+//
+// The pair kernel is antisymmetric, K(i->j) = -K(j->i): dx, dz, r^2, q and -- the expensive part --
+// rsq(q) are shared by the ordered pairs (i,j) and (j,i).  Direct evaluation costs 8 full-rate VALU
+// ops + 1 v_rsq_f32 per ordered pair (24 issue cycles per 64 lanes on CDNA4); evaluating each
+// UNORDERED pair once costs 11 ops + 1 rsq per TWO ordered pairs (15 cycles per ordered pair).
+//
+// Wave-autonomous systolic scheme (no LDS, no barriers, no cross-lane reductions):
+//   * vortices are cut into tiles of W = 64*T; a wavefront owns one tile I: lane l keeps T targets
+//     (x, z, Gamma, accumulators) in registers for its whole life;
+//   * for each partner tile J the lane loads T vortices of J the same way, with their own
+//     accumulators; lane l then evaluates its T x T pairs IN REGISTERS, updating both sides, and the
+//     J set (x, z, Gamma and its accumulators) is rotated one lane with v_mov_b32_dpp wave_rol:1;
+//     after 64 rotations every i of I has met every j of J and the J accumulators are back home;
+//   * tile pairs are enumerated cyclically, J = I + d (mod NT), d = 1 .. (NT-1)/2, so every unordered
+//     tile pair is visited once and every wave has the same amount of work; d = 0 (the diagonal tile,
+//     which holds the self pairs) is evaluated with the ordered formula;
+//   * results are accumulated with float atomics into acc_u / acc_w (zeroed by the caller) and turned
+//     into velocities (or an Euler step) by a finisher.  The summation order of the atomics is not
+//     fixed: results are reproducible to rounding, not bitwise (the direct kernel is bitwise).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pair_kernels.hpp"
+
+namespace ludvm {
+
+struct SymArgs {
+  const float* x; const float* z; const float* g;  // N vortices (device)
+  long long n;
+  long long ntiles;      // ceil(n / (64*T))
+  long long dmax;        // floor((ntiles-1)/2): symmetric offsets 1..dmax (+ ntiles/2 when even)
+  int ysplit;            // number of d-chunks (gridDim.x = ceil(ntiles*ysplit / 4))
+  float* acc_u; float* acc_w;  // raw sums: u = acc_u/(2 pi), w = -acc_w/(2 pi)
+  float vc4;
+};
+
+// lane l receives the value of lane l+1 (wrapping): data moves one lane down
+__device__ __forceinline__ float dpp_rol1(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x134, 0xf, 0xf, false));
+}
+__device__ __forceinline__ f32x2 dpp_rol1(f32x2 v) { return (f32x2){dpp_rol1(v.x), dpp_rol1(v.y)}; }
+
+// T = 4: 256-vortex tiles.  Per rotation step a lane evaluates T*T = 16 unordered pairs with
+// 88 packed ops + 16 v_rsq_f32; the J tile's (x, z, Gamma) sit in a wave-private LDS slab and are
+// read with a per-lane rotating address (ds_read_b128, off the VALU pipe); only the J accumulators
+// travel between lanes (8 v_mov_b32_dpp, 4 issue cycles each on gfx950).
+template <int T>
+__global__ void __launch_bounds__(kBlock)
+pair_sym_f32(SymArgs a) {
+  static_assert(T == 4, "the LDS slab is laid out for 4 vortices (one ds_read_b128) per lane");
+  constexpr int H = T / 2;
+  constexpr int kWaves = kBlock / 64;
+  __shared__ __attribute__((aligned(16))) float slab[kWaves][3][64 * T];
+
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const long long wid = (long long)blockIdx.x * kWaves + wv;
+  if (wid >= a.ntiles * a.ysplit) return;   // whole waves leave together; no block-wide barrier is used
+  const long long I = wid % a.ntiles;
+  const int y = (int)(wid / a.ntiles);
+  const long long W = 64LL * T;
+  float* const lx = slab[wv][0];
+  float* const lz = slab[wv][1];
+  float* const lg = slab[wv][2];
+
+  const bool even = (a.ntiles % 2 == 0) && a.ntiles > 1;
+  const long long dtot = a.dmax + (even ? 1 : 0);
+  const long long per = (dtot + a.ysplit - 1) / a.ysplit;
+  const long long d_lo = 1 + (long long)y * per;
+  long long d_hi = d_lo + per;  // exclusive
+  if (d_hi > dtot + 1) d_hi = dtot + 1;
+
+  // my targets (duplicated into register pairs: the packed ops pair two SOURCES against one target)
+  f32x2 xp[T], zp[T], gp[T], au[T], aw[T];
+  f32x4 X, Z, G;
+  {
+    float x[T], z[T], g[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const long long i = I * W + lane + 64LL * t;
+      const bool ok = i < a.n;
+      x[t] = ok ? a.x[i] : kPadPosF; z[t] = ok ? a.z[i] : kPadPosF; g[t] = ok ? a.g[i] : 0.0f;
+      xp[t] = (f32x2){x[t], x[t]}; zp[t] = (f32x2){z[t], z[t]}; gp[t] = (f32x2){g[t], g[t]};
+      au[t] = (f32x2){0.f, 0.f}; aw[t] = (f32x2){0.f, 0.f};
+    }
+    X = (f32x4){x[0], x[1], x[2], x[3]}; Z = (f32x4){z[0], z[1], z[2], z[3]}; G = (f32x4){g[0], g[1], g[2], g[3]};
+  }
+  const f32x2 vc4 = {a.vc4, a.vc4};
+
+  // ---- diagonal tile: ordered evaluation, i-side only (contains the self pairs) ----------------
+  if (y == 0) {
+    *reinterpret_cast<f32x4*>(&lx[lane * T]) = X;
+    *reinterpret_cast<f32x4*>(&lz[lane * T]) = Z;
+    *reinterpret_cast<f32x4*>(&lg[lane * T]) = G;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int k = 0; k < 64; ++k) {
+      const int pos = ((lane + k) & 63) * T;
+      const f32x4 XJ = *reinterpret_cast<const f32x4*>(&lx[pos]);
+      const f32x4 ZJ = *reinterpret_cast<const f32x4*>(&lz[pos]);
+      const f32x4 GJ = *reinterpret_cast<const f32x4*>(&lg[pos]);
+#pragma unroll
+      for (int m = 0; m < H; ++m) {
+        const f32x2 xj = m ? (f32x2){XJ.z, XJ.w} : (f32x2){XJ.x, XJ.y};
+        const f32x2 zj = m ? (f32x2){ZJ.z, ZJ.w} : (f32x2){ZJ.x, ZJ.y};
+        const f32x2 gj = m ? (f32x2){GJ.z, GJ.w} : (f32x2){GJ.x, GJ.y};
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const f32x2 dx = xp[t] - xj;
+          const f32x2 dz = zp[t] - zj;
+          f32x2 r2 = dx * dx;
+          r2 = __builtin_elementwise_fma(dz, dz, r2);
+          const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
+          f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+          s = s * gj;
+          au[t] = __builtin_elementwise_fma(dz, s, au[t]);
+          aw[t] = __builtin_elementwise_fma(dx, s, aw[t]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- off-diagonal tiles: each unordered pair once, both sides accumulated --------------------
+  for (long long d = d_lo; d < d_hi; ++d) {
+    if (even && d == dtot && I >= a.ntiles / 2) break;  // the half-way offset pairs each tile twice
+    long long J = I + d;
+    if (J >= a.ntiles) J -= a.ntiles;
+    {
+      float x[T], z[T], g[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const long long j = J * W + lane + 64LL * t;
+        const bool ok = j < a.n;
+        x[t] = ok ? a.x[j] : kPadPosF; z[t] = ok ? a.z[j] : kPadPosF; g[t] = ok ? a.g[j] : 0.0f;
+      }
+      *reinterpret_cast<f32x4*>(&lx[lane * T]) = (f32x4){x[0], x[1], x[2], x[3]};
+      *reinterpret_cast<f32x4*>(&lz[lane * T]) = (f32x4){z[0], z[1], z[2], z[3]};
+      *reinterpret_cast<f32x4*>(&lg[lane * T]) = (f32x4){g[0], g[1], g[2], g[3]};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x2 bu[H], bw[H];
+#pragma unroll
+    for (int m = 0; m < H; ++m) { bu[m] = (f32x2){0.f, 0.f}; bw[m] = (f32x2){0.f, 0.f}; }
+
+    // (issuing the reads of step k+1 ahead of the arithmetic of step k measured no gain: with 4-5
+    // waves per SIMD the LDS latency is already covered)
+    for (int k = 0; k < 64; ++k) {
+      // at step k this lane holds the accumulators of the J vortices whose home lane is (lane + k) % 64
+      const int pos = ((lane + k) & 63) * T;
+      const f32x4 XJ = *reinterpret_cast<const f32x4*>(&lx[pos]);
+      const f32x4 ZJ = *reinterpret_cast<const f32x4*>(&lz[pos]);
+      const f32x4 GJ = *reinterpret_cast<const f32x4*>(&lg[pos]);
+#pragma unroll
+      for (int m = 0; m < H; ++m) {
+        const f32x2 xj = m ? (f32x2){XJ.z, XJ.w} : (f32x2){XJ.x, XJ.y};
+        const f32x2 zj = m ? (f32x2){ZJ.z, ZJ.w} : (f32x2){ZJ.x, ZJ.y};
+        const f32x2 gj = m ? (f32x2){GJ.z, GJ.w} : (f32x2){GJ.x, GJ.y};
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const f32x2 dx = xp[t] - xj;
+          const f32x2 dz = zp[t] - zj;
+          f32x2 r2 = dx * dx;
+          r2 = __builtin_elementwise_fma(dz, dz, r2);
+          const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
+          const f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+          const f32x2 sj = s * gj;         // strength of j acting on i
+          const f32x2 si = s * gp[t];      // strength of i acting on j
+          au[t] = __builtin_elementwise_fma(dz, sj, au[t]);
+          aw[t] = __builtin_elementwise_fma(dx, sj, aw[t]);
+          bu[m] = __builtin_elementwise_fma(dz, si, bu[m]);
+          bw[m] = __builtin_elementwise_fma(dx, si, bw[m]);
+        }
+      }
+      // hand the J accumulators to the lane that meets the same J vortices next step (lane - 1)
+#pragma unroll
+      for (int m = 0; m < H; ++m) { bu[m] = dpp_rol1(bu[m]); bw[m] = dpp_rol1(bw[m]); }
+    }
+    // 64 rotations: the J accumulators are home again; j feels the opposite of what i feels.
+    // home lane l holds vortices J*W + l + 64*t as packed elements t = 0..3
+#pragma unroll
+    for (int m = 0; m < H; ++m) {
+      const long long j0 = J * W + lane + 64LL * (2 * m), j1 = j0 + 64;
+      if (j0 < a.n) { atomicAdd(&a.acc_u[j0], -bu[m].x); atomicAdd(&a.acc_w[j0], -bw[m].x); }
+      if (j1 < a.n) { atomicAdd(&a.acc_u[j1], -bu[m].y); atomicAdd(&a.acc_w[j1], -bw[m].y); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next tile
+  }
+
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const long long i = I * W + lane + 64LL * t;
+    if (i < a.n) { atomicAdd(&a.acc_u[i], au[t].x + au[t].y); atomicAdd(&a.acc_w[i], aw[t].x + aw[t].y); }
+  }
+}
+
+// acc -> velocities
+__global__ void __launch_bounds__(kBlock)
+finish_sym(const float* acc_u, const float* acc_w, long long n, float* u, float* w) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float s = (float)kInv2PiD;
+  u[i] = acc_u[i] * s;
+  w[i] = -acc_w[i] * s;
+}
+
+// acc -> Euler step of targets [t_first, t_first + nt)
+__global__ void __launch_bounds__(kBlock)
+finish_sym_advect(const float* acc_u, const float* acc_w, const float* x, const float* z, long long t_first, long long nt,
+                  float dt, float* x_out, float* z_out) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nt) return;
+  const float s = (float)kInv2PiD;
+  x_out[i] = __builtin_fmaf(dt, acc_u[t_first + i] * s, x[t_first + i]);
+  z_out[i] = __builtin_fmaf(dt, -acc_w[t_first + i] * s, z[t_first + i]);
+}
+
+// Resident-wake Euler step from the symmetric kernel's raw sums plus the (already scaled) velocities
+// induced by the bound vortices (direct kernel, `foil` = [2][nt_pad] slab or nullptr): float64 update
+// of the master copy, refresh of the fp32 mirrors (LUDVM.py:1108-1127).
+__global__ void __launch_bounds__(kBlock)
+finish_wake_advect_sym(const float* acc_u, const float* acc_w, const float* foil, long long nt, long long nt_pad, double dt,
+                       double* x64, double* z64, float* xh, float* xl, float* zh, float* zl, double* u_out,
+                       double* w_out) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nt) return;
+  const float s = (float)kInv2PiD;
+  float su = acc_u[i] * s, sw = -acc_w[i] * s;
+  if (foil) { su += foil[i]; sw += foil[nt_pad + i]; }
+  if (u_out) { u_out[i] = (double)su; w_out[i] = (double)sw; }
+  const double xn = x64[i] + dt * (double)su;
+  const double zn = z64[i] + dt * (double)sw;
+  x64[i] = xn;
+  z64[i] = zn;
+  split_hilo(xn, xh[i], xl[i]);
+  split_hilo(zn, zh[i], zl[i]);
+}
+
+}  // namespace ludvm

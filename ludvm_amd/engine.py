@@ -94,6 +94,11 @@ class Engine:
     def set_tuning(self, targets_per_lane=0, source_splits=0):
         self._check(self._lib.ludvm_set_tuning(self._ctx, int(targets_per_lane), int(source_splits)))
 
+    def set_symmetric(self, mode=1):
+        """0: always the direct kernel (bitwise reproducible); 1: self-interaction launches may use the
+        symmetric kernel (each unordered pair once; float atomics)."""
+        self._check(self._lib.ludvm_set_symmetric(self._ctx, int(mode)))
+
     # -- stateless pair sum ----------------------------------------------------------------------
     def induce(self, circulation, xw, zw, xp, zp, v_core, precision="f32"):
         """(u, w) float64 arrays; host arrays in, host arrays out (LUDVM.py:549-570)."""

@@ -220,8 +220,9 @@ def test_error_reporting(eng):
 
 
 def test_full_size_config3_properties(eng):
-    """N = 1e6 all-pairs (BASELINE config 3): sampled targets against the C oracle, impulse invariant,
-    exact power-of-two linearity, reproducibility."""
+    """N = 1e6 all-pairs (BASELINE config 3), direct and symmetric kernels: sampled targets against the
+    C oracle, impulse invariant; the direct kernel is bitwise reproducible and exactly linear under
+    power-of-two scaling, the symmetric one (float atomics) reproduces to rounding."""
     import torch
     n = 1_000_000
     rng = np.random.default_rng(20260101)
@@ -232,23 +233,94 @@ def test_full_size_config3_properties(eng):
     dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
     du, dw = torch.empty_like(dx), torch.empty_like(dx)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    sel = rng.choice(n, 1024, replace=False)
+    ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float),
+                                       x[sel].astype(float), z[sel].astype(float), 0.065)
+    gd = g.astype(float)
     try:
         def run(gam):
             eng.induce_dev(dx.data_ptr(), dz.data_ptr(), gam.data_ptr(), n, dx.data_ptr(), dz.data_ptr(), n, 0.065,
                            du.data_ptr(), dw.data_ptr())
             torch.cuda.synchronize()
             return du.cpu().numpy().copy(), dw.cpu().numpy().copy()
-        u, w = run(dg)
-        u2, w2 = run(dg)
-        assert np.array_equal(u, u2) and np.array_equal(w, w2)
-        sel = rng.choice(n, 1024, replace=False)
-        ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float),
-                                           x[sel].astype(float), z[sel].astype(float), 0.065)
-        assert _rel(u[sel], w[sel], ur, wr) < 1e-5
-        gd = g.astype(float)
-        assert abs(np.sum(gd * u)) < 1e-4 * np.sum(np.abs(gd * u))
-        assert abs(np.sum(gd * w)) < 1e-4 * np.sum(np.abs(gd * w))
-        u4, w4 = run(dg * 4.0)
-        assert np.array_equal(u4, 4.0 * u) and np.array_equal(w4, 4.0 * w)
+        res = {}
+        for mode in (0, 1):
+            eng.set_symmetric(mode)
+            u, w = run(dg)
+            res[mode] = (u, w)
+            assert _rel(u[sel], w[sel], ur, wr) < 1e-5, mode
+            assert abs(np.sum(gd * u)) < 1e-4 * np.sum(np.abs(gd * u))
+            assert abs(np.sum(gd * w)) < 1e-4 * np.sum(np.abs(gd * w))
+            u2, w2 = run(dg)
+            u4, w4 = run(dg * 4.0)
+            if mode == 0:
+                assert np.array_equal(u, u2) and np.array_equal(w, w2)
+                assert np.array_equal(u4, 4.0 * u) and np.array_equal(w4, 4.0 * w)
+            else:
+                scale = max(np.abs(u).max(), np.abs(w).max())
+                assert np.abs(u - u2).max() < 1e-5 * scale and np.abs(u4 - 4.0 * u).max() < 4e-5 * scale
+        scale = max(np.abs(res[0][0]).max(), np.abs(res[0][1]).max())
+        assert np.abs(res[0][0] - res[1][0]).max() < 1e-5 * scale and np.abs(res[0][1] - res[1][1]).max() < 1e-5 * scale
     finally:
+        eng.set_symmetric(1)
+        eng.set_stream(None)
+
+
+@pytest.mark.parametrize("n", [16384, 16385, 20000, 65536 + 255, 131072])
+def test_symmetric_kernel_tile_edges(eng, n):
+    """Symmetric self-interaction at sizes around its 256-vortex tiling (odd and even tile counts,
+    ragged last tile) against the C oracle and the direct kernel."""
+    import torch
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-10, 0, n).astype(np.float32)
+    z = rng.uniform(-2, 2, n).astype(np.float32)
+    g = (rng.standard_normal(n) / n).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
+    du, dw = torch.empty_like(dx), torch.empty_like(dx)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    sel = np.r_[0:300, n - 300:n, rng.choice(n, 400, replace=False)]
+    ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float),
+                                       x[sel].astype(float), z[sel].astype(float), 0.065)
+    try:
+        out = {}
+        for mode in (0, 1):
+            eng.set_symmetric(mode)
+            du.fill_(float("nan")); dw.fill_(float("nan"))
+            eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, dx.data_ptr(), dz.data_ptr(), n, 0.065,
+                           du.data_ptr(), dw.data_ptr())
+            torch.cuda.synchronize()
+            out[mode] = (du.cpu().numpy().copy(), dw.cpu().numpy().copy())
+            assert np.isfinite(out[mode][0]).all()
+            assert _rel(out[mode][0][sel], out[mode][1][sel], ur, wr) < 1e-5, mode
+        scale = max(np.abs(out[0][0]).max(), np.abs(out[0][1]).max())
+        assert np.abs(out[0][0] - out[1][0]).max() < 1e-5 * scale
+        assert np.abs(out[0][1] - out[1][1]).max() < 1e-5 * scale
+    finally:
+        eng.set_symmetric(1)
+        eng.set_stream(None)
+
+
+def test_symmetric_inviscid_self_pairs_are_nan_like_the_reference(eng):
+    import torch
+    n = 20000
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-10, 0, n).astype(np.float32)
+    z = rng.uniform(-2, 2, n).astype(np.float32)
+    g = (rng.standard_normal(n) / n).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
+    du, dw = torch.empty_like(dx), torch.empty_like(dx)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        # v_core = 0 with targets == sources: every target coincides with one source -> NaN (0/0), as in
+        # the reference (SURVEY H7), in both kernels
+        for mode in (0, 1):
+            eng.set_symmetric(mode)
+            eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, dx.data_ptr(), dz.data_ptr(), n, 0.0,
+                           du.data_ptr(), dw.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.isnan(du).all() and torch.isnan(dw).all()
+    finally:
+        eng.set_symmetric(1)
         eng.set_stream(None)

@@ -78,6 +78,32 @@ def test_wake_advect_is_one_reference_roll_up_step(eng, precision, tol):
     np.testing.assert_allclose(x2, xn + dt * u2, rtol=0, atol=tol * scale * dt + 1e-15)
 
 
+def test_wake_advect_symmetric_path(eng):
+    """fp32 roll-up of a wake large enough for the symmetric kernel (each unordered pair once) plus the
+    direct bound-vortex launch: same answer as the direct kernel and the oracle."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(12)
+    n, nf = 20001, 80
+    x, z, g = rng.uniform(-10, 0, n), rng.uniform(-2, 2, n), rng.standard_normal(n) / n
+    fx, fz, fg = np.linspace(-10.9, -10.0, nf), 0.02 * np.cos(np.linspace(0, 2, nf)), rng.standard_normal(nf) / 100
+    dt, vc = 5e-2, 0.065
+    ur, wr = c_oracle.induced_velocity(np.r_[g, fg], np.r_[x, fx], np.r_[z, fz], x, z, vc)
+    scale = max(np.abs(ur).max(), np.abs(wr).max())
+    try:
+        for mode in (1, 0):
+            eng.set_symmetric(mode)
+            eng.wake_clear()
+            eng.wake_append(x, z, g)
+            u, w = eng.wake_advect(dt, fx, fz, fg, vc, precision="f32", return_velocity=True)
+            assert np.abs(u - ur).max() <= 3e-5 * scale and np.abs(w - wr).max() <= 3e-5 * scale, mode
+            xn, zn = eng.wake_read(0, n)
+            np.testing.assert_allclose(xn, x + dt * ur, rtol=0, atol=3e-5 * scale * dt)
+            np.testing.assert_allclose(zn, z + dt * wr, rtol=0, atol=3e-5 * scale * dt)
+            assert eng.wake_size() == n
+    finally:
+        eng.set_symmetric(1)
+
+
 # ---------------------------------------------------------------------------------------------
 # the drop-in class, end to end
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Measure the BASELINE configs that are not bench.py's headline line (run on the GPU box).
+
+    python tools/run_configs.py cfg5            # flow field 4096 x 4096 grid over N = 1e6 vortices
+    python tools/run_configs.py cfg2 --tf 50    # NACA0012 sinusoidal pitch, dt = 1e-3, full time_loop
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def cfg5(args):
+    import torch
+    from ludvm_amd import Engine
+    from oracle import c_oracle
+    n, nx, nz = args.vortices, args.grid, args.grid
+    rng = np.random.default_rng(20260101)
+    x = rng.uniform(-10, 0, n).astype(np.float32)
+    z = rng.uniform(-2, 2, n).astype(np.float32)
+    g = (rng.standard_normal(n) / n).astype(np.float32)
+    xmin, zmin, dr = -8.0, -4.0, 8.0 / nx
+    dev = torch.device("cuda", 0)
+    eng = Engine(0)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
+    du = torch.empty(nx * nz, dtype=torch.float32, device=dev)
+    dw = torch.empty_like(du)
+    dome = torch.empty_like(du)
+
+    def run():
+        eng.flowfield_dev(xmin, zmin, dr, nx, nz, dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, 0.065,
+                          du.data_ptr(), dw.data_ptr())
+        eng.vorticity_dev(du.data_ptr(), dw.data_ptr(), nx, nz, dr, dome.data_ptr())
+    run()
+    torch.cuda.synchronize()
+    eng.kernel_timing(True)
+    eng.kernel_time_ms(True)
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        run()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / args.reps
+    kms, _ = eng.kernel_time_ms(True)
+    pairs = float(nx) * nz * n
+    # parity on sampled grid points against the C oracle
+    sel = rng.choice(nx * nz, 512, replace=False)
+    xt = xmin + (sel // nz) * dr
+    zt = zmin + (sel % nz) * dr
+    ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float), xt, zt, 0.065)
+    u, w = du.cpu().numpy()[sel], dw.cpu().numpy()[sel]
+    err = max(np.abs(u - ur).max(), np.abs(w - wr).max()) / max(np.abs(ur).max(), np.abs(wr).max())
+    print(json.dumps({"config": f"cfg5 flowfield {nx}x{nz} grid over N={n}", "s_per_call": el, "pairs_per_s": pairs / el,
+                      "pair_kernel_ms": kms, "pct_fp32_peak": 13 * pairs / (kms * 1e-3) / 157.3e12 * 100,
+                      "sampled_rel_err_vs_oracle": err, "omega_finite": bool(torch.isfinite(dome).all().item())}))
+
+
+def cfg2(args):
+    from ludvm_amd import LUDVM, Engine
+    eng = Engine(0)
+    eng.kernel_timing(True)
+    t0 = time.perf_counter()
+    sim = LUDVM(t0=0, tf=args.tf, dt=1e-3, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2,
+                Naca="0012", verbose=args.verbose, engine=eng, precision=args.precision, history="sparse",
+                snapshot_steps=[])
+    el = time.perf_counter() - t0
+    kms, nl = eng.kernel_time_ms(True)
+    ntev, nlev = sim.itev + 1, sim.ilev + (1 if sim.LEV_shed[-1] != -1 else 0)
+    # pairs of the roll-up launches: sum_i (n_i + 80) * n_i with n_i = wake size at step i
+    sizes = 1 + np.arange(1, sim.nt) + np.cumsum(sim.LEV_shed[1:] != -1)
+    pairs = float(np.sum((sizes + 80.0) * sizes))
+    print(json.dumps({"config": f"cfg2 time_loop dt=1e-3 tf={args.tf} precision={args.precision}", "steps": sim.nt - 1,
+                      "wall_s": el, "final_wake": int(sizes[-1]), "tev": int(ntev), "lev": int(nlev),
+                      "rollup_pairs": pairs, "pairs_per_s_wall": pairs / el, "kernel_launches": nl,
+                      "kernel_ms_total": kms * nl, "Cl_last": float(sim.Cl[-1]), "Cl_mean_last_period": float(np.mean(sim.Cl[-10000:])),
+                      "max_abs_LESP": float(np.abs(sim.LESP).max())}))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", choices=["cfg5", "cfg2"])
+    ap.add_argument("--vortices", type=int, default=1_000_000)
+    ap.add_argument("--grid", type=int, default=4096)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--tf", type=float, default=50.0)
+    ap.add_argument("--precision", default="f32")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    {"cfg5": cfg5, "cfg2": cfg2}[a.which](a)
