@@ -30,6 +30,11 @@ if ROOT not in sys.path:
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBPS = 8000.0
 FLOP_PER_PAIR = 13                # sub sub mul fma fma rsq mul fma fma (FMA = 2, rsq = 1), SURVEY 8(d)
+# HBM-side bytes per launch of the dominant kernel at config 3 (N = 1e6), from separate rocprofv3 --pmc
+# passes of this same command (profiles/r01_bench_cfg3_{direct,sym}_pmc_{fetch,write}.csv): FETCH_SIZE +
+# WRITE_SIZE in bytes.  Uncalibrated for these access widths (MI355X_MICROARCH.md, HBM section); the
+# symmetric kernel's write side is its float atomics (2.46e8 64-B requests).  Not measured in this run.
+PMC_TRAFFIC_BYTES_CFG3 = {"direct": 73.2e6 + 72.0e6, "symmetric": 2.38e9 + 15.76e9}
 V_CORE = 0.065
 DT = 5e-2
 
@@ -119,8 +124,8 @@ def main():
     eng.set_symmetric(args.symmetric)
     info = eng.device_info()
 
-    # the symmetric kernel serves launches whose targets are exactly the sources (1-GPU configs)
-    symmetric = bool(args.symmetric) and world == 1 and n >= 16384
+    # the symmetric kernel serves self-interaction launches (configs 3 and 4)
+    symmetric = bool(args.symmetric) and n >= 16384
     if workload == "cfg3":
         dx, dz, dg = (torch.from_numpy(a).to(device) for a in (x, z, g))
         du, dw = torch.empty_like(dx), torch.empty_like(dx)
@@ -133,12 +138,13 @@ def main():
         desc = f"config 3: synthetic wake N={n}, one induced_velocity all-pairs call per step (targets = sources)"
         scaling = "strong"
     else:
-        wake = ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device)
+        wake = ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric)
         step = wake.step
         pairs_per_step = wake.pairs_per_step
         pairs_per_launch = float(wake.n_loc) * float(wake.n_pad)
         desc = (f"config 4: synthetic wake N={n}, targets sharded over {world} GPU(s), per step: all-pairs "
-                f"kernel on own N/G targets + Euler update + one RCCL all-gather of positions")
+                f"kernel on own N/G targets + Euler update + one RCCL all-gather of positions"
+                + (" (symmetric kernel: + one reduce-scatter of the raw sums)" if symmetric else ""))
         scaling = "strong"
 
     def fence():
@@ -193,7 +199,10 @@ def main():
                 "pct_fp32_vector_peak": 100.0 * achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
                 "hbm_algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_achieved_gbps": alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0, "hbm_peak_gbps": HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": PMC_TRAFFIC_BYTES_CFG3["symmetric" if symmetric else "direct"]
+                if (workload == "cfg3" and n == 1_000_000) else None,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed under "
+                                  "profiles/ (not collected in this run)",
             },
         }
         if workload == "cfg3" and world == 1 and args.cpu_rows > 0:

@@ -103,6 +103,22 @@ int ludvm_induce_dev_f32(ludvm_ctx* ctx, const float* d_xs, const float* d_zs, c
 int ludvm_advect_dev_f32(ludvm_ctx* ctx, const float* d_xs, const float* d_zs, const float* d_gs, size_t ns,
                          size_t t_first, size_t nt, float vcore, float dt, float* d_x_out, float* d_z_out);
 
+/* Multi-GPU building blocks of the symmetric roll-up (ludvm_amd/sharded.py).  Vortices are cut into
+ * tiles of LUDVM_SYM_TILE; the caller owns tiles [tile_first, tile_first + tile_count) of the
+ * ceil(n / LUDVM_SYM_TILE) tiles.  ludvm_sym_accumulate_dev_f32 evaluates this owner's share of the
+ * unordered pairs (its tiles against the cyclic half of the tile ring) and ADDS the raw sums of both
+ * partners into d_acc_u / d_acc_w (n floats each, zeroed by the caller): summed over all owners,
+ * u = acc_u / (2 pi), w = -acc_w / (2 pi).  ludvm_advect_from_sums_dev_f32 turns the summed values of
+ * targets [t_first, t_first + nt) (d_sum_*[i] belongs to target t_first + i) into the Euler step
+ * x_out[i] = x[t_first + i] + dt * u, z_out likewise (LUDVM.py:1108-1109). */
+#define LUDVM_SYM_TILE 256
+int ludvm_sym_accumulate_dev_f32(ludvm_ctx* ctx, const float* d_x, const float* d_z, const float* d_g, size_t n,
+                                 size_t tile_first, size_t tile_count, float vcore, float* d_acc_u,
+                                 float* d_acc_w);
+int ludvm_advect_from_sums_dev_f32(ludvm_ctx* ctx, const float* d_sum_u, const float* d_sum_w, const float* d_x,
+                                   const float* d_z, size_t t_first, size_t nt, float dt, float* d_x_out,
+                                   float* d_z_out);
+
 /* ---- resident wake: backs LUDVM.time_loop (LUDVM.py:597-1171) ----------------------------- */
 /* The wake (TEV, LEV and FREE vortices, in an order the host chooses) lives on the device across
  * time steps as float64 master copies plus the fp32 (hi, lo) SoA the pair kernel reads. */

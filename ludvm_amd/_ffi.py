@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libludvm_hip.so")
 
 OK, E_ARG, E_HIP, E_NOMEM, E_NODEVICE, E_STATE = range(6)
 PREC_F32, PREC_F32X2, PREC_F64 = 0, 1, 2
+SYM_TILE = 256
 ABI_VERSION = 1
 
 _pd, _pf = POINTER(c_double), POINTER(c_float)
@@ -34,6 +35,10 @@ SIGNATURES = {
                              c_float, c_void_p, c_void_p],
     "ludvm_advect_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float,
                              c_float, c_void_p, c_void_p],
+    "ludvm_sym_accumulate_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float,
+                                     c_void_p, c_void_p],
+    "ludvm_advect_from_sums_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float,
+                                       c_void_p, c_void_p],
     "ludvm_wake_reserve": [c_void_p, c_size_t],
     "ludvm_wake_clear": [c_void_p],
     "ludvm_wake_size": [c_void_p, POINTER(c_size_t)],

@@ -279,35 +279,48 @@ int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, i
 
 constexpr long long kSymMinN = 16384;   // below this the direct kernel's launch is as fast
 constexpr int kSymT = 4;                // vortices per lane of the symmetric kernel (tile = 256)
+static_assert(64 * kSymT == LUDVM_SYM_TILE, "header and kernel disagree on the symmetric tile");
 constexpr long long kSymTargetWaves = 65536;
 
 bool use_symmetric(const ludvm_ctx* c, long long n) { return c->sym_mode == 1 && n >= kSymMinN; }
 
-// Symmetric self-interaction of (x, z, g)[0, n): zero the accumulators, run the kernel.  The raw sums
-// are left in c->acc as [acc_u | acc_w], each nt_pad floats.
-int launch_sym(ludvm_ctx* c, const float* x, const float* z, const float* g, long long n, double vc4, long long* nt_pad_out) {
-  const long long nt_pad = (n + 63) / 64 * 64;
-  CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(float)));
-  HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(float), c->stream));
+// Symmetric kernel over I tiles [i_first, i_first + i_count) of the tile ring of (x, z, g)[0, n); raw sums
+// are ADDED into acc_u / acc_w (n floats each, zeroed by the caller).
+int launch_sym_tiles(ludvm_ctx* c, const float* x, const float* z, const float* g, long long n, long long i_first,
+                     long long i_count, double vc4, float* acc_u, float* acc_w) {
   SymArgs a{};
   a.x = x; a.z = z; a.g = g; a.n = n;
   const long long W = 64LL * kSymT;
   a.ntiles = (n + W - 1) / W;
   a.dmax = (a.ntiles - 1) / 2;
+  a.i_first = i_first;
+  a.i_count = i_count;
   const long long dtot = a.dmax + ((a.ntiles % 2 == 0 && a.ntiles > 1) ? 1 : 0);
-  long long ys = c->tune_split > 0 ? c->tune_split : (kSymTargetWaves + a.ntiles - 1) / a.ntiles;
+  long long ys = c->tune_split > 0 ? c->tune_split : (kSymTargetWaves + i_count - 1) / i_count;
   ys = std::max<long long>(1, std::min<long long>(std::min<long long>(ys, 64), std::max<long long>(dtot, 1)));
   a.ysplit = (int)ys;
-  a.acc_u = static_cast<float*>(c->acc.p);
-  a.acc_w = a.acc_u + nt_pad;
+  a.acc_u = acc_u;
+  a.acc_w = acc_w;
   a.vc4 = (float)vc4;
-  const long long waves = a.ntiles * ys;
+  const long long waves = i_count * ys;
   TimedLaunch t{};
   bool active = false;
   CHK(timed_begin(c, t, active));
   hipLaunchKernelGGL((pair_sym_f32<kSymT>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
   CHK(timed_end(c, t, active));
+  return LUDVM_OK;
+}
+
+// Symmetric self-interaction of all of (x, z, g)[0, n): zero the context's accumulators, run the kernel.
+// The raw sums are left in c->acc as [acc_u | acc_w], each nt_pad floats.
+int launch_sym(ludvm_ctx* c, const float* x, const float* z, const float* g, long long n, double vc4, long long* nt_pad_out) {
+  const long long nt_pad = (n + 63) / 64 * 64;
+  CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(float)));
+  HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(float), c->stream));
+  float* acc = static_cast<float*>(c->acc.p);
+  const long long ntiles = (n + 64LL * kSymT - 1) / (64LL * kSymT);
+  CHK(launch_sym_tiles(c, x, z, g, n, 0, ntiles, vc4, acc, acc + nt_pad));
   *nt_pad_out = nt_pad;
   return LUDVM_OK;
 }
@@ -593,7 +606,7 @@ int ludvm_advect_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, con
     CHK(launch_sym(c, d_xs, d_zs, d_gs, (long long)ns, v2 * v2, &nt_pad));
     const float* acc = static_cast<const float*>(c->acc.p);
     hipLaunchKernelGGL(finish_sym_advect, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad,
-                       d_xs, d_zs, 0LL, (long long)nt, dt, d_x_out, d_z_out);
+                       d_xs, d_zs, 0LL, (long long)nt, dt, d_x_out, d_z_out);  // t_first = 0: sums index = target index
     HIPCHK(c, hipGetLastError());
     return LUDVM_OK;
   }
@@ -606,6 +619,31 @@ int ludvm_advect_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, con
   hipLaunchKernelGGL(finish_advect_f32, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream,
                      static_cast<const float*>(c->part.p), (long long)nt, p.nt_pad, p.nsplit, d_xs, d_zs,
                      (long long)t_first, dt, d_x_out, d_z_out);
+  HIPCHK(c, hipGetLastError());
+  return LUDVM_OK;
+}
+
+int ludvm_sym_accumulate_dev_f32(ludvm_ctx* c, const float* d_x, const float* d_z, const float* d_g, size_t n,
+                                 size_t tile_first, size_t tile_count, float vcore, float* d_acc_u, float* d_acc_w) {
+  if (!c) return LUDVM_E_ARG;
+  if (!d_x || !d_z || !d_g || !d_acc_u || !d_acc_w) return fail(c, LUDVM_E_ARG, "null array");
+  const size_t ntiles = (n + LUDVM_SYM_TILE - 1) / LUDVM_SYM_TILE;
+  if (tile_first + tile_count > ntiles) return fail(c, LUDVM_E_ARG, "tile range outside the tile ring");
+  if (tile_count == 0) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const double v2 = (double)vcore * (double)vcore;
+  return launch_sym_tiles(c, d_x, d_z, d_g, (long long)n, (long long)tile_first, (long long)tile_count, v2 * v2, d_acc_u,
+                          d_acc_w);
+}
+
+int ludvm_advect_from_sums_dev_f32(ludvm_ctx* c, const float* d_sum_u, const float* d_sum_w, const float* d_x,
+                                   const float* d_z, size_t t_first, size_t nt, float dt, float* d_x_out, float* d_z_out) {
+  if (!c) return LUDVM_E_ARG;
+  if (!d_sum_u || !d_sum_w || !d_x || !d_z || !d_x_out || !d_z_out) return fail(c, LUDVM_E_ARG, "null array");
+  if (nt == 0) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(finish_sym_advect, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, d_sum_u, d_sum_w, d_x,
+                     d_z, (long long)t_first, (long long)nt, dt, d_x_out, d_z_out);
   HIPCHK(c, hipGetLastError());
   return LUDVM_OK;
 }

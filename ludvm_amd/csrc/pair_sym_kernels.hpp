@@ -15,7 +15,9 @@
 //     after 64 rotations every i of I has met every j of J and the J accumulators are back home;
 //   * tile pairs are enumerated cyclically, J = I + d (mod NT), d = 1 .. (NT-1)/2, so every unordered
 //     tile pair is visited once and every wave has the same amount of work; d = 0 (the diagonal tile,
-//     which holds the self pairs) is evaluated with the ordered formula;
+//     which holds the self pairs) is evaluated with the ordered formula.  Because the work of a tile I
+//     depends on I alone, a GPU that owns a contiguous block of I tiles does exactly 1/G of the job
+//     (multi-GPU: the raw sums are then reduce-scattered, see ludvm_amd/sharded.py);
 //   * results are accumulated with float atomics into acc_u / acc_w (zeroed by the caller) and turned
 //     into velocities (or an Euler step) by a finisher.  The summation order of the atomics is not
 //     fixed: results are reproducible to rounding, not bitwise (the direct kernel is bitwise).
@@ -30,7 +32,9 @@ struct SymArgs {
   long long n;
   long long ntiles;      // ceil(n / (64*T))
   long long dmax;        // floor((ntiles-1)/2): symmetric offsets 1..dmax (+ ntiles/2 when even)
-  int ysplit;            // number of d-chunks (gridDim.x = ceil(ntiles*ysplit / 4))
+  long long i_first;     // this launch owns I tiles [i_first, i_first + i_count): one GPU's block of the
+  long long i_count;     //   global tile ring (multi-GPU), or all tiles
+  int ysplit;            // number of d-chunks (gridDim.x = ceil(i_count*ysplit / 4))
   float* acc_u; float* acc_w;  // raw sums: u = acc_u/(2 pi), w = -acc_w/(2 pi)
   float vc4;
 };
@@ -57,9 +61,9 @@ pair_sym_f32(SymArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const long long wid = (long long)blockIdx.x * kWaves + wv;
-  if (wid >= a.ntiles * a.ysplit) return;   // whole waves leave together; no block-wide barrier is used
-  const long long I = wid % a.ntiles;
-  const int y = (int)(wid / a.ntiles);
+  if (wid >= a.i_count * a.ysplit) return;   // whole waves leave together; no block-wide barrier is used
+  const long long I = a.i_first + wid % a.i_count;
+  const int y = (int)(wid / a.i_count);
   const long long W = 64LL * T;
   float* const lx = slab[wv][0];
   float* const lz = slab[wv][1];
@@ -211,15 +215,15 @@ finish_sym(const float* acc_u, const float* acc_w, long long n, float* u, float*
   w[i] = -acc_w[i] * s;
 }
 
-// acc -> Euler step of targets [t_first, t_first + nt)
+// raw sums of targets [t_first, t_first + nt) (sum_u[i], sum_w[i] belong to target t_first + i) -> Euler step
 __global__ void __launch_bounds__(kBlock)
-finish_sym_advect(const float* acc_u, const float* acc_w, const float* x, const float* z, long long t_first, long long nt,
+finish_sym_advect(const float* sum_u, const float* sum_w, const float* x, const float* z, long long t_first, long long nt,
                   float dt, float* x_out, float* z_out) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nt) return;
   const float s = (float)kInv2PiD;
-  x_out[i] = __builtin_fmaf(dt, acc_u[t_first + i] * s, x[t_first + i]);
-  z_out[i] = __builtin_fmaf(dt, -acc_w[t_first + i] * s, z[t_first + i]);
+  x_out[i] = __builtin_fmaf(dt, sum_u[i] * s, x[t_first + i]);
+  z_out[i] = __builtin_fmaf(dt, -sum_w[i] * s, z[t_first + i]);
 }
 
 // Resident-wake Euler step from the symmetric kernel's raw sums plus the (already scaled) velocities

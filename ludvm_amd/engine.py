@@ -126,6 +126,14 @@ class Engine:
         self._check(self._lib.ludvm_advect_dev_f32(self._ctx, d_xs, d_zs, d_gs, ns, t_first, nt, float(v_core),
                                                    float(dt), d_x_out, d_z_out))
 
+    def sym_accumulate_dev(self, d_x, d_z, d_g, n, tile_first, tile_count, v_core, d_acc_u, d_acc_w):
+        self._check(self._lib.ludvm_sym_accumulate_dev_f32(self._ctx, d_x, d_z, d_g, n, tile_first, tile_count,
+                                                           float(v_core), d_acc_u, d_acc_w))
+
+    def advect_from_sums_dev(self, d_sum_u, d_sum_w, d_x, d_z, t_first, nt, dt, d_x_out, d_z_out):
+        self._check(self._lib.ludvm_advect_from_sums_dev_f32(self._ctx, d_sum_u, d_sum_w, d_x, d_z, t_first, nt,
+                                                             float(dt), d_x_out, d_z_out))
+
     # -- resident wake ---------------------------------------------------------------------------
     def wake_reserve(self, capacity):
         self._check(self._lib.ludvm_wake_reserve(self._ctx, int(capacity)))

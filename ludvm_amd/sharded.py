@@ -1,54 +1,83 @@
-"""Multi-GPU wake self-advection: targets sharded across ranks, one all-gather of the updated
-source positions per step (BASELINE config 4).
+"""Multi-GPU wake self-advection: the pair work is sharded across ranks and the updated source
+positions are republished with one all-gather per step (BASELINE config 4).
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Every rank holds
 the full source SoA (x, z, Gamma: 12 B per vortex, 96 MB at N = 8e6) and owns the contiguous block
-of targets [rank*n_loc, (rank+1)*n_loc).  A step is
+of vortices [rank*n_loc, (rank+1)*n_loc).  Two step variants:
 
+direct (symmetric=False) -- what the north star describes:
     1. pair kernel: all N sources -> own n_loc targets, fused explicit-Euler update of the own block
        (reference LUDVM.py:1105-1109 with the wake as both source and target set), written straight
-       into this rank's slot of the send buffer [2, n_loc] (x row, z row);
-    2. ONE all-gather of the [2, n_loc] blocks -> [G, 2, n_loc];
-    3. one strided device copy that lays the gathered blocks out as the next contiguous x[N], z[N]
-       (Gamma never moves).
+       into this rank's send slot [2, n_loc] (x row, z row);
+    2. ONE all-gather of the [2, n_loc] blocks -> [G, 2, n_loc]; one strided device copy lays them out
+       as the next contiguous x[N], z[N] (Gamma never moves).
 
-There is no other collective on the data path.  The pair arithmetic is injected (`kernel`): the
-product passes HipShardKernel (HIP engine, device pointers); the CPU tests pass a checker built on
-the oracle to cover the sharding / all-gather logic under gloo.
+symmetric (default) -- each unordered pair evaluated once, chip-wide 1.4x faster:
+    1. symmetric kernel over the rank's own I-tiles of the global tile ring: J = I + d (mod NT),
+       d <= NT/2, so a rank's work depends only on how many tiles it owns (exactly 1/G of the job) and
+       touches its own block plus the next half of the ring; raw (u, w) sums of BOTH partners are
+       accumulated into a full-length buffer [2, N];
+    2. one reduce-scatter (sum) of that buffer: each rank receives the complete sums of its own block
+       (8 B per vortex over xGMI, ~1 ms at N = 8e6 against ~1 s of pair arithmetic);
+    3. Euler update of the own block into the send slot, then the same all-gather as above.
+
+The pair arithmetic is injected (`kernel`): the product passes HipShardKernel (HIP engine, device
+pointers); the CPU tests pass a checker built on the oracle to cover the sharding / collective logic
+under gloo.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
-PAD_POS = 1.0e6  # padding vortices (N not divisible by the world size): zero strength, far away
+from ._ffi import SYM_TILE
+
+PAD_POS = 1.0e6  # padding vortices (block sizes are rounded up): zero strength, far away
 
 
 class HipShardKernel:
-    """advect(xs, zs, gs, t_first, nt, v_core, dt, x_out, z_out) on CUDA/HIP tensors via the engine."""
+    """The pair arithmetic of a shard step on CUDA/HIP float32 tensors, via the engine's
+    device-pointer entry points (asynchronous on torch's current stream)."""
 
     def __init__(self, engine):
         self.engine = engine
 
-    def advect(self, xs, zs, gs, t_first, nt, v_core, dt, x_out, z_out):
-        for t in (xs, zs, gs, x_out, z_out):
+    def _check(self, *tensors):
+        for t in tensors:
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 raise ValueError("HipShardKernel needs contiguous float32 device tensors")
         self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def advect(self, xs, zs, gs, t_first, nt, v_core, dt, x_out, z_out):
+        self._check(xs, zs, gs, x_out, z_out)
         self.engine.advect_dev(xs.data_ptr(), zs.data_ptr(), gs.data_ptr(), xs.numel(), t_first, nt, v_core, dt,
                                x_out.data_ptr(), z_out.data_ptr())
 
+    def sym_accumulate(self, xs, zs, gs, tile_first, tile_count, v_core, acc_u, acc_w):
+        self._check(xs, zs, gs, acc_u, acc_w)
+        self.engine.sym_accumulate_dev(xs.data_ptr(), zs.data_ptr(), gs.data_ptr(), xs.numel(), tile_first, tile_count,
+                                       v_core, acc_u.data_ptr(), acc_w.data_ptr())
+
+    def advect_from_sums(self, sum_u, sum_w, xs, zs, t_first, nt, dt, x_out, z_out):
+        self._check(sum_u, sum_w, xs, zs, x_out, z_out)
+        self.engine.advect_from_sums_dev(sum_u.data_ptr(), sum_w.data_ptr(), xs.data_ptr(), zs.data_ptr(), t_first, nt,
+                                         dt, x_out.data_ptr(), z_out.data_ptr())
+
 
 class ShardedWake:
-    def __init__(self, x, z, gamma, v_core, dt, kernel, device, group=None):
+    def __init__(self, x, z, gamma, v_core, dt, kernel, device, group=None, symmetric=True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.kernel, self.device = kernel, device
         self.v_core, self.dt = float(v_core), float(dt)
+        self.symmetric = bool(symmetric)
         self.n = len(x)
         g = self.world
-        self.n_loc = (self.n + g - 1) // g
-        n_pad = self.n_loc * g
+        n_loc = (self.n + g - 1) // g
+        if self.symmetric:   # block boundaries must fall on tile boundaries of the symmetric kernel
+            n_loc = (n_loc + SYM_TILE - 1) // SYM_TILE * SYM_TILE
+        self.n_loc = n_loc
+        n_pad = n_loc * g
         pad = n_pad - self.n
 
         def padded(a, fill):
@@ -57,19 +86,45 @@ class ShardedWake:
 
         self.xs, self.zs, self.gs = padded(x, PAD_POS), padded(z, PAD_POS), padded(gamma, 0.0)
         self.n_pad = n_pad
-        self.lo = self.rank * self.n_loc
-        self._send = torch.empty([2, self.n_loc], dtype=torch.float32, device=device)
-        self._recv = torch.empty([g, 2, self.n_loc], dtype=torch.float32, device=device)
+        self.lo = self.rank * n_loc
+        self._send = torch.empty([2, n_loc], dtype=torch.float32, device=device)
+        self._recv = torch.empty([g, 2, n_loc], dtype=torch.float32, device=device)
         self._xz = torch.empty([2, n_pad], dtype=torch.float32, device=device)
+        if self.symmetric:
+            self._acc = torch.empty([2, n_pad], dtype=torch.float32, device=device)
+            self._own = torch.empty([2, n_loc], dtype=torch.float32, device=device)
 
     @property
     def pairs_per_step(self):
         """Whole-job ordered pair interactions of one step (self pairs count; padding does not)."""
         return float(self.n) * float(self.n)
 
+    def _reduce_own_sums(self):
+        """Sum the per-rank partial (u, w) sums and keep this rank's block: one reduce-scatter."""
+        acc, own, g = self._acc, self._own, self.world
+        if g == 1:
+            return acc[0, : self.n_loc], acc[1, : self.n_loc]
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":
+            # [2, G, n_loc] -> [G, 2, n_loc] so that chunk r of the flat input is rank r's (u, w) block
+            stage = acc.view(2, g, self.n_loc).permute(1, 0, 2).contiguous()
+            dist.reduce_scatter_tensor(own.view(-1), stage.view(-1), op=dist.ReduceOp.SUM, group=self.group)
+        else:  # gloo (CPU tests, one-GPU rehearsals) has no reduce_scatter: all-reduce and slice
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
+            own.copy_(acc[:, self.lo:self.lo + self.n_loc])
+        return own[0], own[1]
+
     def step(self):
         send = self._send
-        self.kernel.advect(self.xs, self.zs, self.gs, self.lo, self.n_loc, self.v_core, self.dt, send[0], send[1])
+        if self.symmetric:
+            self._acc.zero_()
+            tiles = self.n_loc // SYM_TILE
+            self.kernel.sym_accumulate(self.xs, self.zs, self.gs, self.rank * tiles, tiles, self.v_core,
+                                       self._acc[0], self._acc[1])
+            su, sw = self._reduce_own_sums()
+            self.kernel.advect_from_sums(su, sw, self.xs, self.zs, self.lo, self.n_loc, self.dt, send[0], send[1])
+        else:
+            self.kernel.advect(self.xs, self.zs, self.gs, self.lo, self.n_loc, self.v_core, self.dt, send[0], send[1])
         if self.world > 1:
             dist.all_gather_into_tensor(self._recv.view(-1), send.view(-1), group=self.group)
             # [G, 2, n_loc] -> [2, G*n_loc].  In-place reuse of _xz is safe: in stream order the pair
@@ -77,7 +132,8 @@ class ShardedWake:
             self._xz.view(2, self.world, self.n_loc).copy_(self._recv.permute(1, 0, 2))
             self.xs, self.zs = self._xz[0], self._xz[1]
         else:
-            self.xs, self.zs = send[0].clone(), send[1].clone()
+            self._xz[:, : self.n_loc].copy_(send)
+            self.xs, self.zs = self._xz[0], self._xz[1]
 
     def positions(self):
         """Current (x, z) of the N real vortices as float32 numpy arrays."""

@@ -181,10 +181,14 @@ def test_device_pointer_entries_with_torch(eng):
         np.testing.assert_allclose(zo.cpu().numpy(), z[lo:lo + cnt] + 0.05 * wr[lo:lo + cnt], rtol=0, atol=2e-6)
         # the shard step with a world of one is the same thing
         from ludvm_amd.sharded import HipShardKernel, ShardedWake
-        wake = ShardedWake(x, z, g, 0.065, 0.05, HipShardKernel(eng), dev)
-        wake.step()
-        xs1, zs1 = wake.positions()
-        np.testing.assert_allclose(xs1, x + 0.05 * ur, rtol=0, atol=2e-6)
+        for symmetric in (True, False):
+            wake = ShardedWake(x, z, g, 0.065, 0.05, HipShardKernel(eng), dev, symmetric=symmetric)
+            wake.step()
+            xs1, zs1 = wake.positions()
+            np.testing.assert_allclose(xs1, x + 0.05 * ur, rtol=0, atol=2e-6)
+            np.testing.assert_allclose(zs1, z + 0.05 * wr, rtol=0, atol=2e-6)
+            wake.step()   # second step reads the re-laid-out buffers
+            assert np.isfinite(wake.positions()[0]).all()
     finally:
         eng.set_stream(None)
 
@@ -296,6 +300,56 @@ def test_symmetric_kernel_tile_edges(eng, n):
         scale = max(np.abs(out[0][0]).max(), np.abs(out[0][1]).max())
         assert np.abs(out[0][0] - out[1][0]).max() < 1e-5 * scale
         assert np.abs(out[0][1] - out[1][1]).max() < 1e-5 * scale
+    finally:
+        eng.set_symmetric(1)
+        eng.set_stream(None)
+
+
+@pytest.mark.parametrize("ranks,n", [(2, 70000), (3, 100000), (8, 300001)])
+def test_symmetric_tile_ring_partition(eng, ranks, n):
+    """Multi-GPU building block on one GPU: the owners of the tile ring, run one after the other with
+    separate accumulators, add up to the full self-interaction (what the reduce-scatter does), and one
+    owner's block step equals the direct advection of that block."""
+    import torch
+    tile = 256
+    n_loc = ((n + ranks - 1) // ranks + tile - 1) // tile * tile
+    n_pad = n_loc * ranks
+    rng = np.random.default_rng(n)
+    x = np.r_[rng.uniform(-10, 0, n), np.full(n_pad - n, 1e6)].astype(np.float32)
+    z = np.r_[rng.uniform(-2, 2, n), np.full(n_pad - n, 1e6)].astype(np.float32)
+    g = np.r_[rng.standard_normal(n) / n, np.zeros(n_pad - n)].astype(np.float32)
+    dev = torch.device("cuda", 0)
+    dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        total = torch.zeros([2, n_pad], device=dev)
+        tiles = n_loc // tile
+        for r in range(ranks):
+            acc = torch.zeros([2, n_pad], device=dev)
+            eng.sym_accumulate_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n_pad, r * tiles, tiles, 0.065,
+                                   acc[0].data_ptr(), acc[1].data_ptr())
+            total += acc
+        torch.cuda.synchronize()
+        u = (total[0] / (2 * np.pi)).cpu().numpy()
+        w = (-total[1] / (2 * np.pi)).cpu().numpy()
+        eng.set_symmetric(0)
+        du, dw = torch.empty(n_pad, device=dev), torch.empty(n_pad, device=dev)
+        eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n_pad, dx.data_ptr(), dz.data_ptr(), n_pad, 0.065,
+                       du.data_ptr(), dw.data_ptr())
+        torch.cuda.synchronize()
+        ud, wd = du.cpu().numpy(), dw.cpu().numpy()
+        scale = max(np.abs(ud[:n]).max(), np.abs(wd[:n]).max())
+        assert np.abs(u[:n] - ud[:n]).max() < 1e-5 * scale and np.abs(w[:n] - wd[:n]).max() < 1e-5 * scale
+        # padding vortices (zero strength, 1e6 away) only feel the far field of the net circulation
+        assert np.abs(u[n:]).max() < 1e-6 * scale and np.abs(w[n:]).max() < 1e-6 * scale
+        # block step of the last owner from its summed block
+        lo = (ranks - 1) * n_loc
+        xo, zo = torch.empty(n_loc, device=dev), torch.empty(n_loc, device=dev)
+        eng.advect_from_sums_dev(total[0, lo:].data_ptr(), total[1, lo:].data_ptr(), dx.data_ptr(), dz.data_ptr(), lo,
+                                 n_loc, 0.05, xo.data_ptr(), zo.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(xo.cpu().numpy(), x[lo:] + 0.05 * ud[lo:], rtol=0, atol=1e-5 * scale * 0.05 + 1e-6)
+        np.testing.assert_allclose(zo.cpu().numpy(), z[lo:] + 0.05 * wd[lo:], rtol=0, atol=1e-5 * scale * 0.05 + 1e-6)
     finally:
         eng.set_symmetric(1)
         eng.set_stream(None)

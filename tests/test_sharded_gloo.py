@@ -14,7 +14,10 @@ from oracle import ludvm_oracle as O
 
 
 class OracleShardKernel:
-    """advect() with the same contract as HipShardKernel, on CPU tensors."""
+    """The shard-step arithmetic with the same contract as HipShardKernel, on CPU tensors (float64
+    NumPy inside).  sym_accumulate follows the symmetric kernel's assignment of unordered pairs to
+    I-tiles: J = I + d (mod NT), d = 1..(NT-1)/2, the half-way offset of an even ring taken by the
+    lower half only, the diagonal tile evaluated ordered."""
 
     def advect(self, xs, zs, gs, t_first, nt, v_core, dt, x_out, z_out):
         x, z, g = xs.numpy().astype(np.float64), zs.numpy().astype(np.float64), gs.numpy().astype(np.float64)
@@ -22,6 +25,44 @@ class OracleShardKernel:
         u, w = O.induced_velocity(g, x, z, x[sl], z[sl], v_core)
         x_out.copy_(torch.from_numpy((x[sl] + dt * u).astype(np.float32)))
         z_out.copy_(torch.from_numpy((z[sl] + dt * w).astype(np.float32)))
+
+    def sym_accumulate(self, xs, zs, gs, tile_first, tile_count, v_core, acc_u, acc_w):
+        x, z, g = xs.numpy().astype(np.float64), zs.numpy().astype(np.float64), gs.numpy().astype(np.float64)
+        n, W = len(x), 256
+        nt = (n + W - 1) // W
+        even = nt % 2 == 0 and nt > 1
+        dtot = (nt - 1) // 2 + (1 if even else 0)
+        au, aw = np.zeros(n), np.zeros(n)
+
+        def block(isl, jsl):
+            dx = x[isl, None] - x[None, jsl]
+            dz = z[isl, None] - z[None, jsl]
+            s = 1.0 / np.sqrt((dx * dx + dz * dz) ** 2 + v_core**4)
+            return dx, dz, s
+
+        for I in range(tile_first, tile_first + tile_count):
+            isl = slice(I * W, min(n, (I + 1) * W))
+            dx, dz, s = block(isl, isl)                     # diagonal tile: ordered, i-side only
+            au[isl] += (g[None, isl] * dz * s).sum(1)
+            aw[isl] += (g[None, isl] * dx * s).sum(1)
+            for d in range(1, dtot + 1):
+                if even and d == dtot and I >= nt // 2:
+                    break
+                J = (I + d) % nt
+                jsl = slice(J * W, min(n, (J + 1) * W))
+                dx, dz, s = block(isl, jsl)
+                au[isl] += (g[None, jsl] * dz * s).sum(1)
+                aw[isl] += (g[None, jsl] * dx * s).sum(1)
+                au[jsl] -= (g[isl, None] * dz * s).sum(0)   # j feels the opposite of what i feels
+                aw[jsl] -= (g[isl, None] * dx * s).sum(0)
+        acc_u += torch.from_numpy(au.astype(np.float32))
+        acc_w += torch.from_numpy(aw.astype(np.float32))
+
+    def advect_from_sums(self, sum_u, sum_w, xs, zs, t_first, nt, dt, x_out, z_out):
+        sl = slice(t_first, t_first + nt)
+        k = 1.0 / (2 * np.pi)
+        x_out.copy_(xs[sl] + dt * (sum_u * k))
+        z_out.copy_(zs[sl] - dt * (sum_w * k))
 
 
 def _wake(n):
@@ -40,14 +81,15 @@ def _serial(n, steps, v_core, dt):
     return x, z
 
 
-def _worker(rank, world, port, n, steps, out):
+def _worker(rank, world, port, n, steps, out, symmetric):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ludvm_amd.sharded import ShardedWake
         x, z, g = _wake(n)
-        wake = ShardedWake(x, z, g, 0.065, 5e-2, OracleShardKernel(), torch.device("cpu"))
-        assert wake.n_loc == (n + world - 1) // world and wake.lo == rank * wake.n_loc
+        wake = ShardedWake(x, z, g, 0.065, 5e-2, OracleShardKernel(), torch.device("cpu"), symmetric=symmetric)
+        per = (n + world - 1) // world
+        assert wake.n_loc == ((per + 255) // 256 * 256 if symmetric else per) and wake.lo == rank * wake.n_loc
         assert wake.pairs_per_step == float(n) * n
         for _ in range(steps):
             wake.step()
@@ -66,20 +108,22 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n", [(2, 600), (3, 601)])
-def test_sharded_steps_equal_serial(tmp_path, world, n):
+@pytest.mark.parametrize("world,n,symmetric", [(2, 600, False), (3, 601, False), (2, 600, True), (3, 601, True),
+                                               (2, 1500, True)])
+def test_sharded_steps_equal_serial(tmp_path, world, n, symmetric):
     out = str(tmp_path / "pos.npy")
-    mp.spawn(_worker, args=(world, _free_port(), n, 3, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, 3, out, symmetric), nprocs=world, join=True)
     got = np.load(out)
     xr, zr = _serial(n, 3, 0.065, 5e-2)
     np.testing.assert_allclose(got[0], xr, rtol=0, atol=2e-6)
     np.testing.assert_allclose(got[1], zr, rtol=0, atol=2e-6)
 
 
-def test_single_process_world_of_one():
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_single_process_world_of_one(symmetric):
     from ludvm_amd.sharded import ShardedWake
     x, z, g = _wake(300)
-    wake = ShardedWake(x, z, g, 0.065, 5e-2, OracleShardKernel(), torch.device("cpu"))
+    wake = ShardedWake(x, z, g, 0.065, 5e-2, OracleShardKernel(), torch.device("cpu"), symmetric=symmetric)
     wake.step()
     wake.step()
     xr, zr = _serial(300, 2, 0.065, 5e-2)
