@@ -144,6 +144,14 @@ int ludvm_wake_read(ludvm_ctx* ctx, size_t first, size_t count, double* x, doubl
  * these O(Npanels x Nw) sums feed the Gamma solve and the loads and cost <1 % of a step. */
 int ludvm_wake_induce_on_points(ludvm_ctx* ctx, size_t src_first, size_t src_count, const double* xt,
                                 const double* zt, size_t nt, double vcore, double* u, double* w);
+/* One call for everything a time step needs at the chord before the Gamma solve: the sum of
+ * ludvm_wake_induce_on_points over wake vortices [src_first, src_first+src_count) -> (u_wake, w_wake)[nt],
+ * plus the velocity induced there by n_unit (<= 4) unit-strength vortices at (unit_x, unit_z) -- the new
+ * TEV and the candidate LEV (LUDVM.py:751, :926, :931) -> u_unit, w_unit as [n_unit][nt] rows.  fp64.
+ * One host->device copy, one device->host copy, one synchronisation. */
+int ludvm_wake_chord_sums(ludvm_ctx* ctx, size_t src_first, size_t src_count, const double* xt, const double* zt,
+                          size_t nt, const double* unit_x, const double* unit_z, size_t n_unit, double vcore,
+                          double* u_wake, double* w_wake, double* u_unit, double* w_unit);
 /* Wake roll-up, fused (LUDVM.py:1095-1127): for every wake vortex i in [0, size):
  *   (u,w)_i = induced by all wake vortices  +  induced by the nfoil bound vortices (foil_x, foil_z,
  *   foil_dgamma: LUDVM.py:1096,1099-1100), both with the same core radius;
@@ -153,6 +161,12 @@ int ludvm_wake_induce_on_points(ludvm_ctx* ctx, size_t src_first, size_t src_cou
 int ludvm_wake_advect(ludvm_ctx* ctx, double dt, const double* foil_x, const double* foil_z,
                       const double* foil_dgamma, size_t nfoil, double vcore, int precision, double* u_out,
                       double* w_out);
+/* Same, and read back the updated positions of the last tail_count wake vortices (the newest TEV / LEV,
+ * which place the next ones: LUDVM.py:680-681, 797-798) in the same call; synchronous when
+ * tail_count > 0. */
+int ludvm_wake_advect_tail(ludvm_ctx* ctx, double dt, const double* foil_x, const double* foil_z,
+                           const double* foil_dgamma, size_t nfoil, double vcore, int precision, size_t tail_count,
+                           double* tail_x, double* tail_z);
 
 /* ---- flow field: backs LUDVM.flowfield (LUDVM.py:1186-1298) -------------------------------- */
 

@@ -45,6 +45,7 @@ struct ludvm_ctx {
   Buf arena;  // staging for the host-pointer entry points
   char* pin = nullptr;  // pinned host ring for small uploads from entry points that do not synchronize
   size_t pin_off = 0;
+  char* pin_out = nullptr;  // pinned host buffer for small synchronous read-backs
 
   // resident wake (float64 master + fp32 mirrors)
   size_t wake_cap = 0, wake_n = 0;
@@ -117,6 +118,17 @@ int h2d(ludvm_ctx* c, void* dst, const void* src, size_t bytes) {
   std::memcpy(c->pin + c->pin_off, src, bytes);
   HIPCHK(c, hipMemcpyAsync(dst, c->pin + c->pin_off, bytes, hipMemcpyHostToDevice, c->stream));
   c->pin_off += need;
+  return LUDVM_OK;
+}
+
+constexpr size_t kPinOutBytes = (size_t)1 << 16;
+
+// Small synchronous device -> host read-back through pinned memory (one DMA, one wait).
+int d2h_small_sync(ludvm_ctx* c, const void* dsrc, size_t bytes, void** host_view) {
+  if (!c->pin_out) HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin_out), kPinOutBytes, hipHostMallocDefault));
+  HIPCHK(c, hipMemcpyAsync(c->pin_out, dsrc, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *host_view = c->pin_out;
   return LUDVM_OK;
 }
 
@@ -413,6 +425,7 @@ int ludvm_destroy(ludvm_ctx* c) {
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
+  if (c->pin_out) (void)hipHostFree(c->pin_out);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return LUDVM_OK;
@@ -743,6 +756,87 @@ int ludvm_wake_induce_on_points(ludvm_ctx* c, size_t src_first, size_t src_count
   HIPCHK(c, hipMemcpyAsync(u, du, nt * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(w, dw, nt * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LUDVM_OK;
+}
+
+int ludvm_wake_chord_sums(ludvm_ctx* c, size_t src_first, size_t src_count, const double* xt, const double* zt, size_t nt,
+                          const double* unit_x, const double* unit_z, size_t n_unit, double vcore, double* u_wake,
+                          double* w_wake, double* u_unit, double* w_unit) {
+  if (!c) return LUDVM_E_ARG;
+  if (src_first + src_count > c->wake_n) return fail(c, LUDVM_E_ARG, "source range outside the wake");
+  if (nt == 0) return LUDVM_OK;
+  if (!xt || !zt || !u_wake || !w_wake) return fail(c, LUDVM_E_ARG, "null array");
+  if (n_unit > 4) return fail(c, LUDVM_E_ARG, "at most 4 unit vortices");
+  if (n_unit && (!unit_x || !unit_z || !u_unit || !w_unit)) return fail(c, LUDVM_E_ARG, "null unit array");
+  const size_t in_doubles = 2 * nt + 2 * n_unit, out_doubles = 2 * nt * (1 + n_unit);
+  if (out_doubles * 8 > kPinOutBytes || in_doubles * 8 > kPinBytes / 4) {
+    // large point sets: the general entry points
+    CHK(ludvm_wake_induce_on_points(c, src_first, src_count, xt, zt, nt, vcore, u_wake, w_wake));
+    const double one = 1.0;
+    for (size_t k = 0; k < n_unit; ++k)
+      CHK(ludvm_induce_f64(c, unit_x + k, unit_z + k, &one, 1, xt, zt, nt, vcore, LUDVM_PREC_F64, u_unit + k * nt,
+                           w_unit + k * nt));
+    return LUDVM_OK;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(ensure(c, c->arena, Arena::need(in_doubles, 8) + Arena::need(out_doubles, 8)));
+  Arena ar(c->arena.p);
+  double* din = ar.take<double>(in_doubles);
+  double* dout = ar.take<double>(out_doubles);
+  std::vector<double> pack(in_doubles);
+  std::memcpy(pack.data(), xt, nt * 8);
+  std::memcpy(pack.data() + nt, zt, nt * 8);
+  if (n_unit) {
+    std::memcpy(pack.data() + 2 * nt, unit_x, n_unit * 8);
+    std::memcpy(pack.data() + 2 * nt + n_unit, unit_z, n_unit * 8);
+  }
+  CHK(h2d(c, din, pack.data(), in_doubles * 8));
+  const double v2 = vcore * vcore;
+  if (src_count) {
+    PairArgs a{};
+    a.xs = c->x64 + src_first; a.zs = c->z64 + src_first; a.gs = c->g64 + src_first;
+    a.ns = (long long)src_count;
+    a.xt = din; a.zt = din + nt; a.nt = (long long)nt;
+    a.vc4 = v2 * v2;
+    CHK(induce_device(c, a, (long long)nt, (long long)src_count, LUDVM_PREC_F64, dout, dout + nt));
+  } else {
+    HIPCHK(c, hipMemsetAsync(dout, 0, 2 * nt * 8, c->stream));
+  }
+  if (n_unit) {
+    hipLaunchKernelGGL(unit_influence_f64, dim3(blocks_for((long long)(nt * n_unit))), dim3(kBlock), 0, c->stream, din,
+                       din + nt, (long long)nt, din + 2 * nt, din + 2 * nt + n_unit, (int)n_unit, v2 * v2, dout + 2 * nt);
+    HIPCHK(c, hipGetLastError());
+  }
+  void* hv = nullptr;
+  CHK(d2h_small_sync(c, dout, out_doubles * 8, &hv));
+  const double* h = static_cast<const double*>(hv);
+  std::memcpy(u_wake, h, nt * 8);
+  std::memcpy(w_wake, h + nt, nt * 8);
+  for (size_t k = 0; k < n_unit; ++k) {
+    std::memcpy(u_unit + k * nt, h + 2 * nt + (2 * k) * nt, nt * 8);
+    std::memcpy(w_unit + k * nt, h + 2 * nt + (2 * k + 1) * nt, nt * 8);
+  }
+  return LUDVM_OK;
+}
+
+int ludvm_wake_advect_tail(ludvm_ctx* c, double dt, const double* foil_x, const double* foil_z, const double* foil_dgamma,
+                           size_t nfoil, double vcore, int precision, size_t tail_count, double* tail_x, double* tail_z) {
+  if (!c) return LUDVM_E_ARG;
+  if (tail_count > c->wake_n) return fail(c, LUDVM_E_ARG, "tail longer than the wake");
+  if (tail_count && (!tail_x || !tail_z)) return fail(c, LUDVM_E_ARG, "null tail array");
+  CHK(ludvm_wake_advect(c, dt, foil_x, foil_z, foil_dgamma, nfoil, vcore, precision, nullptr, nullptr));
+  if (tail_count == 0) return LUDVM_OK;
+  if (2 * tail_count * 8 > kPinOutBytes) return ludvm_wake_read(c, c->wake_n - tail_count, tail_count, tail_x, tail_z, nullptr);
+  // x and z tails are separate device ranges: stage them next to each other, then one read-back
+  CHK(ensure(c, c->arena, Arena::need(2 * tail_count, 8)));
+  double* stage = static_cast<double*>(c->arena.p);
+  const size_t first = c->wake_n - tail_count;
+  HIPCHK(c, hipMemcpyAsync(stage, c->x64 + first, tail_count * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(stage + tail_count, c->z64 + first, tail_count * 8, hipMemcpyDeviceToDevice, c->stream));
+  void* hv = nullptr;
+  CHK(d2h_small_sync(c, stage, 2 * tail_count * 8, &hv));
+  std::memcpy(tail_x, hv, tail_count * 8);
+  std::memcpy(tail_z, static_cast<const double*>(hv) + tail_count, tail_count * 8);
   return LUDVM_OK;
 }
 

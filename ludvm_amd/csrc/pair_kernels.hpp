@@ -355,6 +355,22 @@ cvt_f32_to_f64(const float* in, double* out, long long n) {
   if (i < n) out[i] = (double)in[i];
 }
 
+// Velocity induced at nt points by n_unit unit-strength vortices (the new TEV / LEV of a time step,
+// LUDVM.py:751, :926, :931), fp64: out[(k*2 + 0)*nt + p] = u, out[(k*2 + 1)*nt + p] = w.
+__global__ void __launch_bounds__(kBlock)
+unit_influence_f64(const double* xt, const double* zt, long long nt, const double* ux, const double* uz, int n_unit,
+                   double vc4, double* out) {
+  const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= nt * n_unit) return;
+  const long long k = idx / nt, p = idx - k * nt;
+  const double dx = xt[p] - ux[k];
+  const double dz = zt[p] - uz[k];
+  const double r2 = __builtin_fma(dz, dz, dx * dx);
+  const double s = kInv2PiD / __builtin_sqrt(__builtin_fma(r2, r2, vc4));
+  out[(k * 2 + 0) * nt + p] = dz * s;
+  out[(k * 2 + 1) * nt + p] = -dx * s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Vorticity stencil of LUDVM.flowfield (LUDVM.py:1224-1292): ome = dw/dx - du/dz on the uniform
 // grid, centred in the interior, one-sided on edges and corners.  u, w, ome are [nx][nz], z fastest.

@@ -176,6 +176,25 @@ class Engine:
                                                           len(xt), float(v_core), _pd(u), _pd(w)))
         return u, w
 
+    def wake_chord_sums(self, src_first, src_count, xp, zp, unit_x, unit_z, v_core):
+        """(u_wake, w_wake)[nt] from the resident wake and (u_unit, w_unit)[n_unit, nt] from unit
+        vortices at (unit_x, unit_z), in one round trip (fp64)."""
+        xt, zt, ux, uz = _f64(xp), _f64(zp), _f64(unit_x), _f64(unit_z)
+        nt, nu = len(xt), len(ux)
+        u, w = np.empty(nt), np.empty(nt)
+        uu, wu = np.empty([nu, nt]), np.empty([nu, nt])
+        self._check(self._lib.ludvm_wake_chord_sums(self._ctx, int(src_first), int(src_count), _pd(xt), _pd(zt), nt,
+                                                    _pd(ux), _pd(uz), nu, float(v_core), _pd(u), _pd(w), _pd(uu), _pd(wu)))
+        return u, w, uu, wu
+
+    def wake_advect_tail(self, dt, foil_x, foil_z, foil_dgamma, v_core, tail_count, precision="f32"):
+        """Roll-up step, then the updated (x, z) of the last `tail_count` wake vortices."""
+        fx, fz, fg = _f64(foil_x), _f64(foil_z), _f64(foil_dgamma)
+        tx, tz = np.empty(tail_count), np.empty(tail_count)
+        self._check(self._lib.ludvm_wake_advect_tail(self._ctx, float(dt), _pd(fx), _pd(fz), _pd(fg), len(fx),
+                                                     float(v_core), _prec(precision), int(tail_count), _pd(tx), _pd(tz)))
+        return tx, tz
+
     def wake_advect(self, dt, foil_x, foil_z, foil_dgamma, v_core, precision="f32", return_velocity=False):
         fx, fz, fg = _f64(foil_x), _f64(foil_z), _f64(foil_dgamma)
         u = w = None

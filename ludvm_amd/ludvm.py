@@ -385,11 +385,16 @@ class LUDVM:
             # from the trailing edge to the previous TEV (:672-681)
             tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
 
-            # existing wake -> chord (T1) and unit new TEV -> chord (T2)  (:743-754)
+            # candidate LEV position: only geometry and the previous LEV enter (:788-800), so it is known
+            # before the solve and its unit influence rides in the same device call as the TEV's
+            lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
+
+            # existing wake -> chord (T1), unit new TEV -> chord (T2), unit candidate LEV -> chord (T3):
+            # one round trip (:743-754, :924-934)
             n_wake = nf + itev + ilev
-            u1, w1 = eng.wake_induce_on_points(0, n_wake, xg, zg, vc)
+            u1, w1, uu, wu = eng.wake_chord_sums(0, n_wake, xg, zg, [tev_xy[0], lev_xy[0]], [tev_xy[1], lev_xy[1]], vc)
+            ut1, wt1, ul1, wl1 = uu[0], wu[0], uu[1], wu[1]
             T1 = self._downwash_from(u1, w1, i)
-            ut1, wt1 = eng.induce([1.0], [tev_xy[0]], [tev_xy[1]], xg, zg, vc, precision='f64')
             ut, un = self._chord_frame(ut1, wt1, i)
             T2 = detadx * ut - un
             I1, I2 = T1 @ cm1, T2 @ cm1
@@ -409,12 +414,9 @@ class LUDVM:
             self.LESP_prev[itev] = A[0]
 
             shed = abs(A[0]) >= abs(lesp_crit)                                    # :781
-            ul1 = wl1 = None
             if shed:
                 LEV_shed[i] = ilev
-                lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()  # :788-800
                 lesp_crit = -abs(lesp_crit) if A[0] < 0 else abs(lesp_crit)       # :802-805
-                ul1, wl1 = eng.induce([1.0], [lev_xy[0]], [lev_xy[1]], xg, zg, vc, precision='f64')
                 ult, uln = self._chord_frame(ul1, wl1, i)
                 T3 = detadx * ult - uln
                 I3 = T3 @ cm1
@@ -478,9 +480,9 @@ class LUDVM:
                 new_x.append(0.0); new_z.append(0.0); new_g.append(0.0)
             eng.wake_append(new_x, new_z, new_g)
             n_after = n_wake + len(new_x)
-            eng.wake_advect(dt, xg, zg, dGamma, vc, precision=self.precision)
 
             if record:
+                eng.wake_advect(dt, xg, zg, dGamma, vc, precision=self.precision)
                 xs, zs = eng.wake_read(0, n_after)
                 row_t = np.stack([xs[tev_slot[:itev + 1]], zs[tev_slot[:itev + 1]]])
                 lslots = lev_slot[:ilev + 1] if shed else np.append(lev_slot[:ilev], n_after - 1)
@@ -500,8 +502,9 @@ class LUDVM:
                 elif len(new_x) == 2:
                     eng.wake_truncate(n_after - 1)   # drop the phantom LEV slot
             else:
+                # only the newest TEV / LEV come back: they place the next ones (:680-681, :797-798)
                 k = 2 if shed else 1
-                xs, zs = eng.wake_read(n_after - k, k)
+                xs, zs = eng.wake_advect_tail(dt, xg, zg, dGamma, vc, k, precision=self.precision)
                 last_tev = np.array([xs[0], zs[0]])
                 if shed:
                     last_lev = np.array([xs[1], zs[1]])

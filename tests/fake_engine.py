@@ -14,7 +14,7 @@ class FakeEngine:
         self.x = np.zeros(0)
         self.z = np.zeros(0)
         self.g = np.zeros(0)
-        self.calls = {"induce": 0, "points": 0, "advect": 0}
+        self.calls = {"induce": 0, "points": 0, "advect": 0, "chord": 0}
 
     # stateless
     def induce(self, circulation, xw, zw, xp, zp, v_core, precision="f32"):
@@ -55,6 +55,20 @@ class FakeEngine:
         self.calls["points"] += 1
         s = slice(src_first, src_first + src_count)
         return O.induced_velocity(self.g[s], self.x[s], self.z[s], xp, zp, v_core)
+
+    def wake_chord_sums(self, src_first, src_count, xp, zp, unit_x, unit_z, v_core):
+        self.calls["chord"] += 1
+        s = slice(src_first, src_first + src_count)
+        u, w = O.induced_velocity(self.g[s], self.x[s], self.z[s], xp, zp, v_core)
+        uu = np.empty([len(unit_x), len(xp)])
+        wu = np.empty_like(uu)
+        for k in range(len(unit_x)):
+            uu[k], wu[k] = O.induced_velocity(np.array([1]), np.array([unit_x[k]]), np.array([unit_z[k]]), xp, zp, v_core)
+        return u, w, uu, wu
+
+    def wake_advect_tail(self, dt, foil_x, foil_z, foil_dgamma, v_core, tail_count, precision="f32"):
+        self.wake_advect(dt, foil_x, foil_z, foil_dgamma, v_core, precision)
+        return self.x[-tail_count:].copy(), self.z[-tail_count:].copy()
 
     def wake_advect(self, dt, foil_x, foil_z, foil_dgamma, v_core, precision="f32", return_velocity=False):
         self.calls["advect"] += 1

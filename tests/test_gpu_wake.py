@@ -52,6 +52,33 @@ def test_wake_induce_on_points_is_fp64(eng, offset):
         np.testing.assert_allclose(w, wr, rtol=0, atol=1e-11 * max(1.0, np.abs(wr).max()))
 
 
+def test_wake_chord_sums_and_tail(eng):
+    """The fused per-step calls equal their separate counterparts."""
+    rng = np.random.default_rng(9)
+    n = 5000
+    x, z, g = rng.uniform(-10, 0, n) - 40.0, rng.uniform(-2, 2, n), rng.standard_normal(n)
+    xt, zt = np.linspace(-1, 0, 80) - 40.0, 0.05 * np.sin(np.linspace(0, 3, 80))
+    ux, uz = np.array([-39.99, -41.0]), np.array([0.001, 0.02])
+    eng.wake_clear()
+    eng.wake_append(x, z, g)
+    u, w, uu, wu = eng.wake_chord_sums(0, n, xt, zt, ux, uz, 1.3e-3)
+    ur, wr = O.induced_velocity(g, x, z, xt, zt, 1.3e-3)
+    np.testing.assert_allclose(u, ur, rtol=0, atol=1e-11 * np.abs(ur).max())
+    np.testing.assert_allclose(w, wr, rtol=0, atol=1e-11 * np.abs(wr).max())
+    for k in range(2):
+        ukr, wkr = O.induced_velocity(np.array([1]), ux[k:k + 1], uz[k:k + 1], xt, zt, 1.3e-3)
+        np.testing.assert_allclose(uu[k], ukr, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(wu[k], wkr, rtol=1e-12, atol=1e-13)
+    u0, w0, uu0, _ = eng.wake_chord_sums(0, 0, xt, zt, ux[:1], uz[:1], 1.3e-3)    # empty wake, one unit vortex
+    assert not u0.any() and not w0.any() and uu0.shape == (1, 80)
+    fx, fz, fg = np.linspace(-41, -40, 80), np.zeros(80), rng.standard_normal(80) / 100
+    tx, tz = eng.wake_advect_tail(1e-3, fx, fz, fg, 1.3e-3, 2, precision="f64")
+    xa, za = eng.wake_read(n - 2, 2)
+    assert np.array_equal(tx, xa) and np.array_equal(tz, za)
+    uf, wf = O.induced_velocity(np.r_[g, fg], np.r_[x, fx], np.r_[z, fz], x[-2:], z[-2:], 1.3e-3)
+    np.testing.assert_allclose(tx, x[-2:] + 1e-3 * uf, rtol=0, atol=1e-12)
+
+
 @pytest.mark.parametrize("precision,tol", [("f32", 3e-5), ("f32x2", 3e-6), ("f64", 1e-12)])
 def test_wake_advect_is_one_reference_roll_up_step(eng, precision, tol):
     """wake + bound vortices -> every wake vortex, explicit Euler (LUDVM.py:1095-1127)."""

@@ -40,10 +40,10 @@ def test_config1_matches_reference(sim1, g2):
 
 
 def test_config1_uses_one_point_sum_per_step(sim1):
-    # 400 steps: one wake->chord sum and one fused roll-up per step; unit TEV (+ LEV on 202 steps)
+    # 400 steps: one fused chord call (wake sum + unit TEV / candidate LEV) and one fused roll-up per step
     eng = sim1.engine
-    assert eng.calls["points"] == 400 and eng.calls["advect"] == 400
-    assert eng.calls["induce"] == 400 + 202
+    assert eng.calls["chord"] == 400 and eng.calls["advect"] == 400
+    assert eng.calls["induce"] == 0 and eng.calls["points"] == 0
 
 
 def test_public_methods_match_reference_signatures(sim1, g1_cases):
