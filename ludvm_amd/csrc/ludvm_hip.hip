@@ -299,9 +299,11 @@ bool use_symmetric(const ludvm_ctx* c, long long n) { return c->sym_mode == 1 &&
 // Symmetric kernel over I tiles [i_first, i_first + i_count) of the tile ring of (x, z, g)[0, n); raw sums
 // are ADDED into acc_u / acc_w (n floats each, zeroed by the caller).
 int launch_sym_tiles(ludvm_ctx* c, const float* x, const float* z, const float* g, long long n, long long i_first,
-                     long long i_count, double vc4, float* acc_u, float* acc_w) {
+                     long long i_count, double vc4, float* acc_u, float* acc_w, const float* xl = nullptr,
+                     const float* zl = nullptr) {
   SymArgs a{};
   a.x = x; a.z = z; a.g = g; a.n = n;
+  a.xl = xl; a.zl = zl;
   const long long W = 64LL * kSymT;
   a.ntiles = (n + W - 1) / W;
   a.dmax = (a.ntiles - 1) / 2;
@@ -318,7 +320,10 @@ int launch_sym_tiles(ludvm_ctx* c, const float* x, const float* z, const float* 
   TimedLaunch t{};
   bool active = false;
   CHK(timed_begin(c, t, active));
-  hipLaunchKernelGGL((pair_sym_f32<kSymT>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, c->stream, a);
+  if (xl && zl)
+    hipLaunchKernelGGL((pair_sym_f32<kSymT, true>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL((pair_sym_f32<kSymT, false>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
   CHK(timed_end(c, t, active));
   return LUDVM_OK;
@@ -326,13 +331,14 @@ int launch_sym_tiles(ludvm_ctx* c, const float* x, const float* z, const float* 
 
 // Symmetric self-interaction of all of (x, z, g)[0, n): zero the context's accumulators, run the kernel.
 // The raw sums are left in c->acc as [acc_u | acc_w], each nt_pad floats.
-int launch_sym(ludvm_ctx* c, const float* x, const float* z, const float* g, long long n, double vc4, long long* nt_pad_out) {
+int launch_sym(ludvm_ctx* c, const float* x, const float* z, const float* g, long long n, double vc4, long long* nt_pad_out,
+               const float* xl = nullptr, const float* zl = nullptr) {
   const long long nt_pad = (n + 63) / 64 * 64;
   CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(float)));
   HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(float), c->stream));
   float* acc = static_cast<float*>(c->acc.p);
   const long long ntiles = (n + 64LL * kSymT - 1) / (64LL * kSymT);
-  CHK(launch_sym_tiles(c, x, z, g, n, 0, ntiles, vc4, acc, acc + nt_pad));
+  CHK(launch_sym_tiles(c, x, z, g, n, 0, ntiles, vc4, acc, acc + nt_pad, xl, zl));
   *nt_pad_out = nt_pad;
   return LUDVM_OK;
 }
@@ -859,22 +865,24 @@ int ludvm_wake_advect(ludvm_ctx* c, double dt, const double* foil_x, const doubl
   }
   const long long ns = (long long)(n + nfoil), nt = (long long)n;
   const double v2 = vcore * vcore;
-  if (precision == LUDVM_PREC_F32 && use_symmetric(c, nt)) {
+  if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt)) {
     // wake x wake: each unordered pair once; bound vortices -> wake: direct kernel into slab row 0
+    const bool hilo = precision == LUDVM_PREC_F32X2;
     long long nt_pad = 0;
-    CHK(launch_sym(c, c->xh, c->zh, c->g32, nt, v2 * v2, &nt_pad));
+    CHK(launch_sym(c, c->xh, c->zh, c->g32, nt, v2 * v2, &nt_pad, hilo ? c->xl : nullptr, hilo ? c->zl : nullptr));
     const float* foil_part = nullptr;
     Plan pf{};
     if (nfoil) {
       PairArgs af{};
       af.xs = c->xh + n; af.zs = c->zh + n; af.gs = c->g32 + n; af.ns = (long long)nfoil;
       af.xt = c->xh; af.zt = c->zh; af.nt = nt;
+      if (hilo) { af.xsl = c->xl + n; af.zsl = c->zl + n; af.xtl = c->xl; af.ztl = c->zl; }
       af.vc4 = v2 * v2;
-      pf = make_plan(c, nt, (long long)nfoil, LUDVM_PREC_F32);   // nfoil <= one LDS tile: a single split
+      pf = make_plan(c, nt, (long long)nfoil, precision);   // nfoil <= one LDS tile: a single split
       if (pf.nsplit != 1) return fail(c, LUDVM_E_ARG, "too many bound vortices for the fused roll-up");
       const bool was = c->timing;
       c->timing = false;   // the O(N * Npanels) launch is not the dominant kernel
-      int rc = launch_pair(c, af, pf, LUDVM_PREC_F32, nullptr, nullptr);
+      int rc = launch_pair(c, af, pf, precision, nullptr, nullptr);
       c->timing = was;
       CHK(rc);
       foil_part = static_cast<const float*>(c->part.p);

@@ -29,6 +29,7 @@ namespace ludvm {
 
 struct SymArgs {
   const float* x; const float* z; const float* g;  // N vortices (device)
+  const float* xl; const float* zl;                // lo parts of the positions (HILO kernels only)
   long long n;
   long long ntiles;      // ceil(n / (64*T))
   long long dmax;        // floor((ntiles-1)/2): symmetric offsets 1..dmax (+ ntiles/2 when even)
@@ -50,13 +51,16 @@ __device__ __forceinline__ f32x2 dpp_rol1(f32x2 v) { return (f32x2){dpp_rol1(v.x
 // 88 packed ops + 16 v_rsq_f32; the J tile's (x, z, Gamma) sit in a wave-private LDS slab and are
 // read with a per-lane rotating address (ds_read_b128, off the VALU pipe); only the J accumulators
 // travel between lanes (8 v_mov_b32_dpp, 4 issue cycles each on gfx950).
-template <int T>
+// HILO: positions are hi+lo fp32 pairs, dx = (xh_i - xh_j) + (xl_i - xl_j), +4 packed ops
+// per two unordered pairs; everything after the difference is plain fp32.
+template <int T, bool HILO = false>
 __global__ void __launch_bounds__(kBlock)
 pair_sym_f32(SymArgs a) {
   static_assert(T == 4, "the LDS slab is laid out for 4 vortices (one ds_read_b128) per lane");
   constexpr int H = T / 2;
   constexpr int kWaves = kBlock / 64;
-  __shared__ __attribute__((aligned(16))) float slab[kWaves][3][64 * T];
+  constexpr int kComp = HILO ? 5 : 3;
+  __shared__ __attribute__((aligned(16))) float slab[kWaves][kComp][64 * T];
 
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -68,6 +72,8 @@ pair_sym_f32(SymArgs a) {
   float* const lx = slab[wv][0];
   float* const lz = slab[wv][1];
   float* const lg = slab[wv][2];
+  float* const lxl = slab[wv][HILO ? 3 : 0];
+  float* const lzl = slab[wv][HILO ? 4 : 1];
 
   const bool even = (a.ntiles % 2 == 0) && a.ntiles > 1;
   const long long dtot = a.dmax + (even ? 1 : 0);
@@ -77,19 +83,22 @@ pair_sym_f32(SymArgs a) {
   if (d_hi > dtot + 1) d_hi = dtot + 1;
 
   // my targets (duplicated into register pairs: the packed ops pair two SOURCES against one target)
-  f32x2 xp[T], zp[T], gp[T], au[T], aw[T];
-  f32x4 X, Z, G;
+  f32x2 xp[T], zp[T], gp[T], au[T], aw[T], xpl[T], zpl[T];
+  f32x4 X, Z, G, XL, ZL;
   {
-    float x[T], z[T], g[T];
+    float x[T], z[T], g[T], xl[T], zl[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const long long i = I * W + lane + 64LL * t;
       const bool ok = i < a.n;
       x[t] = ok ? a.x[i] : kPadPosF; z[t] = ok ? a.z[i] : kPadPosF; g[t] = ok ? a.g[i] : 0.0f;
+      xl[t] = (HILO && ok) ? a.xl[i] : 0.0f; zl[t] = (HILO && ok) ? a.zl[i] : 0.0f;
       xp[t] = (f32x2){x[t], x[t]}; zp[t] = (f32x2){z[t], z[t]}; gp[t] = (f32x2){g[t], g[t]};
+      xpl[t] = (f32x2){xl[t], xl[t]}; zpl[t] = (f32x2){zl[t], zl[t]};
       au[t] = (f32x2){0.f, 0.f}; aw[t] = (f32x2){0.f, 0.f};
     }
     X = (f32x4){x[0], x[1], x[2], x[3]}; Z = (f32x4){z[0], z[1], z[2], z[3]}; G = (f32x4){g[0], g[1], g[2], g[3]};
+    XL = (f32x4){xl[0], xl[1], xl[2], xl[3]}; ZL = (f32x4){zl[0], zl[1], zl[2], zl[3]};
   }
   const f32x2 vc4 = {a.vc4, a.vc4};
 
@@ -98,6 +107,10 @@ pair_sym_f32(SymArgs a) {
     *reinterpret_cast<f32x4*>(&lx[lane * T]) = X;
     *reinterpret_cast<f32x4*>(&lz[lane * T]) = Z;
     *reinterpret_cast<f32x4*>(&lg[lane * T]) = G;
+    if (HILO) {
+      *reinterpret_cast<f32x4*>(&lxl[lane * T]) = XL;
+      *reinterpret_cast<f32x4*>(&lzl[lane * T]) = ZL;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -106,15 +119,26 @@ pair_sym_f32(SymArgs a) {
       const f32x4 XJ = *reinterpret_cast<const f32x4*>(&lx[pos]);
       const f32x4 ZJ = *reinterpret_cast<const f32x4*>(&lz[pos]);
       const f32x4 GJ = *reinterpret_cast<const f32x4*>(&lg[pos]);
+      f32x4 XJL, ZJL;
+      if (HILO) {
+        XJL = *reinterpret_cast<const f32x4*>(&lxl[pos]);
+        ZJL = *reinterpret_cast<const f32x4*>(&lzl[pos]);
+      }
 #pragma unroll
       for (int m = 0; m < H; ++m) {
         const f32x2 xj = m ? (f32x2){XJ.z, XJ.w} : (f32x2){XJ.x, XJ.y};
         const f32x2 zj = m ? (f32x2){ZJ.z, ZJ.w} : (f32x2){ZJ.x, ZJ.y};
         const f32x2 gj = m ? (f32x2){GJ.z, GJ.w} : (f32x2){GJ.x, GJ.y};
+        f32x2 xjl, zjl;
+        if (HILO) {
+          xjl = m ? (f32x2){XJL.z, XJL.w} : (f32x2){XJL.x, XJL.y};
+          zjl = m ? (f32x2){ZJL.z, ZJL.w} : (f32x2){ZJL.x, ZJL.y};
+        }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const f32x2 dx = xp[t] - xj;
-          const f32x2 dz = zp[t] - zj;
+          f32x2 dx = xp[t] - xj;
+          f32x2 dz = zp[t] - zj;
+          if (HILO) { dx = dx + (xpl[t] - xjl); dz = dz + (zpl[t] - zjl); }
           f32x2 r2 = dx * dx;
           r2 = __builtin_elementwise_fma(dz, dz, r2);
           const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
@@ -135,16 +159,21 @@ pair_sym_f32(SymArgs a) {
     long long J = I + d;
     if (J >= a.ntiles) J -= a.ntiles;
     {
-      float x[T], z[T], g[T];
+      float x[T], z[T], g[T], xl[T], zl[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const long long j = J * W + lane + 64LL * t;
         const bool ok = j < a.n;
         x[t] = ok ? a.x[j] : kPadPosF; z[t] = ok ? a.z[j] : kPadPosF; g[t] = ok ? a.g[j] : 0.0f;
+        xl[t] = (HILO && ok) ? a.xl[j] : 0.0f; zl[t] = (HILO && ok) ? a.zl[j] : 0.0f;
       }
       *reinterpret_cast<f32x4*>(&lx[lane * T]) = (f32x4){x[0], x[1], x[2], x[3]};
       *reinterpret_cast<f32x4*>(&lz[lane * T]) = (f32x4){z[0], z[1], z[2], z[3]};
       *reinterpret_cast<f32x4*>(&lg[lane * T]) = (f32x4){g[0], g[1], g[2], g[3]};
+      if (HILO) {
+        *reinterpret_cast<f32x4*>(&lxl[lane * T]) = (f32x4){xl[0], xl[1], xl[2], xl[3]};
+        *reinterpret_cast<f32x4*>(&lzl[lane * T]) = (f32x4){zl[0], zl[1], zl[2], zl[3]};
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -161,15 +190,26 @@ pair_sym_f32(SymArgs a) {
       const f32x4 XJ = *reinterpret_cast<const f32x4*>(&lx[pos]);
       const f32x4 ZJ = *reinterpret_cast<const f32x4*>(&lz[pos]);
       const f32x4 GJ = *reinterpret_cast<const f32x4*>(&lg[pos]);
+      f32x4 XJL, ZJL;
+      if (HILO) {
+        XJL = *reinterpret_cast<const f32x4*>(&lxl[pos]);
+        ZJL = *reinterpret_cast<const f32x4*>(&lzl[pos]);
+      }
 #pragma unroll
       for (int m = 0; m < H; ++m) {
         const f32x2 xj = m ? (f32x2){XJ.z, XJ.w} : (f32x2){XJ.x, XJ.y};
         const f32x2 zj = m ? (f32x2){ZJ.z, ZJ.w} : (f32x2){ZJ.x, ZJ.y};
         const f32x2 gj = m ? (f32x2){GJ.z, GJ.w} : (f32x2){GJ.x, GJ.y};
+        f32x2 xjl, zjl;
+        if (HILO) {
+          xjl = m ? (f32x2){XJL.z, XJL.w} : (f32x2){XJL.x, XJL.y};
+          zjl = m ? (f32x2){ZJL.z, ZJL.w} : (f32x2){ZJL.x, ZJL.y};
+        }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const f32x2 dx = xp[t] - xj;
-          const f32x2 dz = zp[t] - zj;
+          f32x2 dx = xp[t] - xj;
+          f32x2 dz = zp[t] - zj;
+          if (HILO) { dx = dx + (xpl[t] - xjl); dz = dz + (zpl[t] - zjl); }
           f32x2 r2 = dx * dx;
           r2 = __builtin_elementwise_fma(dz, dz, r2);
           const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);

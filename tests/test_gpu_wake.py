@@ -105,6 +105,31 @@ def test_wake_advect_is_one_reference_roll_up_step(eng, precision, tol):
     np.testing.assert_allclose(x2, xn + dt * u2, rtol=0, atol=tol * scale * dt + 1e-15)
 
 
+def test_wake_advect_symmetric_hilo_late_time_wake(eng):
+    """The config-2 regime (|x| ~ 50, spacing ~ 1e-3, v_core = 1.3e-3): hi+lo positions keep the
+    symmetric roll-up at 1e-5 where plain fp32 positions lose three digits."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(31)
+    n = 40000
+    x = -50.0 + np.sort(rng.uniform(0, 40, n))                  # a sheet ~1e-3 apart, far from the origin
+    z = 0.3 * np.sin(0.7 * x) + 1e-3 * rng.standard_normal(n)
+    g = rng.standard_normal(n) * 1e-3
+    vc, dt = 1.3e-3, 1e-3
+    ur, wr = c_oracle.induced_velocity(g, x, z, x, z, vc)
+    scale = max(np.abs(ur).max(), np.abs(wr).max())
+    err = {}
+    try:
+        eng.set_symmetric(1)
+        for prec in ("f32", "f32x2"):
+            eng.wake_clear()
+            eng.wake_append(x, z, g)
+            u, w = eng.wake_advect(dt, [], [], [], vc, precision=prec, return_velocity=True)
+            err[prec] = max(np.abs(u - ur).max(), np.abs(w - wr).max()) / scale
+        assert err["f32x2"] < 1e-5 and err["f32x2"] < 0.1 * err["f32"], err
+    finally:
+        eng.set_symmetric(1)
+
+
 def test_wake_advect_symmetric_path(eng):
     """fp32 roll-up of a wake large enough for the symmetric kernel (each unordered pair once) plus the
     direct bound-vortex launch: same answer as the direct kernel and the oracle."""
@@ -117,12 +142,12 @@ def test_wake_advect_symmetric_path(eng):
     ur, wr = c_oracle.induced_velocity(np.r_[g, fg], np.r_[x, fx], np.r_[z, fz], x, z, vc)
     scale = max(np.abs(ur).max(), np.abs(wr).max())
     try:
-        for mode in (1, 0):
+        for mode, prec, tol in ((1, "f32", 3e-5), (0, "f32", 3e-5), (1, "f32x2", 3e-6), (0, "f32x2", 3e-6)):
             eng.set_symmetric(mode)
             eng.wake_clear()
             eng.wake_append(x, z, g)
-            u, w = eng.wake_advect(dt, fx, fz, fg, vc, precision="f32", return_velocity=True)
-            assert np.abs(u - ur).max() <= 3e-5 * scale and np.abs(w - wr).max() <= 3e-5 * scale, mode
+            u, w = eng.wake_advect(dt, fx, fz, fg, vc, precision=prec, return_velocity=True)
+            assert np.abs(u - ur).max() <= tol * scale and np.abs(w - wr).max() <= tol * scale, (mode, prec)
             xn, zn = eng.wake_read(0, n)
             np.testing.assert_allclose(xn, x + dt * ur, rtol=0, atol=3e-5 * scale * dt)
             np.testing.assert_allclose(zn, z + dt * wr, rtol=0, atol=3e-5 * scale * dt)
