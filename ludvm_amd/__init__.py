@@ -10,5 +10,7 @@ include/ludvm_hip.h), the ctypes binding, and the host-side mirror of the refere
 from ._ffi import LudvmHipError  # noqa: F401
 from .engine import Engine  # noqa: F401
 from .ludvm import LUDVM, SparseHistory  # noqa: F401
+from .freevort import (generate_free_vortices, generate_free_single_vortex, generate_flowfield_vortices,  # noqa: F401
+                       generate_flowfield_turbulence)
 
 __version__ = "0.1.0"

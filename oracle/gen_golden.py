@@ -14,6 +14,7 @@ Fixture groups:
   G3 boundary trace   -- every induced_velocity call (arguments and returns) of selected steps.
   G4 flowfield        -- coarse grid at three time steps (LUDVM.py:1186-1298).
   G5 variants         -- method='Ramesh', user free vortices, alpha_m != 0.
+  G6 generators       -- the deterministic free-vortex cloud builders (LUDVM.py:53-96).
 G2-G5 run the unmodified reference class with oracle/airfoils_standin on sys.path (zero camber,
 valid for the symmetric NACA0012 all BASELINE configs use).
 """
@@ -212,9 +213,19 @@ def g5_variants():
     print("G5c alpha_m: ilev", sim.ilev)
 
 
+def g6_generators():
+    """Deterministic free-vortex generators (LUDVM.py:53-96)."""
+    xy1, g1 = REF.generate_free_single_vortex()
+    xy2, g2 = REF.generate_flowfield_vortices()
+    np.savez_compressed(os.path.join(OUT, "g6_generators.npz"), single_xy=xy1, single_gamma=g1, lattice_xy=xy2,
+                        lattice_gamma=g2)
+    print("G6: single", xy1.shape, "lattice", xy2.shape)
+
+
 if __name__ == "__main__":
     g1_kernel_kats()
     g2_g3_g4_config1()
     g5_variants()
+    g6_generators()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("total fixture bytes:", tot)
