@@ -179,7 +179,7 @@ int ludvm_flowfield_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, siz
                         const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
                         float* u, float* w);
 /* Same, device-resident fp32 sources and outputs (asynchronous). */
-int ludvm_flowfield_dev_f32(ludvm_ctx* ctx, float xmin, float zmin, float dr, size_t nx, size_t nz,
+int ludvm_flowfield_dev_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz,
                             const float* d_xs, const float* d_zs, const float* d_gs, size_t ns, float vcore,
                             float* d_u, float* d_w);
 /* Vorticity dw/dx - du/dz on the uniform grid: centred differences inside, one-sided on edges and

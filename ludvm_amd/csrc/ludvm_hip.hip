@@ -943,7 +943,7 @@ int ludvm_wake_advect(ludvm_ctx* c, double dt, const double* foil_x, const doubl
 
 /* ---- flow field ---------------------------------------------------------------------------- */
 
-int ludvm_flowfield_dev_f32(ludvm_ctx* c, float xmin, float zmin, float dr, size_t nx, size_t nz, const float* d_xs,
+int ludvm_flowfield_dev_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, const float* d_xs,
                             const float* d_zs, const float* d_gs, size_t ns, float vcore, float* d_u, float* d_w) {
   if (!c) return LUDVM_E_ARG;
   if (nx == 0 || nz == 0) return LUDVM_OK;

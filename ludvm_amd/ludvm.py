@@ -82,6 +82,8 @@ class LUDVM:
                  snapshot_steps + last step) or 'auto' (full up to nt = 2001)
       snapshot_steps  iterable of time-step indices to record when history is sparse
       run        False builds geometry and kinematics only
+      checkpoint_every, checkpoint_path   write an .npz checkpoint every so many steps (0 = never);
+                 `LUDVM.resume(path)` continues such a run (the reference has no checkpointing)
     """
 
     def __init__(self, t0=0, tf=12, dt=1.5e-2, chord=1, rho=1.225, Uinf=1,
@@ -90,7 +92,12 @@ class LUDVM:
                  alpha_max=10, k=0.2 * np.pi, phi=90, h_max=1,
                  verbose=True, method='Faure',
                  circulation_freevort=None, xy_freevort=None, *,
-                 engine=None, device=0, precision='f32', history='auto', snapshot_steps=(), run=True):
+                 engine=None, device=0, precision='f32', history='auto', snapshot_steps=(), run=True,
+                 checkpoint_every=0, checkpoint_path=None):
+        self._ctor = dict(t0=t0, tf=tf, dt=dt, chord=chord, rho=rho, Uinf=Uinf, Npoints=Npoints, Ncoeffs=Ncoeffs,
+                          LESPcrit=LESPcrit, Naca=Naca, foil_filename=foil_filename, G=G, T=T, alpha_m=alpha_m,
+                          alpha_max=alpha_max, k=k, phi=phi, h_max=h_max, method=method, precision=precision,
+                          history=history, snapshot_steps=sorted(int(s) for s in snapshot_steps))
         # parameters (LUDVM.py:237-263)
         self.t0, self.tf, self.dt = t0, tf, dt
         self.chord, self.rho, self.Uinf = chord, rho, Uinf
@@ -124,6 +131,9 @@ class LUDVM:
         self.precision = precision
         self.history = ('full' if self.nt <= _FULL_HISTORY_MAX_NT else 'sparse') if history == 'auto' else history
         self.snapshot_steps = {int(s) for s in snapshot_steps}
+        self.checkpoint_every, self.checkpoint_path = int(checkpoint_every), checkpoint_path
+        if self.checkpoint_every and not checkpoint_path:
+            raise ValueError("checkpoint_every needs a checkpoint_path")
         self.engine = engine if engine is not None else Engine(device)  # raises without the HIP library / GPU
 
         self.start_time = timeit.default_timer()
@@ -310,11 +320,12 @@ class LUDVM:
     def _record_row(self, i):
         return self.history == 'full' or i in self.snapshot_steps or i == self.nt - 1
 
-    def time_loop(self, print_dt=50, BCcheck=False):
+    def time_loop(self, print_dt=50, BCcheck=False, _resume=None):
         """Time marching (LUDVM.py:597-1171): per step place the new TEV, solve Gamma_TEV (and
         Gamma_LEV when |A0| reaches LESPcrit), rebuild the bound vorticity, integrate the loads and
         convect the wake.  `BCcheck` is accepted for signature compatibility; the reference's check
-        (:1144-1161) raises a shape error and has no effect on the results."""
+        (:1144-1161) raises a shape error and has no effect on the results.  `_resume` is the state a
+        checkpoint holds (see `resume`)."""
         pi, U, c, rho, dt = np.pi, self.Uinf, self.chord, self.rho, self.dt
         eng, vc = self.engine, self.v_core
         nt, nv, nf, npan = self.nt, self.nt - 1, self.n_freevort, self.Npoints - 1
@@ -374,8 +385,29 @@ class LUDVM:
         itev = ilev = 0
         lesp_crit = self.LESPcrit
         LEV_shed = -1 * np.ones(nt)
+        first_step = 1
+        if _resume is not None:
+            R = _resume
+            first_step, itev, ilev = int(R['next_step']), int(R['itev']), int(R['ilev'])
+            lesp_crit, sum_tev, sum_lev = float(R['lesp_crit']), float(R['sum_tev']), float(R['sum_lev'])
+            last_tev = None if np.isnan(R['last_tev']).any() else R['last_tev'].copy()
+            last_lev = None if np.isnan(R['last_lev']).any() else R['last_lev'].copy()
+            LEV_shed, tev_slot, lev_slot = R['LEV_shed'].copy(), R['tev_slot'].copy(), R['lev_slot'].copy()
+            for key in ('TEV', 'LEV', 'bound', 'airfoil', 'gamma_airfoil', 'Gamma_airfoil'):
+                C[key][...] = R['circ_' + key]
+            for name in ('Fn', 'Fs', 'L', 'D', 'T', 'M', 'fourier', 'LESP', 'LESP_prev'):
+                getattr(self, name)[...] = R[name]
+            for key in ('TEV', 'LEV', 'FREE'):
+                if full:
+                    P[key][:first_step] = R['path_' + key]
+                else:
+                    for srow in R['rows_steps']:
+                        P[key].store(int(srow), R[f'row_{key}_{int(srow)}'])
+            eng.wake_clear()
+            eng.wake_append(R['wake_x'], R['wake_z'], R['wake_g'])
+            self.ilev, self.itev, self.LEV_shed = int(R['self_ilev']), int(R['self_itev']), LEV_shed
 
-        for i in range(1, nt):
+        for i in range(first_step, nt):
             if (i == 1 or i == nt - 1 or i / print_dt == int(i / print_dt)) and self.verbose == True:  # noqa: E712
                 print('Step {} out of {}. Elapsed time {}'.format(i, nt - 1, timeit.default_timer() - self.start_time))
             xg, zg = gpts[i, 0, :], gpts[i, 1, :]
@@ -515,7 +547,62 @@ class LUDVM:
                 sum_lev += g_lev
                 ilev += 1
             itev += 1
+            if self.checkpoint_every and i % self.checkpoint_every == 0 and i < nt - 1:
+                self._write_checkpoint(i + 1, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
+                                       tev_slot, lev_slot)
         return None
+
+    # ------------------------------------------------------------------------------------------
+    # checkpoint / resume (not in the reference)
+    # ------------------------------------------------------------------------------------------
+    def _write_checkpoint(self, next_step, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
+                          tev_slot, lev_slot):
+        import json
+        import os
+        C, P = self.circulation, self.path
+        n = self.engine.wake_size()
+        wx, wz, wg = self.engine.wake_read(0, n, gamma=True)
+        nan2 = np.full(2, np.nan)
+        d = dict(ctor=np.array(json.dumps(self._ctor)), next_step=next_step, itev=itev, ilev=ilev, lesp_crit=lesp_crit,
+                 sum_tev=sum_tev, sum_lev=sum_lev, last_tev=nan2 if last_tev is None else last_tev,
+                 last_lev=nan2 if last_lev is None else last_lev, LEV_shed=LEV_shed, tev_slot=tev_slot,
+                 lev_slot=lev_slot, self_itev=self.itev, self_ilev=self.ilev, wake_x=wx, wake_z=wz, wake_g=wg,
+                 circulation_freevort=np.asarray(self.circulation_freevort),
+                 xy_freevort=np.asarray(self.xy_freevort, dtype=float))
+        for key in ('TEV', 'LEV', 'bound', 'airfoil', 'gamma_airfoil', 'Gamma_airfoil'):
+            d['circ_' + key] = C[key]
+        for name in ('Fn', 'Fs', 'L', 'D', 'T', 'M', 'fourier', 'LESP', 'LESP_prev'):
+            d[name] = getattr(self, name)
+        if self.history == 'full':
+            for key in ('TEV', 'LEV', 'FREE'):
+                d['path_' + key] = P[key][:next_step]
+        else:
+            steps = P['TEV'].steps()
+            d['rows_steps'] = np.array(steps, dtype=np.int64)
+            for key in ('TEV', 'LEV', 'FREE'):
+                for srow in steps:
+                    d[f'row_{key}_{srow}'] = P[key][srow]
+        tmp = self.checkpoint_path + '.tmp.npz'
+        np.savez(tmp, **d)
+        os.replace(tmp, self.checkpoint_path)      # a reader never sees a half-written file
+
+    @classmethod
+    def resume(cls, path, engine=None, device=0, verbose=True, checkpoint_every=0, checkpoint_path=None):
+        """Continue a run from a checkpoint written with `checkpoint_every` / `checkpoint_path`: rebuilds
+        geometry and kinematics from the stored constructor arguments, uploads the wake and marches
+        from the stored step to the end."""
+        import json
+        R = np.load(path, allow_pickle=False)
+        kw = json.loads(str(R['ctor']))
+        free = {}
+        if R['circulation_freevort'].size != 1 or float(np.abs(R['circulation_freevort']).sum()) != 0.0 \
+                or float(np.abs(R['xy_freevort']).sum()) != 0.0:
+            free = dict(circulation_freevort=R['circulation_freevort'], xy_freevort=R['xy_freevort'])
+        sim = cls(**kw, **free, verbose=verbose, engine=engine, device=device, run=False,
+                  checkpoint_every=checkpoint_every, checkpoint_path=checkpoint_path)
+        sim.time_loop(_resume=R)
+        sim.compute_coefficients()
+        return sim
 
     # Newton variants of the reference's 'Ramesh' method.  The downwash is linear in the circulations
     # of the vortices being shed, W = T1 + G_tev T2 + G_lev T3, so the reference's repeated

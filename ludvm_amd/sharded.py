@@ -63,6 +63,73 @@ class HipShardKernel:
                                          dt, x_out.data_ptr(), z_out.data_ptr())
 
 
+def flowfield_rows(nx, world, rank):
+    """Contiguous block of grid rows (x index) owned by `rank`: [r0, r1)."""
+    per = (nx + world - 1) // world
+    r0 = min(nx, rank * per)
+    return r0, min(nx, r0 + per)
+
+
+class ShardedFlowfield:
+    """LUDVM.flowfield (LUDVM.py:1186-1298) with the grid rows sharded across ranks: every rank holds
+    all sources and evaluates rows [r0, r1) of the x-major grid (plus one halo row on each interior
+    side, so that the vorticity stencil needs no exchange).  There is no collective on the data path;
+    `gather()` assembles the full fields on every rank for callers that want them.
+
+    `kernel` provides flowfield(xmin, zmin, dr, nx, nz, xs, zs, gs, v_core, u, w) and
+    vorticity(u, w, nx, nz, dr, ome) on [nx, nz] float32 tensors (HipFlowfieldKernel for the product)."""
+
+    def __init__(self, kernel, device, group=None):
+        self.kernel, self.device, self.group = kernel, device, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def compute(self, xmin, zmin, dr, nx, nz, xs, zs, gs, v_core):
+        """(u, w, ome) float32 tensors [r1 - r0, nz] for this rank's rows."""
+        r0, r1 = flowfield_rows(nx, self.world, self.rank)
+        self.rows = (r0, r1)
+        if r1 <= r0:
+            e = torch.empty([0, nz], dtype=torch.float32, device=self.device)
+            return e, e.clone(), e.clone()
+        h0, h1 = max(0, r0 - 1), min(nx, r1 + 1)          # halo rows for the centred differences
+        n_rows = h1 - h0
+        u = torch.empty([n_rows, nz], dtype=torch.float32, device=self.device)
+        w = torch.empty_like(u)
+        ome = torch.empty_like(u)
+        self.kernel.flowfield(xmin + h0 * dr, zmin, dr, n_rows, nz, xs, zs, gs, v_core, u, w)
+        self.kernel.vorticity(u, w, n_rows, nz, dr, ome)
+        # rows computed with a one-sided difference only because the halo ended there are dropped; rows
+        # at the true grid edge keep the reference's one-sided form (:1233-1248)
+        lo, hi = r0 - h0, r0 - h0 + (r1 - r0)
+        return u[lo:hi], w[lo:hi], ome[lo:hi]
+
+    def gather(self, field, nx):
+        """All ranks' row blocks of `field` stacked into [nx, nz] (blocks are padded to equal height)."""
+        if self.world == 1:
+            return field
+        per = (nx + self.world - 1) // self.world
+        nz = field.shape[1]
+        send = torch.zeros([per, nz], dtype=field.dtype, device=field.device)
+        send[: field.shape[0]] = field
+        recv = torch.empty([self.world * per, nz], dtype=field.dtype, device=field.device)
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+        return recv[:nx]
+
+
+class HipFlowfieldKernel:
+    def __init__(self, engine):
+        self.engine = engine
+
+    def flowfield(self, xmin, zmin, dr, nx, nz, xs, zs, gs, v_core, u, w):
+        self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.engine.flowfield_dev(xmin, zmin, dr, nx, nz, xs.data_ptr(), zs.data_ptr(), gs.data_ptr(), xs.numel(), v_core,
+                                  u.data_ptr(), w.data_ptr())
+
+    def vorticity(self, u, w, nx, nz, dr, ome):
+        self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.engine.vorticity_dev(u.data_ptr(), w.data_ptr(), nx, nz, dr, ome.data_ptr())
+
+
 class ShardedWake:
     def __init__(self, x, z, gamma, v_core, dt, kernel, device, group=None, symmetric=True):
         self.group = group

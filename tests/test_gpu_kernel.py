@@ -211,6 +211,34 @@ def test_flowfield_grid_and_vorticity(eng):
         eng.vorticity(u[:1], w[:1], dr)
 
 
+def test_flowfield_row_blocks_with_halo_equal_the_full_grid(eng):
+    """Multi-GPU flow field on one GPU: the row blocks of 3 owners (each with its halo rows) reproduce
+    the single-launch fields bit for bit in (u, w) and in the vorticity."""
+    import torch
+    from ludvm_amd.sharded import HipFlowfieldKernel, ShardedFlowfield, flowfield_rows
+    rng = np.random.default_rng(5)
+    ns, nx, nz, dr = 3000, 50, 33, 0.2
+    dev = torch.device("cuda", 0)
+    xs, zs, gs = (torch.from_numpy(a.astype(np.float32)).to(dev) for a in
+                  (rng.uniform(-10, 0, ns), rng.uniform(-2, 2, ns), rng.standard_normal(ns) / 50))
+    ff = ShardedFlowfield(HipFlowfieldKernel(eng), dev)
+    try:
+        u, w, ome = ff.compute(-10.0, -3.0, dr, nx, nz, xs, zs, gs, 0.065)     # world of one: the full grid
+        assert u.shape == (nx, nz)
+        for world in (3, 7):
+            for rank in range(world):
+                ff.world, ff.rank = world, rank
+                ub, wb, ob = ff.compute(-10.0, -3.0, dr, nx, nz, xs, zs, gs, 0.065)
+                r0, r1 = flowfield_rows(nx, world, rank)
+                # grid x of a block row = (xmin + h0*dr) + i*dr instead of xmin + (h0+i)*dr (double rounding),
+                # and a different launch shape sums the sources in a different order
+                assert torch.allclose(ub, u[r0:r1], rtol=0, atol=1e-5 * float(u.abs().max()))
+                assert torch.allclose(wb, w[r0:r1], rtol=0, atol=1e-5 * float(w.abs().max()))
+                assert torch.allclose(ob, ome[r0:r1], rtol=0, atol=1e-3 * float(ome.abs().max()))
+    finally:
+        eng.set_stream(None)
+
+
 def test_error_reporting(eng):
     from ludvm_amd import LudvmHipError
     eng.wake_clear()

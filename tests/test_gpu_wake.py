@@ -255,3 +255,17 @@ def test_public_induced_velocity_and_downwash(eng, g1_cases):
     c2 = g1_cases["p129x333_inviscid"]
     u, w = sim.induced_velocity(c2["g"], c2["xw"], c2["zw"], c2["xp"], c2["zp"], viscous=False)
     np.testing.assert_allclose(u, c2["u"], rtol=1e-10, atol=1e-12)
+
+
+def test_checkpoint_resume_on_the_device(eng, tmp_path):
+    """A run resumed from a checkpoint (wake re-uploaded from its float64 master) continues bit for bit
+    when the pair sums are deterministic (fp64 direct kernels)."""
+    from ludvm_amd import LUDVM
+    ck = str(tmp_path / "ck.npz")
+    kw = dict(CONFIG1, tf=6)
+    a = LUDVM(**kw, verbose=False, engine=eng, precision="f64")
+    LUDVM(**kw, verbose=False, engine=eng, precision="f64", checkpoint_every=50, checkpoint_path=ck)
+    c = LUDVM.resume(ck, engine=eng, verbose=False)
+    for name in ("Cl", "Cd", "Cm", "LESP", "LEV_shed"):
+        assert np.array_equal(getattr(a, name), getattr(c, name)), name
+    assert np.array_equal(a.path["TEV"][-1], c.path["TEV"][-1])

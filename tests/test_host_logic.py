@@ -127,3 +127,25 @@ def test_plunge_and_efficiency_run():
     assert s.etap.shape == (2,)
     s.motion_plunge(G=1, T=2, alpha_m=4)    # the reference raises TypeError here (LUDVM.py:520)
     assert s.alpha_e.shape == (s.nt,) and np.all(np.isfinite(s.alpha_e))
+
+
+@pytest.mark.parametrize("history", ["full", "sparse"])
+def test_checkpoint_resume_is_bitwise_with_a_deterministic_engine(tmp_path, sim1, history):
+    ck = str(tmp_path / "run.npz")
+    kw = dict(CONFIG1, tf=10)
+    a = LUDVM(**kw, verbose=False, engine=FakeEngine(), history=history, snapshot_steps=[50, 120])
+    b = LUDVM(**kw, verbose=False, engine=FakeEngine(), history=history, snapshot_steps=[50, 120],
+              checkpoint_every=70, checkpoint_path=ck)           # writes at steps 70 and 140
+    c = LUDVM.resume(ck, engine=FakeEngine(), verbose=False)     # continues from step 141
+    for name in ("Cl", "Cd", "Cm", "LESP", "LESP_prev", "fourier", "LEV_shed"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+        assert np.array_equal(getattr(a, name), getattr(c, name)), name
+    for key in ("TEV", "LEV", "bound", "airfoil"):
+        assert np.array_equal(a.circulation[key], c.circulation[key]), key
+    assert (a.itev, a.ilev) == (c.itev, c.ilev)
+    for s in (50, 120, 200):
+        for key in ("TEV", "LEV", "FREE"):
+            ra, rc = a.path[key][s], c.path[key][s]
+            assert np.array_equal(np.asarray(ra), np.asarray(rc)), (key, s)
+    with pytest.raises(ValueError):
+        LUDVM(**kw, verbose=False, engine=FakeEngine(), checkpoint_every=10)

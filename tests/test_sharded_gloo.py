@@ -130,3 +130,53 @@ def test_single_process_world_of_one(symmetric):
     xs, zs = wake.positions()
     np.testing.assert_allclose(xs, xr, rtol=0, atol=2e-6)
     np.testing.assert_allclose(zs, zr, rtol=0, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# flow field: grid rows sharded, halo rows instead of an exchange
+# ---------------------------------------------------------------------------------------------
+class OracleFlowfieldKernel:
+    def flowfield(self, xmin, zmin, dr, nx, nz, xs, zs, gs, v_core, u, w):
+        X, Z = np.meshgrid(xmin + np.arange(nx) * dr, zmin + np.arange(nz) * dr, indexing="ij")
+        uu, ww = O.induced_velocity(gs.numpy().astype(float), xs.numpy().astype(float), zs.numpy().astype(float),
+                                    X.ravel(), Z.ravel(), v_core)
+        u.copy_(torch.from_numpy(uu.reshape(nx, nz).astype(np.float32)))
+        w.copy_(torch.from_numpy(ww.reshape(nx, nz).astype(np.float32)))
+
+    def vorticity(self, u, w, nx, nz, dr, ome):
+        X, Z = np.meshgrid(np.arange(nx) * dr, np.arange(nz) * dr, indexing="ij")
+        ome.copy_(torch.from_numpy(O.vorticity(u.numpy()[None].astype(float), w.numpy()[None].astype(float), X, Z)[0]
+                                   .astype(np.float32)))
+
+
+def _ff_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ludvm_amd.sharded import ShardedFlowfield, flowfield_rows
+        x, z, g = (torch.from_numpy(a) for a in _wake(200))
+        ff = ShardedFlowfield(OracleFlowfieldKernel(), torch.device("cpu"))
+        nx, nz = 23, 9
+        u, w, ome = ff.compute(-10.0, -2.0, 0.5, nx, nz, x, z, g * 200, 0.065)
+        r0, r1 = flowfield_rows(nx, world, rank)
+        assert u.shape == (r1 - r0, nz)
+        full = [ff.gather(f.contiguous(), nx) for f in (u, w, ome)]
+        if rank == 0:
+            np.save(out, np.stack([f.numpy() for f in full]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_flowfield_equals_serial(tmp_path, world):
+    out = str(tmp_path / "ff.npy")
+    mp.spawn(_ff_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    x, z, g = _wake(200)
+    k = OracleFlowfieldKernel()
+    u, w, ome = (torch.empty([23, 9]) for _ in range(3))
+    k.flowfield(-10.0, -2.0, 0.5, 23, 9, torch.from_numpy(x), torch.from_numpy(z), torch.from_numpy(g * 200), 0.065, u, w)
+    k.vorticity(u, w, 23, 9, 0.5, ome)
+    np.testing.assert_allclose(got[0], u.numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got[1], w.numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got[2], ome.numpy(), rtol=0, atol=1e-5)
