@@ -53,15 +53,13 @@ __device__ __forceinline__ f32x2 dpp_rol1(f32x2 v) { return (f32x2){dpp_rol1(v.x
 // travel between lanes (8 v_mov_b32_dpp, 4 issue cycles each on gfx950).
 // HILO: positions are hi+lo fp32 pairs, dx = (xh_i - xh_j) + (xl_i - xl_j), +4 packed ops
 // per two unordered pairs; everything after the difference is plain fp32.
-// LDSACC: the J accumulators live in the wave's LDS slab and each step's partial sums are added with
-// ds_add_f32 (no cross-lane traffic on the VALU pipe) instead of travelling through DPP rotations.
-template <int T, bool HILO = false, bool LDSACC = false>
+template <int T, bool HILO = false>
 __global__ void __launch_bounds__(kBlock)
 pair_sym_f32(SymArgs a) {
   static_assert(T == 4, "the LDS slab is laid out for 4 vortices (one ds_read_b128) per lane");
   constexpr int H = T / 2;
   constexpr int kWaves = kBlock / 64;
-  constexpr int kComp = (HILO ? 5 : 3) + (LDSACC ? 2 : 0);
+  constexpr int kComp = HILO ? 5 : 3;
   __shared__ __attribute__((aligned(16))) float slab[kWaves][kComp][64 * T];
 
   const int lane = threadIdx.x & 63;
@@ -76,8 +74,6 @@ pair_sym_f32(SymArgs a) {
   float* const lg = slab[wv][2];
   float* const lxl = slab[wv][HILO ? 3 : 0];
   float* const lzl = slab[wv][HILO ? 4 : 1];
-  float* const lbu = slab[wv][LDSACC ? kComp - 2 : 0];
-  float* const lbw = slab[wv][LDSACC ? kComp - 1 : 1];
 
   const bool even = (a.ntiles % 2 == 0) && a.ntiles > 1;
   const long long dtot = a.dmax + (even ? 1 : 0);
@@ -178,10 +174,6 @@ pair_sym_f32(SymArgs a) {
         *reinterpret_cast<f32x4*>(&lxl[lane * T]) = (f32x4){xl[0], xl[1], xl[2], xl[3]};
         *reinterpret_cast<f32x4*>(&lzl[lane * T]) = (f32x4){zl[0], zl[1], zl[2], zl[3]};
       }
-      if (LDSACC) {
-        *reinterpret_cast<f32x4*>(&lbu[lane * T]) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(&lbw[lane * T]) = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -226,38 +218,13 @@ pair_sym_f32(SymArgs a) {
           const f32x2 si = s * gp[t];      // strength of i acting on j
           au[t] = __builtin_elementwise_fma(dz, sj, au[t]);
           aw[t] = __builtin_elementwise_fma(dx, sj, aw[t]);
-          if (LDSACC && t == 0) {            // per-step partial: starts from the product, no zeroing
-            bu[m] = dz * si;
-            bw[m] = dx * si;
-          } else {
-            bu[m] = __builtin_elementwise_fma(dz, si, bu[m]);
-            bw[m] = __builtin_elementwise_fma(dx, si, bw[m]);
-          }
+          bu[m] = __builtin_elementwise_fma(dz, si, bu[m]);
+          bw[m] = __builtin_elementwise_fma(dx, si, bw[m]);
         }
       }
-      if (LDSACC) {
-        // this step's partial sums go to the LDS accumulators of the J vortices met (distinct per lane)
+      // hand the J accumulators to the lane that meets the same J vortices next step (lane - 1)
 #pragma unroll
-        for (int m = 0; m < H; ++m) {
-          __hip_atomic_fetch_add(&lbu[pos + 2 * m], bu[m].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          __hip_atomic_fetch_add(&lbu[pos + 2 * m + 1], bu[m].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          __hip_atomic_fetch_add(&lbw[pos + 2 * m], bw[m].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          __hip_atomic_fetch_add(&lbw[pos + 2 * m + 1], bw[m].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-      } else {
-        // hand the J accumulators to the lane that meets the same J vortices next step (lane - 1)
-#pragma unroll
-        for (int m = 0; m < H; ++m) { bu[m] = dpp_rol1(bu[m]); bw[m] = dpp_rol1(bw[m]); }
-      }
-    }
-    if (LDSACC) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const f32x4 BU = *reinterpret_cast<const f32x4*>(&lbu[lane * T]);
-      const f32x4 BW = *reinterpret_cast<const f32x4*>(&lbw[lane * T]);
-      bu[0] = (f32x2){BU.x, BU.y}; bu[1] = (f32x2){BU.z, BU.w};
-      bw[0] = (f32x2){BW.x, BW.y}; bw[1] = (f32x2){BW.z, BW.w};
+      for (int m = 0; m < H; ++m) { bu[m] = dpp_rol1(bu[m]); bw[m] = dpp_rol1(bw[m]); }
     }
     // 64 rotations: the J accumulators are home again; j feels the opposite of what i feels.
     // home lane l holds vortices J*W + l + 64*t as packed elements t = 0..3
