@@ -252,6 +252,12 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
       case 2: hipLaunchKernelGGL((pair_f32<2, kTileF32, true>), grid, dim3(kBlock), 0, c->stream, a); break;
       default: hipLaunchKernelGGL((pair_f32<4, kTileF32, true>), grid, dim3(kBlock), 0, c->stream, a); break;
     }
+  } else if (a.grid_nz > 0 && a.grid_nz % 4 == 0 && c->tune_tpl == 0) {
+    // flow-field grid: 4 consecutive points of a row per lane (shared dx); same target count per block
+    // as TPL = 4, so the plan's grid is recomputed for it
+    const long long ttiles = (a.nt + (long long)kBlock * 4 - 1) / ((long long)kBlock * 4);
+    grid = dim3((unsigned)ttiles, grid.y, 1);
+    hipLaunchKernelGGL((pair_f32<4, kTileF32, false, true>), grid, dim3(kBlock), 0, c->stream, a);
   } else {
     switch (p.tpl) {
       case 1: hipLaunchKernelGGL((pair_f32<1, kTileF32, false>), grid, dim3(kBlock), 0, c->stream, a); break;

@@ -69,10 +69,14 @@ __device__ __forceinline__ void grid_point(const PairArgs& a, long long p, doubl
 //               after the difference is plain fp32 (removes the cancellation error of
 //               |x| ~ 50 against a vortex spacing of ~1e-3).
 // ---------------------------------------------------------------------------------------------
-template <int TPL, int TILE, bool HILO>
+// GRIDROW = true (flow-field grids with nz % TPL == 0): a lane owns TPL CONSECUTIVE grid points of one
+//               row (same x, z stepping by dr), so dx and dx^2 are computed once per source pair and
+//               shared by the lane's targets: 6 instead of 8 packed ops per two pairs and target.
+template <int TPL, int TILE, bool HILO, bool GRIDROW = false>
 __global__ void __launch_bounds__(kBlock)
 pair_f32(PairArgs a) {
   static_assert(TILE % kBlock == 0, "tile must be a multiple of the block size");
+  static_assert(!(GRIDROW && HILO), "the grid variant is plain fp32");
   __shared__ __attribute__((aligned(16))) float lx[TILE];
   __shared__ __attribute__((aligned(16))) float lz[TILE];
   __shared__ __attribute__((aligned(16))) float lg[TILE];
@@ -84,7 +88,9 @@ pair_f32(PairArgs a) {
   const float* __restrict__ gs = static_cast<const float*>(a.gs);
 
   const int tid = threadIdx.x;
-  const long long t0 = ((long long)blockIdx.x * kBlock) * TPL + tid;  // targets tid, tid+256, ...
+  // targets of this lane: tid, tid+256, ... of the block's slab; or TPL consecutive points (GRIDROW)
+  const long long t0 = GRIDROW ? ((long long)blockIdx.x * kBlock + tid) * TPL : ((long long)blockIdx.x * kBlock) * TPL + tid;
+  constexpr long long kTStride = GRIDROW ? 1 : kBlock;
   const long long s_begin = (long long)blockIdx.y * a.chunk;
   long long s_end = s_begin + a.chunk;
   if (s_end > a.ns) s_end = a.ns;
@@ -92,7 +98,7 @@ pair_f32(PairArgs a) {
   f32x2 xp[TPL], zp[TPL], xpl[TPL], zpl[TPL], au[TPL], aw[TPL];
 #pragma unroll
   for (int t = 0; t < TPL; ++t) {
-    const long long ti = t0 + (long long)t * kBlock;
+    const long long ti = t0 + (long long)t * kTStride;
     float x = 0.0f, z = 0.0f, xl = 0.0f, zl = 0.0f;
     if (ti < a.nt) {
       if (a.grid_nz > 0) {
@@ -134,6 +140,13 @@ pair_f32(PairArgs a) {
     }
     __syncthreads();
 
+    // two-level sum: a tile's 1024 contributions are summed on their own and then added to the running
+    // total, so the fp32 rounding error grows with tile + N/tile terms instead of N (a 1e6-source
+    // flow-field launch with one split: 1.6e-5 -> 2e-6 of max|u|)
+    f32x2 tu[TPL], tw[TPL];
+#pragma unroll
+    for (int t = 0; t < TPL; ++t) { tu[t] = (f32x2){0.0f, 0.0f}; tw[t] = (f32x2){0.0f, 0.0f}; }
+
 #pragma unroll 2
     for (int j = 0; j < TILE; j += 4) {
       const f32x4 X = *reinterpret_cast<const f32x4*>(&lx[j]);
@@ -154,6 +167,21 @@ pair_f32(PairArgs a) {
           xl2 = h ? (f32x2){XL.z, XL.w} : (f32x2){XL.x, XL.y};
           zl2 = h ? (f32x2){ZL.z, ZL.w} : (f32x2){ZL.x, ZL.y};
         }
+        if (GRIDROW) {
+          const f32x2 dx = xp[0] - xs2;      // every target of the lane sits in the same grid row
+          const f32x2 dxx = dx * dx;
+#pragma unroll
+          for (int t = 0; t < TPL; ++t) {
+            const f32x2 dz = zp[t] - zs2;
+            const f32x2 r2 = __builtin_elementwise_fma(dz, dz, dxx);
+            const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
+            f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+            s = s * gs2;
+            tu[t] = __builtin_elementwise_fma(dz, s, tu[t]);
+            tw[t] = __builtin_elementwise_fma(dx, s, tw[t]);
+          }
+          continue;
+        }
 #pragma unroll
         for (int t = 0; t < TPL; ++t) {
           f32x2 dx = xp[t] - xs2;
@@ -167,17 +195,19 @@ pair_f32(PairArgs a) {
           const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
           f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
           s = s * gs2;
-          au[t] = __builtin_elementwise_fma(dz, s, au[t]);
-          aw[t] = __builtin_elementwise_fma(dx, s, aw[t]);
+          tu[t] = __builtin_elementwise_fma(dz, s, tu[t]);
+          tw[t] = __builtin_elementwise_fma(dx, s, tw[t]);
         }
       }
     }
+#pragma unroll
+    for (int t = 0; t < TPL; ++t) { au[t] = au[t] + tu[t]; aw[t] = aw[t] + tw[t]; }
   }
 
   const float scale = (float)kInv2PiD;
 #pragma unroll
   for (int t = 0; t < TPL; ++t) {
-    const long long ti = t0 + (long long)t * kBlock;
+    const long long ti = t0 + (long long)t * kTStride;
     if (ti < a.nt) {
       const float uu = (au[t].x + au[t].y) * scale;
       const float ww = -(aw[t].x + aw[t].y) * scale;

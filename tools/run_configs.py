@@ -29,6 +29,7 @@ def cfg5(args):
     dev = torch.device("cuda", 0)
     eng = Engine(0)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_tuning(args.tpl, 0)      # tpl != 0 forces the generic kernel (no shared-dx grid variant)
     dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
     du = torch.empty(nx * nz, dtype=torch.float32, device=dev)
     dw = torch.empty_like(du)
@@ -56,7 +57,7 @@ def cfg5(args):
     ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float), xt, zt, 0.065)
     u, w = du.cpu().numpy()[sel], dw.cpu().numpy()[sel]
     err = max(np.abs(u - ur).max(), np.abs(w - wr).max()) / max(np.abs(ur).max(), np.abs(wr).max())
-    print(json.dumps({"config": f"cfg5 flowfield {nx}x{nz} grid over N={n}", "s_per_call": el, "pairs_per_s": pairs / el,
+    print(json.dumps({"config": f"cfg5 flowfield {nx}x{nz} grid over N={n}", "kernel": "generic tpl=%d" % args.tpl if args.tpl else "grid-row (shared dx)", "s_per_call": el, "pairs_per_s": pairs / el,
                       "pair_kernel_ms": kms, "pct_fp32_peak": 13 * pairs / (kms * 1e-3) / 157.3e12 * 100,
                       "sampled_rel_err_vs_oracle": err, "omega_finite": bool(torch.isfinite(dome).all().item())}))
 
@@ -88,6 +89,7 @@ if __name__ == "__main__":
     ap.add_argument("--vortices", type=int, default=1_000_000)
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--tpl", type=int, default=0)
     ap.add_argument("--tf", type=float, default=50.0)
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--verbose", action="store_true")
