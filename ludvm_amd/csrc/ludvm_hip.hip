@@ -550,9 +550,20 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
     hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)nt)), bs, 0, c->stream, dxt, fxt, fxtl, (long long)nt);
     hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)nt)), bs, 0, c->stream, dzt, fzt, fztl, (long long)nt);
     HIPCHK(c, hipGetLastError());
-    a.xs = fxs; a.zs = fzs; a.gs = fgs; a.xsl = fxsl; a.zsl = fzsl;
-    a.xt = fxt; a.zt = fzt; a.xtl = fxtl; a.ztl = fztl;
-    CHK(induce_device(c, a, (long long)nt, (long long)ns, precision, fu, fw));
+    if (xt == xs && zt == zs && nt == ns && use_symmetric(c, (long long)ns)) {
+      // the caller passed the same arrays as sources and targets (self-interaction): symmetric kernel
+      long long nt_pad = 0;
+      const bool hilo = precision == LUDVM_PREC_F32X2;
+      CHK(launch_sym(c, fxs, fzs, fgs, (long long)ns, a.vc4, &nt_pad, hilo ? fxsl : nullptr, hilo ? fzsl : nullptr));
+      const float* acc = static_cast<const float*>(c->acc.p);
+      hipLaunchKernelGGL(finish_sym, dim3(blocks_for((long long)nt)), bs, 0, c->stream, acc, acc + nt_pad, (long long)nt, fu,
+                         fw);
+      HIPCHK(c, hipGetLastError());
+    } else {
+      a.xs = fxs; a.zs = fzs; a.gs = fgs; a.xsl = fxsl; a.zsl = fzsl;
+      a.xt = fxt; a.zt = fzt; a.xtl = fxtl; a.ztl = fztl;
+      CHK(induce_device(c, a, (long long)nt, (long long)ns, precision, fu, fw));
+    }
     hipLaunchKernelGGL(cvt_f32_to_f64, dim3(blocks_for((long long)nt)), bs, 0, c->stream, fu, du, (long long)nt);
     hipLaunchKernelGGL(cvt_f32_to_f64, dim3(blocks_for((long long)nt)), bs, 0, c->stream, fw, dw, (long long)nt);
     HIPCHK(c, hipGetLastError());

@@ -102,7 +102,11 @@ class Engine:
     # -- stateless pair sum ----------------------------------------------------------------------
     def induce(self, circulation, xw, zw, xp, zp, v_core, precision="f32"):
         """(u, w) float64 arrays; host arrays in, host arrays out (LUDVM.py:549-570)."""
-        g, xs, zs, xt, zt = _f64(circulation), _f64(xw), _f64(zw), _f64(xp), _f64(zp)
+        g, xs, zs = _f64(circulation), _f64(xw), _f64(zw)
+        # the same objects as targets (self-interaction) stay the same buffers, which lets the library
+        # pick the symmetric kernel
+        xt = xs if xp is xw else _f64(xp)
+        zt = zs if zp is zw else _f64(zp)
         if not (len(g) == len(xs) == len(zs)) or len(xt) != len(zt):
             raise ValueError("induce: source arrays (and target arrays) must have equal lengths")
         u, w = np.empty(len(xt)), np.empty(len(xt))

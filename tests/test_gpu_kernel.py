@@ -112,6 +112,7 @@ def test_launch_shapes_agree_and_are_reproducible(eng):
     ur, wr = c_oracle.induced_velocity(g, xs, zs, xs, zs, 0.065)
     results = {}
     try:
+        eng.set_symmetric(0)      # the property under test belongs to the direct kernel (no atomics)
         for tpl in (1, 2, 4):
             for splits in (1, 3, 16):
                 eng.set_tuning(tpl, splits)
@@ -122,6 +123,7 @@ def test_launch_shapes_agree_and_are_reproducible(eng):
                 results[(tpl, splits)] = u
     finally:
         eng.set_tuning(0, 0)
+        eng.set_symmetric(1)
 
 
 def test_linearity_and_antisymmetry(eng):
@@ -141,6 +143,29 @@ def test_linearity_and_antisymmetry(eng):
     # a single vortex induces nothing on itself
     u, w = eng.induce([3.0], [0.5], [0.25], [0.5], [0.25], 0.065)
     assert u[0] == 0.0 and w[0] == 0.0
+
+
+def test_host_entry_uses_symmetric_kernel_for_self_interaction(eng):
+    rng = np.random.default_rng(41)
+    n = 30000
+    x, z, g = rng.uniform(-10, 0, n), rng.uniform(-2, 2, n), rng.standard_normal(n) / n
+    ur, wr = c_oracle.induced_velocity(g, x, z, x, z, 0.065)
+    try:
+        for prec, tol in (("f32", 1e-5), ("f32x2", 2e-6)):
+            eng.set_symmetric(0)
+            ud, wd = eng.induce(g, x, z, x, z, 0.065, precision=prec)
+            eng.set_symmetric(1)
+            eng.kernel_timing(True)
+            eng.kernel_time_ms(reset=True)
+            us, ws = eng.induce(g, x, z, x, z, 0.065, precision=prec)      # same objects -> symmetric path
+            _, launches = eng.kernel_time_ms(reset=True)
+            eng.kernel_timing(False)
+            assert launches == 1
+            assert _rel(us, ws, ur, wr) < tol and _rel(ud, wd, ur, wr) < tol
+            assert not np.array_equal(us, ud)                               # a different kernel did run
+    finally:
+        eng.set_symmetric(1)
+        eng.kernel_timing(False)
 
 
 def test_host_float32_entry(eng):
