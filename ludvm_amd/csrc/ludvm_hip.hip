@@ -300,7 +300,10 @@ constexpr int kSymT = 4;                // vortices per lane of the symmetric ke
 static_assert(64 * kSymT == LUDVM_SYM_TILE, "header and kernel disagree on the symmetric tile");
 constexpr long long kSymTargetWaves = 65536;
 
-bool use_symmetric(const ludvm_ctx* c, long long n) { return c->sym_mode == 1 && n >= kSymMinN; }
+bool use_symmetric(const ludvm_ctx* c, long long n) {
+  if (c->sym_mode == 0) return false;
+  return n >= (c->sym_mode == 1 ? kSymMinN : (long long)c->sym_mode);
+}
 
 // Symmetric kernel over I tiles [i_first, i_first + i_count) of the tile ring of (x, z, g)[0, n); raw sums
 // are ADDED into acc_u / acc_w (n floats each, zeroed by the caller).
@@ -486,7 +489,7 @@ int ludvm_set_tuning(ludvm_ctx* c, int targets_per_lane, int source_splits) {
 
 int ludvm_set_symmetric(ludvm_ctx* c, int mode) {
   if (!c) return LUDVM_E_ARG;
-  if (mode != 0 && mode != 1) return fail(c, LUDVM_E_ARG, "symmetric mode must be 0 or 1");
+  if (mode < 0) return fail(c, LUDVM_E_ARG, "symmetric mode must be >= 0");
   c->sym_mode = mode;
   return LUDVM_OK;
 }
