@@ -191,6 +191,31 @@ class Engine:
                                                     _pd(ux), _pd(uz), nu, float(v_core), _pd(u), _pd(w), _pd(uu), _pd(wu)))
         return u, w, uu, wu
 
+    def step_buffers(self, npoints):
+        """Preallocated host buffers (and their ctypes pointers) for the two per-step calls of a time
+        loop with `npoints` chord points: removes the per-call array allocation and pointer casting."""
+        b = type("StepBuffers", (), {})()
+        b.n = npoints
+        b.unit = np.zeros([2, 2])                       # [x|z][tev, lev]
+        b.u, b.w = np.empty(npoints), np.empty(npoints)
+        b.uu, b.wu = np.empty([2, npoints]), np.empty([2, npoints])
+        b.tail = np.empty([2, 2])                       # [x|z][newest two]
+        b.p_unit_x, b.p_unit_z = _pd(b.unit[0]), _pd(b.unit[1])
+        b.p_u, b.p_w, b.p_uu, b.p_wu = _pd(b.u), _pd(b.w), _pd(b.uu), _pd(b.wu)
+        b.p_tx, b.p_tz = _pd(b.tail[0]), _pd(b.tail[1])
+        return b
+
+    def wake_chord_sums_into(self, b, src_count, xp, zp, v_core):
+        """wake_chord_sums over sources [0, src_count) with the unit vortices in b.unit, results in
+        b.u, b.w, b.uu, b.wu.  xp, zp must be contiguous float64 arrays of length b.n."""
+        self._check(self._lib.ludvm_wake_chord_sums(self._ctx, 0, src_count, _pd(xp), _pd(zp), b.n, b.p_unit_x, b.p_unit_z,
+                                                    2, v_core, b.p_u, b.p_w, b.p_uu, b.p_wu))
+
+    def wake_advect_tail_into(self, b, dt, foil_x, foil_z, foil_dgamma, v_core, tail_count, precision):
+        """wake_advect_tail with contiguous float64 foil arrays; newest positions land in b.tail[:, :tail_count]."""
+        self._check(self._lib.ludvm_wake_advect_tail(self._ctx, dt, _pd(foil_x), _pd(foil_z), _pd(foil_dgamma),
+                                                     len(foil_x), v_core, precision, tail_count, b.p_tx, b.p_tz))
+
     def wake_advect_tail(self, dt, foil_x, foil_z, foil_dgamma, v_core, tail_count, precision="f32"):
         """Roll-up step, then the updated (x, z) of the last `tail_count` wake vortices."""
         fx, fz, fg = _f64(foil_x), _f64(foil_z), _f64(foil_dgamma)

@@ -407,6 +407,11 @@ class LUDVM:
             eng.wake_append(R['wake_x'], R['wake_z'], R['wake_g'])
             self.ilev, self.itev, self.LEV_shed = int(R['self_ilev']), int(R['self_itev']), LEV_shed
 
+        # preallocated host buffers for the two device calls of a step (engines that offer them)
+        sb = eng.step_buffers(npan) if hasattr(eng, 'step_buffers') else None
+        prec_code = {'f32': 0, 'f32x2': 1, 'f64': 2}[self.precision]
+        vc_f, dt_f = float(vc), float(dt)
+
         for i in range(first_step, nt):
             if (i == 1 or i == nt - 1 or i / print_dt == int(i / print_dt)) and self.verbose == True:  # noqa: E712
                 print('Step {} out of {}. Elapsed time {}'.format(i, nt - 1, timeit.default_timer() - self.start_time))
@@ -424,8 +429,13 @@ class LUDVM:
             # existing wake -> chord (T1), unit new TEV -> chord (T2), unit candidate LEV -> chord (T3):
             # one round trip (:743-754, :924-934)
             n_wake = nf + itev + ilev
-            u1, w1, uu, wu = eng.wake_chord_sums(0, n_wake, xg, zg, [tev_xy[0], lev_xy[0]], [tev_xy[1], lev_xy[1]], vc)
-            ut1, wt1, ul1, wl1 = uu[0], wu[0], uu[1], wu[1]
+            if sb is not None:
+                sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1] = tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]
+                eng.wake_chord_sums_into(sb, n_wake, xg, zg, vc_f)
+                u1, w1, ut1, wt1, ul1, wl1 = sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1]
+            else:
+                u1, w1, uu, wu = eng.wake_chord_sums(0, n_wake, xg, zg, [tev_xy[0], lev_xy[0]], [tev_xy[1], lev_xy[1]], vc)
+                ut1, wt1, ul1, wl1 = uu[0], wu[0], uu[1], wu[1]
             T1 = self._downwash_from(u1, w1, i)
             ut, un = self._chord_frame(ut1, wt1, i)
             T2 = detadx * ut - un
@@ -536,7 +546,11 @@ class LUDVM:
             else:
                 # only the newest TEV / LEV come back: they place the next ones (:680-681, :797-798)
                 k = 2 if shed else 1
-                xs, zs = eng.wake_advect_tail(dt, xg, zg, dGamma, vc, k, precision=self.precision)
+                if sb is not None:
+                    eng.wake_advect_tail_into(sb, dt_f, xg, zg, dGamma, vc_f, k, prec_code)
+                    xs, zs = sb.tail[0], sb.tail[1]
+                else:
+                    xs, zs = eng.wake_advect_tail(dt, xg, zg, dGamma, vc, k, precision=self.precision)
                 last_tev = np.array([xs[0], zs[0]])
                 if shed:
                     last_lev = np.array([xs[1], zs[1]])
