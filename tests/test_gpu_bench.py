@@ -1,0 +1,51 @@
+"""GPU tier: the bench.py output contract (one JSON line with the metric, roofline and cpu_baseline
+objects), on a small workload so it runs in seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(*args):
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines           # exactly one line on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("symmetric", [1, 0])
+def test_bench_json_contract(symmetric):
+    d = _run("--vortices", "40000", "--steps", "3", "--warmup", "1", "--cpu-rows", "64", "--symmetric", str(symmetric))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and d["config"]["kernel_variant"] == ("symmetric" if symmetric else "direct")
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and r["kernel_launches_timed"] == 3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    # whole-job value is consistent with the step time, and the kernel time is inside the step time
+    assert abs(d["value"] - 40000.0**2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert r["kernel_ms_avg"] <= d["ms_per_step"] * 1.02
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "pairs/s" and c["value"] > 1e6
+    assert c["gpu_vs_oracle_max_rel_err"] < 1e-5
+
+
+def test_bench_config4_shape_on_one_gpu():
+    d = _run("--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1", "--cpu-rows", "0")
+    assert d["scaling"] == "strong" and "config 4" in d["config"]["workload"] and "cpu_baseline" not in d
+    assert d["value"] > 1e11
