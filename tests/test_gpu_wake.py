@@ -269,3 +269,20 @@ def test_checkpoint_resume_on_the_device(eng, tmp_path):
     for name in ("Cl", "Cd", "Cm", "LESP", "LEV_shed"):
         assert np.array_equal(getattr(a, name), getattr(c, name)), name
     assert np.array_equal(a.path["TEV"][-1], c.path["TEV"][-1])
+
+
+def test_config2_regime_first_300_steps(eng):
+    """BASELINE config 2's parameters (dt = 1e-3, v_core = 1.3e-3, NACA0012 sinusoidal pitch) over the
+    first 300 steps against the oracle: fp64 mode to rounding, fp32 modes to their tier (the shed
+    vortices are ~1e-3 apart, the regime the hi+lo positions are for)."""
+    from ludvm_amd import LUDVM
+    kw = dict(CONFIG1, dt=1e-3, tf=0.3)
+    ref = O.OracleLUDVM(**kw)
+    assert ref.nt == 301 and abs(ref.v_core - 1.3e-3) < 1e-15
+    for prec, tol_load, tol_pos in (("f64", 1e-9, 1e-11), ("f32x2", 1e-5, 1e-6), ("f32", 1e-3, 1e-4)):
+        sim = LUDVM(**kw, verbose=False, engine=eng, precision=prec)
+        assert np.array_equal(sim.LEV_shed, ref.LEV_shed), prec
+        for name in ("Cl", "Cd", "Cm"):
+            assert np.abs(getattr(sim, name) - getattr(ref, name)).max() <= tol_load * max(1.0, np.abs(getattr(ref, name)).max()), (prec, name)
+        assert np.abs(sim.path["TEV"][-1] - ref.path["TEV"][-1]).max() <= tol_pos, prec
+        assert np.abs(sim.circulation["TEV"] - ref.circulation["TEV"]).max() <= tol_load, prec
