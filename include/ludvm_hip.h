@@ -169,6 +169,24 @@ int ludvm_wake_advect_tail(ludvm_ctx* ctx, double dt, const double* foil_x, cons
                            const double* foil_dgamma, size_t nfoil, double vcore, int precision, size_t tail_count,
                            double* tail_x, double* tail_z);
 
+/* One round trip per time step -- one packed upload, one staging kernel, the pair kernels, one download:
+ *   1. append the n_new vortices shed this step (new_x/z/gamma; LUDVM.py:672-681, 788-800, 953-954);
+ *   2. the roll-up of step i exactly as ludvm_wake_advect (LUDVM.py:1095-1127);
+ *   3. what step i+1 needs before its Gamma solve:
+ *      - placement of the next TEV and of the candidate LEV from the advected positions: one third of the
+ *        way from the trailing edge te[2] / leading edge le[2] (of step i+1) to the newest TEV (vortex
+ *        size - tail_count) / newest LEV (vortex size - 1, used when lev_from_prev != 0 and tail_count == 2;
+ *        otherwise the candidate sits on the leading edge)  (LUDVM.py:680-681, :788-800);
+ *      - ludvm_wake_chord_sums over the whole advected wake at the nt points (xt, zt) of step i+1 with those
+ *        two unit vortices.
+ * Outputs: tail_x/z[tail_count] (updated newest vortices), unit_x/z[2] (the placed TEV, LEV candidate),
+ * u_wake/w_wake[nt], u_unit/w_unit[2][nt].  tail_count is 1 or 2. */
+int ludvm_wake_step(ludvm_ctx* ctx, const double* new_x, const double* new_z, const double* new_gamma, size_t n_new,
+                    double dt, const double* foil_x, const double* foil_z, const double* foil_dgamma, size_t nfoil,
+                    double vcore, int precision, const double* te, const double* le, int lev_from_prev,
+                    size_t tail_count, const double* xt, const double* zt, size_t nt, double* tail_x, double* tail_z,
+                    double* unit_x, double* unit_z, double* u_wake, double* w_wake, double* u_unit, double* w_unit);
+
 /* ---- flow field: backs LUDVM.flowfield (LUDVM.py:1186-1298) -------------------------------- */
 
 /* Grid targets generated on the device, x-major ravel like np.meshgrid(indexing='ij')

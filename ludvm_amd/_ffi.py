@@ -51,6 +51,8 @@ SIGNATURES = {
                               _pd, _pd],
     "ludvm_wake_advect": [c_void_p, c_double, _pd, _pd, _pd, c_size_t, c_double, c_int, _pd, _pd],
     "ludvm_wake_advect_tail": [c_void_p, c_double, _pd, _pd, _pd, c_size_t, c_double, c_int, c_size_t, _pd, _pd],
+    "ludvm_wake_step": [c_void_p, _pd, _pd, _pd, c_size_t, c_double, _pd, _pd, _pd, c_size_t, c_double, c_int, _pd, _pd,
+                        c_int, c_size_t, _pd, _pd, c_size_t, _pd, _pd, _pd, _pd, _pd, _pd, _pd, _pd],
     "ludvm_flowfield_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, _pd, _pd, _pd, c_size_t,
                             c_double, _pf, _pf],
     "ludvm_flowfield_dev_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, c_void_p, c_void_p,

@@ -46,6 +46,7 @@ struct ludvm_ctx {
   char* pin = nullptr;  // pinned host ring for small uploads from entry points that do not synchronize
   size_t pin_off = 0;
   char* pin_out = nullptr;  // pinned host buffer for small synchronous read-backs
+  std::vector<double> pack;  // host staging of a time step's packed upload
 
   // resident wake (float64 master + fp32 mirrors)
   size_t wake_cap = 0, wake_n = 0;
@@ -866,23 +867,11 @@ int ludvm_wake_advect_tail(ludvm_ctx* c, double dt, const double* foil_x, const 
   return LUDVM_OK;
 }
 
-int ludvm_wake_advect(ludvm_ctx* c, double dt, const double* foil_x, const double* foil_z, const double* foil_dgamma,
-                      size_t nfoil, double vcore, int precision, double* u_out, double* w_out) {
-  if (!c) return LUDVM_E_ARG;
-  if (!valid_precision(precision)) return fail(c, LUDVM_E_ARG, "unknown precision");
-  if (nfoil && (!foil_x || !foil_z || !foil_dgamma)) return fail(c, LUDVM_E_ARG, "null foil array");
-  if ((u_out == nullptr) != (w_out == nullptr)) return fail(c, LUDVM_E_ARG, "u_out and w_out go together");
+// Roll-up launch on the resident wake (n vortices) with `nfoil` bound vortices already staged behind it
+// at [n, n + nfoil) (masters and mirrors): pair kernel(s) + Euler finisher.  du/dw: optional device
+// arrays receiving the induced velocities.
+static int advect_launch(ludvm_ctx* c, double dt, size_t nfoil, double vcore, int precision, double* du, double* dw) {
   const size_t n = c->wake_n;
-  if (n == 0) return LUDVM_OK;
-  HIPCHK(c, hipSetDevice(c->device));
-  // bound vortices ride behind the wake in the same source arrays for this launch
-  CHK(wake_grow(c, n + nfoil));
-  if (nfoil) {
-    CHK(h2d(c, c->x64 + n, foil_x, nfoil * 8));
-    CHK(h2d(c, c->z64 + n, foil_z, nfoil * 8));
-    CHK(h2d(c, c->g64 + n, foil_dgamma, nfoil * 8));
-    CHK(wake_refresh(c, n, nfoil));
-  }
   const long long ns = (long long)(n + nfoil), nt = (long long)n;
   const double v2 = vcore * vcore;
   if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt)) {
@@ -907,22 +896,10 @@ int ludvm_wake_advect(ludvm_ctx* c, double dt, const double* foil_x, const doubl
       CHK(rc);
       foil_part = static_cast<const float*>(c->part.p);
     }
-    double *du = nullptr, *dw = nullptr;
-    if (u_out) {
-      CHK(ensure(c, c->arena, 2 * Arena::need(n, 8)));
-      Arena ar(c->arena.p);
-      du = ar.take<double>(n);
-      dw = ar.take<double>(n);
-    }
     const float* acc = static_cast<const float*>(c->acc.p);
     hipLaunchKernelGGL(finish_wake_advect_sym, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad,
                        foil_part, nt, nfoil ? pf.nt_pad : 0, dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, du, dw);
     HIPCHK(c, hipGetLastError());
-    if (u_out) {
-      HIPCHK(c, hipMemcpyAsync(u_out, du, n * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(w_out, dw, n * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
     return LUDVM_OK;
   }
   PairArgs a{};
@@ -937,13 +914,6 @@ int ludvm_wake_advect(ludvm_ctx* c, double dt, const double* foil_x, const doubl
   }
   Plan p = make_plan(c, nt, ns, precision);
   CHK(launch_pair(c, a, p, precision, nullptr, nullptr));  // results stay in the slab
-  double *du = nullptr, *dw = nullptr;
-  if (u_out) {
-    CHK(ensure(c, c->arena, 2 * Arena::need(n, 8)));
-    Arena ar(c->arena.p);
-    du = ar.take<double>(n);
-    dw = ar.take<double>(n);
-  }
   if (precision == LUDVM_PREC_F64)
     hipLaunchKernelGGL(finish_wake_advect<double>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
                        static_cast<const double*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->xh, c->xl,
@@ -953,10 +923,118 @@ int ludvm_wake_advect(ludvm_ctx* c, double dt, const double* foil_x, const doubl
                        static_cast<const float*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->xh, c->xl,
                        c->zh, c->zl, du, dw);
   HIPCHK(c, hipGetLastError());
+  return LUDVM_OK;
+}
+
+int ludvm_wake_advect(ludvm_ctx* c, double dt, const double* foil_x, const double* foil_z, const double* foil_dgamma,
+                      size_t nfoil, double vcore, int precision, double* u_out, double* w_out) {
+  if (!c) return LUDVM_E_ARG;
+  if (!valid_precision(precision)) return fail(c, LUDVM_E_ARG, "unknown precision");
+  if (nfoil && (!foil_x || !foil_z || !foil_dgamma)) return fail(c, LUDVM_E_ARG, "null foil array");
+  if ((u_out == nullptr) != (w_out == nullptr)) return fail(c, LUDVM_E_ARG, "u_out and w_out go together");
+  const size_t n = c->wake_n;
+  if (n == 0) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  // bound vortices ride behind the wake in the same source arrays for this launch
+  CHK(wake_grow(c, n + nfoil));
+  if (nfoil) {
+    CHK(h2d(c, c->x64 + n, foil_x, nfoil * 8));
+    CHK(h2d(c, c->z64 + n, foil_z, nfoil * 8));
+    CHK(h2d(c, c->g64 + n, foil_dgamma, nfoil * 8));
+    CHK(wake_refresh(c, n, nfoil));
+  }
+  double *du = nullptr, *dw = nullptr;
+  if (u_out) {
+    CHK(ensure(c, c->arena, 2 * Arena::need(n, 8)));
+    Arena ar(c->arena.p);
+    du = ar.take<double>(n);
+    dw = ar.take<double>(n);
+  }
+  CHK(advect_launch(c, dt, nfoil, vcore, precision, du, dw));
   if (u_out) {
     HIPCHK(c, hipMemcpyAsync(u_out, du, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(w_out, dw, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return LUDVM_OK;
+}
+
+int ludvm_wake_step(ludvm_ctx* c, const double* new_x, const double* new_z, const double* new_gamma, size_t n_new, double dt,
+                    const double* foil_x, const double* foil_z, const double* foil_dgamma, size_t nfoil, double vcore,
+                    int precision, const double* te, const double* le, int lev_from_prev, size_t tail_count,
+                    const double* xt, const double* zt, size_t nt, double* tail_x, double* tail_z, double* unit_x,
+                    double* unit_z, double* u_wake, double* w_wake, double* u_unit, double* w_unit) {
+  if (!c) return LUDVM_E_ARG;
+  if (!valid_precision(precision)) return fail(c, LUDVM_E_ARG, "unknown precision");
+  if (n_new && (!new_x || !new_z || !new_gamma)) return fail(c, LUDVM_E_ARG, "null new-vortex array");
+  if (nfoil && (!foil_x || !foil_z || !foil_dgamma)) return fail(c, LUDVM_E_ARG, "null foil array");
+  const size_t n0 = c->wake_n, n = n0 + n_new;
+  if (tail_count < 1 || tail_count > 2 || tail_count > n) return fail(c, LUDVM_E_ARG, "tail_count must be 1 or 2");
+  if (!te || !le || !xt || !zt || !tail_x || !tail_z || !unit_x || !unit_z || !u_wake || !w_wake || !u_unit || !w_unit || nt == 0)
+    return fail(c, LUDVM_E_ARG, "null array");
+  const size_t n_stage = 3 * (n_new + nfoil);
+  const size_t in_doubles = n_stage + 2 * nt + 4;           // staged vortices | xt | zt | te, le
+  const size_t out_doubles = 2 * tail_count + 4 + 6 * nt;   // tail x|z, unit[4], wake u|w, unit u,w rows
+  if (out_doubles * 8 > kPinOutBytes || in_doubles * 8 > kPinBytes / 4) return fail(c, LUDVM_E_ARG, "step too large for the fused call");
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(wake_grow(c, n + nfoil));
+  CHK(ensure(c, c->arena, Arena::need(in_doubles, 8) + Arena::need(out_doubles, 8)));
+  Arena ar(c->arena.p);
+  double* din = ar.take<double>(in_doubles);
+  double* dout = ar.take<double>(out_doubles);
+  // ONE upload for the whole step
+  std::vector<double>& pk = c->pack;
+  pk.resize(in_doubles);
+  double* q = pk.data();
+  if (n_new) { std::memcpy(q, new_x, n_new * 8); std::memcpy(q + n_new, new_z, n_new * 8); std::memcpy(q + 2 * n_new, new_gamma, n_new * 8); }
+  q += 3 * n_new;
+  if (nfoil) { std::memcpy(q, foil_x, nfoil * 8); std::memcpy(q + nfoil, foil_z, nfoil * 8); std::memcpy(q + 2 * nfoil, foil_dgamma, nfoil * 8); }
+  q += 3 * nfoil;
+  std::memcpy(q, xt, nt * 8);
+  std::memcpy(q + nt, zt, nt * 8);
+  q[2 * nt] = te[0]; q[2 * nt + 1] = te[1]; q[2 * nt + 2] = le[0]; q[2 * nt + 3] = le[1];
+  CHK(h2d(c, din, pk.data(), in_doubles * 8));
+  if (n_new + nfoil) {
+    hipLaunchKernelGGL(stage_step_inputs, dim3(blocks_for((long long)(n_new + nfoil))), dim3(kBlock), 0, c->stream, din,
+                       (long long)n0, (int)n_new, (int)nfoil, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32);
+    HIPCHK(c, hipGetLastError());
+  }
+  c->wake_n = n;
+  CHK(advect_launch(c, dt, nfoil, vcore, precision, nullptr, nullptr));
+  const double* d_xt = din + n_stage;
+  const double* d_zt = d_xt + nt;
+  const double* d_geo = d_zt + nt;
+  double* d_unit = dout + 2 * tail_count;      // [tev_x, lev_x, tev_z, lev_z]
+  double* d_sums = d_unit + 4;                 // u_wake | w_wake | unit rows
+  hipLaunchKernelGGL(place_next_shed, dim3(1), dim3(64), 0, c->stream, c->x64, c->z64, (long long)n, (int)tail_count,
+                     lev_from_prev, d_geo, dout);
+  HIPCHK(c, hipGetLastError());
+  const double v2 = vcore * vcore;
+  PairArgs a{};
+  a.xs = c->x64; a.zs = c->z64; a.gs = c->g64; a.ns = (long long)n;
+  a.xt = d_xt; a.zt = d_zt; a.nt = (long long)nt;
+  a.vc4 = v2 * v2;
+  const bool was = c->timing;
+  c->timing = false;   // the chord sums are not the dominant kernel
+  int rc = induce_device(c, a, (long long)nt, (long long)n, LUDVM_PREC_F64, d_sums, d_sums + nt);
+  c->timing = was;
+  CHK(rc);
+  hipLaunchKernelGGL(unit_influence_f64, dim3(blocks_for((long long)(2 * nt))), dim3(kBlock), 0, c->stream, d_xt, d_zt,
+                     (long long)nt, d_unit, d_unit + 2, 2, v2 * v2, d_sums + 2 * nt);
+  HIPCHK(c, hipGetLastError());
+  void* hv = nullptr;
+  CHK(d2h_small_sync(c, dout, out_doubles * 8, &hv));
+  const double* h = static_cast<const double*>(hv);
+  std::memcpy(tail_x, h, tail_count * 8);
+  std::memcpy(tail_z, h + tail_count, tail_count * 8);
+  const double* hu = h + 2 * tail_count;
+  unit_x[0] = hu[0]; unit_x[1] = hu[1]; unit_z[0] = hu[2]; unit_z[1] = hu[3];
+  const double* hs = hu + 4;
+  std::memcpy(u_wake, hs, nt * 8);
+  std::memcpy(w_wake, hs + nt, nt * 8);
+  for (size_t k = 0; k < 2; ++k) {
+    std::memcpy(u_unit + k * nt, hs + 2 * nt + (2 * k) * nt, nt * 8);
+    std::memcpy(w_unit + k * nt, hs + 2 * nt + (2 * k + 1) * nt, nt * 8);
   }
   return LUDVM_OK;
 }

@@ -401,6 +401,47 @@ unit_influence_f64(const double* xt, const double* zt, long long nt, const doubl
   out[(k * 2 + 1) * nt + p] = -dx * s;
 }
 
+// One kernel stages everything a time step uploads: `n_new` shed vortices appended at wake index n0 and
+// `n_foil` bound vortices behind them (sources of the roll-up only), from one packed host->device copy
+// pack = [new_x | new_z | new_g | foil_x | foil_z | foil_g]; float64 masters and fp32 mirrors are written.
+__global__ void __launch_bounds__(kBlock)
+stage_step_inputs(const double* pack, long long n0, int n_new, int n_foil, double* x64, double* z64, double* g64, float* xh,
+                  float* xl, float* zh, float* zl, float* g32) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n_new + n_foil) return;
+  const double* base = k < n_new ? pack : pack + 3 * n_new;
+  const int cnt = k < n_new ? n_new : n_foil;
+  const int j = k < n_new ? k : k - n_new;
+  const double x = base[j], z = base[cnt + j], g = base[2 * cnt + j];
+  const long long i = n0 + k;
+  x64[i] = x; z64[i] = z; g64[i] = g;
+  split_hilo(x, xh[i], xl[i]);
+  split_hilo(z, zh[i], zl[i]);
+  g32[i] = (float)g;
+}
+
+// After the roll-up: report the newest `tail` wake vortices and place the next time step's TEV and
+// candidate LEV from them (LUDVM.py:680-681, :797-800): one third of the way from the shedding edge to
+// the newest TEV / LEV.  geo = [te_x, te_z, le_x, le_z]; the newest TEV is vortex n - tail, the newest
+// LEV vortex n - 1 (when tail == 2).  out = [tail_x(tail) | tail_z(tail) | tev_x, lev_x, tev_z, lev_z].
+__global__ void place_next_shed(const double* x64, const double* z64, long long n, int tail, int lev_from_prev,
+                                const double* geo, double* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int t = 0; t < tail; ++t) { out[t] = x64[n - tail + t]; out[tail + t] = z64[n - tail + t]; }
+  double* unit = out + 2 * tail;
+  const double tex = geo[0], tez = geo[1], lex = geo[2], lez = geo[3];
+  const long long it = n - tail;
+  unit[0] = tex + (x64[it] - tex) / 3;
+  unit[2] = tez + (z64[it] - tez) / 3;
+  if (lev_from_prev && tail == 2) {
+    unit[1] = lex + (x64[n - 1] - lex) / 3;
+    unit[3] = lez + (z64[n - 1] - lez) / 3;
+  } else {
+    unit[1] = lex;
+    unit[3] = lez;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Vorticity stencil of LUDVM.flowfield (LUDVM.py:1224-1292): ome = dw/dx - du/dz on the uniform
 // grid, centred in the interior, one-sided on edges and corners.  u, w, ome are [nx][nz], z fastest.

@@ -216,6 +216,18 @@ class Engine:
         self._check(self._lib.ludvm_wake_advect_tail(self._ctx, dt, _pd(foil_x), _pd(foil_z), _pd(foil_dgamma),
                                                      len(foil_x), v_core, precision, tail_count, b.p_tx, b.p_tz))
 
+    def wake_step_into(self, b, new_x, new_z, new_gamma, dt, foil_x, foil_z, foil_dgamma, v_core, precision, te, le,
+                       lev_from_prev, tail_count, xp_next, zp_next):
+        """Append this step's shed vortices, roll the wake up, and return the placement and chord sums
+        of the next step -- one packed upload and one download (ludvm_wake_step).  Results:
+        b.tail[:, :tail_count], b.unit (placed TEV / LEV candidate), b.u, b.w, b.uu, b.wu for the next
+        step.  All array arguments contiguous float64."""
+        self._check(self._lib.ludvm_wake_step(self._ctx, _pd(new_x), _pd(new_z), _pd(new_gamma), len(new_x), dt,
+                                              _pd(foil_x), _pd(foil_z), _pd(foil_dgamma), len(foil_x), v_core, precision,
+                                              _pd(te), _pd(le), 1 if lev_from_prev else 0, tail_count, _pd(xp_next),
+                                              _pd(zp_next), b.n, b.p_tx, b.p_tz, b.p_unit_x, b.p_unit_z, b.p_u, b.p_w,
+                                              b.p_uu, b.p_wu))
+
     def wake_advect_tail(self, dt, foil_x, foil_z, foil_dgamma, v_core, tail_count, precision="f32"):
         """Roll-up step, then the updated (x, z) of the last `tail_count` wake vortices."""
         fx, fz, fg = _f64(foil_x), _f64(foil_z), _f64(foil_dgamma)

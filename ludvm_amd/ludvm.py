@@ -411,6 +411,7 @@ class LUDVM:
         sb = eng.step_buffers(npan) if hasattr(eng, 'step_buffers') else None
         prec_code = {'f32': 0, 'f32x2': 1, 'f64': 2}[self.precision]
         vc_f, dt_f = float(vc), float(dt)
+        have_next = False     # sb already holds step i's placement and chord sums (from the previous wake_step)
 
         for i in range(first_step, nt):
             if (i == 1 or i == nt - 1 or i / print_dt == int(i / print_dt)) and self.verbose == True:  # noqa: E712
@@ -420,16 +421,22 @@ class LUDVM:
 
             # new TEV: first one half a step behind the initial trailing edge, then 1/3 of the way
             # from the trailing edge to the previous TEV (:672-681)
-            tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
-
             # candidate LEV position: only geometry and the previous LEV enter (:788-800), so it is known
             # before the solve and its unit influence rides in the same device call as the TEV's
-            lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
+            n_wake = nf + itev + ilev
+            if have_next:
+                # placed on the device right after the previous roll-up, sums already here
+                tev_xy = np.array([sb.unit[0, 0], sb.unit[1, 0]])
+                lev_xy = np.array([sb.unit[0, 1], sb.unit[1, 1]])
+            else:
+                tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
+                lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
 
             # existing wake -> chord (T1), unit new TEV -> chord (T2), unit candidate LEV -> chord (T3):
             # one round trip (:743-754, :924-934)
-            n_wake = nf + itev + ilev
-            if sb is not None:
+            if have_next:
+                u1, w1, ut1, wt1, ul1, wl1 = sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1]
+            elif sb is not None:
                 sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1] = tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]
                 eng.wake_chord_sums_into(sb, n_wake, xg, zg, vc_f)
                 u1, w1, ut1, wt1, ul1, wl1 = sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1]
@@ -520,10 +527,13 @@ class LUDVM:
                 # the reference also convects LEV slot `ilev` (zero strength, at the origin) on a
                 # non-shedding step and stores it in path['LEV'][i]; reproduce that row entry
                 new_x.append(0.0); new_z.append(0.0); new_g.append(0.0)
-            eng.wake_append(new_x, new_z, new_g)
             n_after = n_wake + len(new_x)
+            one_trip = (not record) and sb is not None and i < nt - 1 and hasattr(eng, 'wake_step_into')
+            if not one_trip:
+                eng.wake_append(new_x, new_z, new_g)
 
             if record:
+                have_next = False
                 eng.wake_advect(dt, xg, zg, dGamma, vc, precision=self.precision)
                 xs, zs = eng.wake_read(0, n_after)
                 row_t = np.stack([xs[tev_slot[:itev + 1]], zs[tev_slot[:itev + 1]]])
@@ -546,7 +556,17 @@ class LUDVM:
             else:
                 # only the newest TEV / LEV come back: they place the next ones (:680-681, :797-798)
                 k = 2 if shed else 1
-                if sb is not None:
+                have_next = False
+                if one_trip:
+                    # append of the shed vortices + roll-up of this step + placement and chord sums of the
+                    # next one: one packed upload, one download
+                    eng.wake_step_into(sb, np.array(new_x), np.array(new_z), np.array(new_g, dtype=float), dt_f, xg, zg,
+                                       dGamma, vc_f, prec_code, np.ascontiguousarray(foil[i + 1, :, -1]),
+                                       np.ascontiguousarray(foil[i + 1, :, 0]), shed, k, gpts[i + 1, 0, :],
+                                       gpts[i + 1, 1, :])
+                    xs, zs = sb.tail[0], sb.tail[1]
+                    have_next = True
+                elif sb is not None:
                     eng.wake_advect_tail_into(sb, dt_f, xg, zg, dGamma, vc_f, k, prec_code)
                     xs, zs = sb.tail[0], sb.tail[1]
                 else:

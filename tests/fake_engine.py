@@ -70,6 +70,41 @@ class FakeEngine:
         self.wake_advect(dt, foil_x, foil_z, foil_dgamma, v_core, precision)
         return self.x[-tail_count:].copy(), self.z[-tail_count:].copy()
 
+    # preallocated-buffer variants used by the time loop's fast path
+    def step_buffers(self, npoints):
+        b = type("StepBuffers", (), {})()
+        b.n = npoints
+        b.unit = np.zeros([2, 2])
+        b.u, b.w = np.empty(npoints), np.empty(npoints)
+        b.uu, b.wu = np.empty([2, npoints]), np.empty([2, npoints])
+        b.tail = np.empty([2, 2])
+        return b
+
+    def wake_chord_sums_into(self, b, src_count, xp, zp, v_core):
+        b.u[:], b.w[:], uu, wu = self.wake_chord_sums(0, src_count, xp, zp, b.unit[0], b.unit[1], v_core)
+        b.uu[:], b.wu[:] = uu, wu
+
+    def wake_advect_tail_into(self, b, dt, foil_x, foil_z, foil_dgamma, v_core, tail_count, precision):
+        tx, tz = self.wake_advect_tail(dt, foil_x, foil_z, foil_dgamma, v_core, tail_count)
+        b.tail[0, :tail_count], b.tail[1, :tail_count] = tx, tz
+
+    def wake_step_into(self, b, new_x, new_z, new_gamma, dt, foil_x, foil_z, foil_dgamma, v_core, precision, te, le,
+                       lev_from_prev, tail_count, xp_next, zp_next):
+        self.calls["step"] = self.calls.get("step", 0) + 1
+        self.wake_append(new_x, new_z, new_gamma)
+        self.wake_advect(dt, foil_x, foil_z, foil_dgamma, v_core)
+        n = len(self.x)
+        b.tail[0, :tail_count], b.tail[1, :tail_count] = self.x[n - tail_count:], self.z[n - tail_count:]
+        it = n - tail_count
+        b.unit[0, 0] = te[0] + (self.x[it] - te[0]) / 3
+        b.unit[1, 0] = te[1] + (self.z[it] - te[1]) / 3
+        if lev_from_prev and tail_count == 2:
+            b.unit[0, 1] = le[0] + (self.x[n - 1] - le[0]) / 3
+            b.unit[1, 1] = le[1] + (self.z[n - 1] - le[1]) / 3
+        else:
+            b.unit[0, 1], b.unit[1, 1] = le[0], le[1]
+        self.wake_chord_sums_into(b, n, xp_next, zp_next, v_core)
+
     def wake_advect(self, dt, foil_x, foil_z, foil_dgamma, v_core, precision="f32", return_velocity=False):
         self.calls["advect"] += 1
         g = np.concatenate([self.g, np.asarray(foil_dgamma, float)])

@@ -79,6 +79,38 @@ def test_wake_chord_sums_and_tail(eng):
     np.testing.assert_allclose(tx, x[-2:] + 1e-3 * uf, rtol=0, atol=1e-12)
 
 
+def test_wake_step_equals_append_advect_and_chord_sums(eng):
+    """The one-round-trip step call against its separate counterparts (fp64 roll-up: deterministic)."""
+    rng = np.random.default_rng(17)
+    n = 3000
+    x, z, g = rng.uniform(-10, 0, n) - 30.0, rng.uniform(-2, 2, n), rng.standard_normal(n) / 30
+    nx, nz, ng = np.array([-29.99, -30.9]), np.array([0.01, 0.03]), np.array([0.4, -0.2])
+    fx, fz, fg = np.linspace(-31, -30, 80), 0.02 * np.cos(np.linspace(0, 2, 80)), rng.standard_normal(80) / 100
+    xt, zt = np.linspace(-31.05, -30.05, 80), 0.02 * np.cos(np.linspace(0, 2, 80)) + 0.01
+    te, le = np.array([-30.05, 0.0]), np.array([-31.05, 0.02])
+    vc, dt = 1.3e-3, 1e-3
+    # separate calls
+    eng.wake_clear(); eng.wake_append(x, z, g); eng.wake_append(nx, nz, ng)
+    tx, tz = eng.wake_advect_tail(dt, fx, fz, fg, vc, 2, precision="f64")
+    tev = te + (np.array([tx[0], tz[0]]) - te) / 3
+    lev = le + (np.array([tx[1], tz[1]]) - le) / 3
+    u, w, uu, wu = eng.wake_chord_sums(0, n + 2, xt, zt, [tev[0], lev[0]], [tev[1], lev[1]], vc)
+    xa, za = eng.wake_read(0, n + 2)
+    # one call
+    eng.wake_clear(); eng.wake_append(x, z, g)
+    b = eng.step_buffers(80)
+    eng.wake_step_into(b, nx, nz, ng, dt, fx, fz, fg, vc, 2, te, le, True, 2, xt, zt)
+    assert eng.wake_size() == n + 2
+    xb, zb = eng.wake_read(0, n + 2)
+    assert np.array_equal(xa, xb) and np.array_equal(za, zb)
+    assert np.array_equal(b.tail[0], tx) and np.array_equal(b.tail[1], tz)
+    assert np.array_equal(b.unit[0], [tev[0], lev[0]]) and np.array_equal(b.unit[1], [tev[1], lev[1]])
+    assert np.array_equal(b.u, u) and np.array_equal(b.w, w) and np.array_equal(b.uu, uu) and np.array_equal(b.wu, wu)
+    # candidate LEV on the leading edge when nothing was shed the step before
+    eng.wake_step_into(b, nx[:1], nz[:1], ng[:1], dt, fx, fz, fg, vc, 2, te, le, False, 1, xt, zt)
+    assert b.unit[0, 1] == le[0] and b.unit[1, 1] == le[1] and eng.wake_size() == n + 3
+
+
 @pytest.mark.parametrize("precision,tol", [("f32", 3e-5), ("f32x2", 3e-6), ("f64", 1e-12)])
 def test_wake_advect_is_one_reference_roll_up_step(eng, precision, tol):
     """wake + bound vortices -> every wake vortex, explicit Euler (LUDVM.py:1095-1127)."""

@@ -40,10 +40,27 @@ def test_config1_matches_reference(sim1, g2):
 
 
 def test_config1_uses_one_point_sum_per_step(sim1):
-    # 400 steps: one fused chord call (wake sum + unit TEV / candidate LEV) and one fused roll-up per step
+    # dense history records every row, so every step takes the two-call path: one fused chord call (wake sum +
+    # unit TEV / candidate LEV) and one fused roll-up
     eng = sim1.engine
     assert eng.calls["chord"] == 400 and eng.calls["advect"] == 400
     assert eng.calls["induce"] == 0 and eng.calls["points"] == 0
+
+
+def test_sparse_history_takes_the_one_round_trip_path(sim1):
+    sp = LUDVM(**CONFIG1, verbose=False, engine=FakeEngine(), history="sparse", snapshot_steps=[100, 250])
+    eng = sp.engine
+    # 400 steps, rows recorded at 100, 250 and 400: those three use the two-call path, and so does the step
+    # after each recorded one (its sums were not produced by a wake_step) -- step 1 likewise
+    assert eng.calls["step"] == 400 - 3 and eng.calls["advect"] == 400
+    # chord sums: 397 inside wake_step (counted there) + the separate calls of steps 1, 101, 251
+    assert eng.calls["chord"] == 397 + 3
+    # same arithmetic; the dense path additionally carries the zero-strength phantom LEV slot, which regroups
+    # the oracle's pairwise sums: ulp-level differences, amplified by the chaotic wake to ~1e-6 by step 400
+    np.testing.assert_allclose(sp.Cl[:100], sim1.Cl[:100], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(sp.Cl, sim1.Cl, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(sp.path["TEV"][100], sim1.path["TEV"][100, :, :100], rtol=0, atol=1e-9)
+    assert np.array_equal(sp.LEV_shed, sim1.LEV_shed)
 
 
 def test_public_methods_match_reference_signatures(sim1, g1_cases):
