@@ -1006,21 +1006,23 @@ int ludvm_wake_step(ludvm_ctx* c, const double* new_x, const double* new_z, cons
   const double* d_geo = d_zt + nt;
   double* d_unit = dout + 2 * tail_count;      // [tev_x, lev_x, tev_z, lev_z]
   double* d_sums = d_unit + 4;                 // u_wake | w_wake | unit rows
-  hipLaunchKernelGGL(place_next_shed, dim3(1), dim3(64), 0, c->stream, c->x64, c->z64, (long long)n, (int)tail_count,
-                     lev_from_prev, d_geo, dout);
-  HIPCHK(c, hipGetLastError());
+  // fp64 wake -> chord partial sums stay in the slab; one small kernel then sums the splits, places the next
+  // TEV / candidate LEV from the advected positions and evaluates their unit influences
   const double v2 = vcore * vcore;
   PairArgs a{};
   a.xs = c->x64; a.zs = c->z64; a.gs = c->g64; a.ns = (long long)n;
   a.xt = d_xt; a.zt = d_zt; a.nt = (long long)nt;
   a.vc4 = v2 * v2;
+  Plan p = make_plan(c, (long long)nt, (long long)n, LUDVM_PREC_F64);
   const bool was = c->timing;
   c->timing = false;   // the chord sums are not the dominant kernel
-  int rc = induce_device(c, a, (long long)nt, (long long)n, LUDVM_PREC_F64, d_sums, d_sums + nt);
+  int rc = launch_pair(c, a, p, LUDVM_PREC_F64, nullptr, nullptr);   // results stay in c->part
   c->timing = was;
   CHK(rc);
-  hipLaunchKernelGGL(unit_influence_f64, dim3(blocks_for((long long)(2 * nt))), dim3(kBlock), 0, c->stream, d_xt, d_zt,
-                     (long long)nt, d_unit, d_unit + 2, 2, v2 * v2, d_sums + 2 * nt);
+  const double* slab = static_cast<const double*>(c->part.p);
+  hipLaunchKernelGGL(chord_finish_f64, dim3(blocks_for((long long)(2 * nt))), dim3(kBlock), 0, c->stream,
+                     p.nsplit > 1 ? slab : (const double*)nullptr, p.nt_pad, p.nsplit, slab, d_xt, d_zt, (long long)nt, c->x64,
+                     c->z64, (long long)n, (int)tail_count, lev_from_prev, d_geo, v2 * v2, dout, d_sums);
   HIPCHK(c, hipGetLastError());
   void* hv = nullptr;
   CHK(d2h_small_sync(c, dout, out_doubles * 8, &hv));

@@ -442,6 +442,57 @@ __global__ void place_next_shed(const double* x64, const double* z64, long long 
   }
 }
 
+// One launch for the three small jobs that follow a time step's roll-up (ludvm_wake_step):
+//   (a) sum the fp64 wake->chord partial slabs in split order        -> out_sums[0 .. 2 nt)
+//   (b) report the newest `tail` vortices and place the next TEV / candidate LEV (as place_next_shed)
+//                                                                     -> out_head = [tail x | tail z | unit[4]]
+//   (c) velocities induced at the chord points by those two unit vortices (as unit_influence_f64)
+//                                                                     -> out_sums[2 nt .. 6 nt)
+// Every thread recomputes the two placements it needs (a handful of flops) instead of waiting for another
+// kernel to publish them.  grid covers 2 * nt threads.
+__global__ void __launch_bounds__(kBlock)
+chord_finish_f64(const double* part, long long nt_pad, int nsplit, const double* direct_u, const double* xt, const double* zt,
+                 long long nt, const double* x64, const double* z64, long long n, int tail, int lev_from_prev,
+                 const double* geo, double vc4, double* out_head, double* out_sums) {
+  const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const double tex = geo[0], tez = geo[1], lex = geo[2], lez = geo[3];
+  const long long it = n - tail;
+  double ux[2], uz[2];
+  ux[0] = tex + (x64[it] - tex) / 3;
+  uz[0] = tez + (z64[it] - tez) / 3;
+  if (lev_from_prev && tail == 2) {
+    ux[1] = lex + (x64[n - 1] - lex) / 3;
+    uz[1] = lez + (z64[n - 1] - lez) / 3;
+  } else {
+    ux[1] = lex;
+    uz[1] = lez;
+  }
+  if (idx == 0) {
+    for (int t = 0; t < tail; ++t) { out_head[t] = x64[n - tail + t]; out_head[tail + t] = z64[n - tail + t]; }
+    double* unit = out_head + 2 * tail;
+    unit[0] = ux[0]; unit[1] = ux[1]; unit[2] = uz[0]; unit[3] = uz[1];
+  }
+  if (idx >= 2 * nt) return;
+  const long long k = idx / nt, p = idx - k * nt;
+  // (c) unit vortex k at chord point p
+  const double dx = xt[p] - ux[k];
+  const double dz = zt[p] - uz[k];
+  const double r2 = __builtin_fma(dz, dz, dx * dx);
+  const double s = kInv2PiD / __builtin_sqrt(__builtin_fma(r2, r2, vc4));
+  out_sums[2 * nt + (k * 2 + 0) * nt + p] = dz * s;
+  out_sums[2 * nt + (k * 2 + 1) * nt + p] = -dx * s;
+  // (a) component k (0: u, 1: w) of the wake sum at chord point p
+  if (nsplit == 0) {                 // empty wake
+    out_sums[k * nt + p] = 0.0;
+  } else if (part == nullptr) {      // one split: the pair kernel wrote u | w directly
+    out_sums[k * nt + p] = direct_u[k * nt_pad + p];
+  } else {
+    double acc = 0.0;
+    for (int sidx = 0; sidx < nsplit; ++sidx) acc += part[(long long)sidx * 2 * nt_pad + k * nt_pad + p];
+    out_sums[k * nt + p] = acc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Vorticity stencil of LUDVM.flowfield (LUDVM.py:1224-1292): ome = dw/dx - du/dz on the uniform
 // grid, centred in the interior, one-sided on edges and corners.  u, w, ome are [nx][nz], z fastest.
