@@ -160,13 +160,15 @@ struct Plan {
 
 constexpr int kTileF32 = 1024;
 constexpr int kTileF64 = 512;
+constexpr int kTileF64Few = 128;         // fp64 launches with few targets (chord points): short tiles, more workgroups
+constexpr long long kFewTargets = 256;
 constexpr long long kTargetBlocks = 16384;  // total workgroups aimed for (2048 resident at 8/CU)
 constexpr int kMaxSplit = 2048;
 
 Plan make_plan(const ludvm_ctx* c, long long nt, long long ns, int precision) {
   Plan p{};
   const bool f64 = precision == LUDVM_PREC_F64;
-  p.tile = f64 ? kTileF64 : kTileF32;
+  p.tile = f64 ? (nt <= kFewTargets ? kTileF64Few : kTileF64) : kTileF32;
   if (f64) {
     p.tpl = 1;
   } else if (c->tune_tpl == 1 || c->tune_tpl == 2 || c->tune_tpl == 4) {
@@ -246,7 +248,10 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
   bool active = false;
   CHK(timed_begin(c, t, active));
   if (precision == LUDVM_PREC_F64) {
-    hipLaunchKernelGGL((pair_f64<kTileF64>), grid, dim3(kBlock), 0, c->stream, a);
+    if (p.tile == kTileF64Few)
+      hipLaunchKernelGGL((pair_f64<kTileF64Few>), grid, dim3(kBlock), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((pair_f64<kTileF64>), grid, dim3(kBlock), 0, c->stream, a);
   } else if (precision == LUDVM_PREC_F32X2) {
     switch (p.tpl) {
       case 1: hipLaunchKernelGGL((pair_f32<1, kTileF32, true>), grid, dim3(kBlock), 0, c->stream, a); break;

@@ -223,8 +223,25 @@ pair_f32(PairArgs a) {
   }
 }
 
+// 1/sqrt(q) in fp64: v_rsq_f64 (~2^-26 relative) refined by two Newton steps y <- y (1.5 - 0.5 q y^2),
+// each squaring the error (-> below 1 ulp); ~10 fp64 ops instead of the ~60 of a divide plus a sqrt.
+// q = 0 (inviscid self pair) gives +inf like the exact form, so G * rsq still reproduces the
+// reference's NaN / inf semantics at coincident points; q = +inf gives 0.
+__device__ __forceinline__ double rsqrt_f64(double q) {
+  double y = __builtin_amdgcn_rsq(q);
+  const double h = 0.5 * q;
+  // the Newton update is only meaningful for finite, non-zero q (inf * 0 would turn the limits into NaN)
+  if (q > 0.0 && q < 1.0e300) {
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    y = y * __builtin_fma(-h * y, y, 1.5);
+  }
+  return y;
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp64 throughout (parity / debug mode and the small chord-target calls).  One target per lane.
+// TILE = 512 for many targets (throughput); TILE = 128 for a few (the 80 chord points of a time step:
+// the launch is latency-bound, so each workgroup walks a short tile and there are 4x as many of them).
 // ---------------------------------------------------------------------------------------------
 template <int TILE>
 __global__ void __launch_bounds__(kBlock)
@@ -258,13 +275,15 @@ pair_f64(PairArgs a) {
   for (long long base = s_begin; base < s_end; base += TILE) {
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < TILE / kBlock; ++k) {
+    for (int k = 0; k < (TILE + kBlock - 1) / kBlock; ++k) {
       const int l = tid + k * kBlock;
-      const long long si = base + l;
-      const bool ok = si < s_end;
-      lx[l] = ok ? xs[si] : kPadPosD;
-      lz[l] = ok ? zs[si] : kPadPosD;
-      lg[l] = ok ? gs[si] : 0.0;
+      if (l < TILE) {
+        const long long si = base + l;
+        const bool ok = si < s_end;
+        lx[l] = ok ? xs[si] : kPadPosD;
+        lz[l] = ok ? zs[si] : kPadPosD;
+        lg[l] = ok ? gs[si] : 0.0;
+      }
     }
     __syncthreads();
 #pragma unroll 4
@@ -273,7 +292,7 @@ pair_f64(PairArgs a) {
       const double dz = zp - lz[j];
       const double r2 = __builtin_fma(dz, dz, dx * dx);
       const double q = __builtin_fma(r2, r2, vc4);
-      const double s = lg[j] / __builtin_sqrt(q);
+      const double s = lg[j] * rsqrt_f64(q);
       au = __builtin_fma(dz, s, au);
       aw = __builtin_fma(dx, s, aw);
     }
@@ -296,14 +315,26 @@ pair_f64(PairArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Finishers: sum the per-split partial slabs in split order (deterministic), then the epilogue.
 // ---------------------------------------------------------------------------------------------
+// Four independent running sums (splits s, s+1, s+2, s+3 mod 4), combined at the end in a fixed order:
+// deterministic, and the loads of a group of four are in flight together instead of one after another.
+template <typename T>
+__device__ __forceinline__ T sum_column(const T* col, long long stride, int nsplit) {
+  T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    a0 += col[(long long)s * stride];
+    a1 += col[(long long)(s + 1) * stride];
+    a2 += col[(long long)(s + 2) * stride];
+    a3 += col[(long long)(s + 3) * stride];
+  }
+  for (; s < nsplit; ++s) a0 += col[(long long)s * stride];
+  return (a0 + a1) + (a2 + a3);
+}
+
 template <typename T>
 __device__ __forceinline__ void sum_splits(const T* part, long long i, long long nt_pad, int nsplit, T& su, T& sw) {
-  su = 0;
-  sw = 0;
-  for (int s = 0; s < nsplit; ++s) {
-    su += part[(long long)s * 2 * nt_pad + i];
-    sw += part[(long long)s * 2 * nt_pad + nt_pad + i];
-  }
+  su = sum_column(part + i, 2 * nt_pad, nsplit);
+  sw = sum_column(part + nt_pad + i, 2 * nt_pad, nsplit);
 }
 
 template <typename T>
@@ -396,7 +427,7 @@ unit_influence_f64(const double* xt, const double* zt, long long nt, const doubl
   const double dx = xt[p] - ux[k];
   const double dz = zt[p] - uz[k];
   const double r2 = __builtin_fma(dz, dz, dx * dx);
-  const double s = kInv2PiD / __builtin_sqrt(__builtin_fma(r2, r2, vc4));
+  const double s = kInv2PiD * rsqrt_f64(__builtin_fma(r2, r2, vc4));
   out[(k * 2 + 0) * nt + p] = dz * s;
   out[(k * 2 + 1) * nt + p] = -dx * s;
 }
@@ -478,7 +509,7 @@ chord_finish_f64(const double* part, long long nt_pad, int nsplit, const double*
   const double dx = xt[p] - ux[k];
   const double dz = zt[p] - uz[k];
   const double r2 = __builtin_fma(dz, dz, dx * dx);
-  const double s = kInv2PiD / __builtin_sqrt(__builtin_fma(r2, r2, vc4));
+  const double s = kInv2PiD * rsqrt_f64(__builtin_fma(r2, r2, vc4));
   out_sums[2 * nt + (k * 2 + 0) * nt + p] = dz * s;
   out_sums[2 * nt + (k * 2 + 1) * nt + p] = -dx * s;
   // (a) component k (0: u, 1: w) of the wake sum at chord point p
@@ -487,9 +518,7 @@ chord_finish_f64(const double* part, long long nt_pad, int nsplit, const double*
   } else if (part == nullptr) {      // one split: the pair kernel wrote u | w directly
     out_sums[k * nt + p] = direct_u[k * nt_pad + p];
   } else {
-    double acc = 0.0;
-    for (int sidx = 0; sidx < nsplit; ++sidx) acc += part[(long long)sidx * 2 * nt_pad + k * nt_pad + p];
-    out_sums[k * nt + p] = acc;
+    out_sums[k * nt + p] = sum_column(part + k * nt_pad + p, 2 * nt_pad, nsplit);
   }
 }
 
