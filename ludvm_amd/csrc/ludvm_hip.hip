@@ -884,26 +884,14 @@ static int advect_launch(ludvm_ctx* c, double dt, size_t nfoil, double vcore, in
     const bool hilo = precision == LUDVM_PREC_F32X2;
     long long nt_pad = 0;
     CHK(launch_sym(c, c->xh, c->zh, c->g32, nt, v2 * v2, &nt_pad, hilo ? c->xl : nullptr, hilo ? c->zl : nullptr));
-    const float* foil_part = nullptr;
-    Plan pf{};
-    if (nfoil) {
-      PairArgs af{};
-      af.xs = c->xh + n; af.zs = c->zh + n; af.gs = c->g32 + n; af.ns = (long long)nfoil;
-      af.xt = c->xh; af.zt = c->zh; af.nt = nt;
-      if (hilo) { af.xsl = c->xl + n; af.zsl = c->zl + n; af.xtl = c->xl; af.ztl = c->zl; }
-      af.vc4 = v2 * v2;
-      pf = make_plan(c, nt, (long long)nfoil, precision);   // nfoil <= one LDS tile: a single split
-      if (pf.nsplit != 1) return fail(c, LUDVM_E_ARG, "too many bound vortices for the fused roll-up");
-      const bool was = c->timing;
-      c->timing = false;   // the O(N * Npanels) launch is not the dominant kernel
-      int rc = launch_pair(c, af, pf, precision, nullptr, nullptr);
-      c->timing = was;
-      CHK(rc);
-      foil_part = static_cast<const float*>(c->part.p);
-    }
+    if (nfoil > (size_t)kBlock) return fail(c, LUDVM_E_ARG, "too many bound vortices for the fused roll-up");
     const float* acc = static_cast<const float*>(c->acc.p);
-    hipLaunchKernelGGL(finish_wake_advect_sym, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad,
-                       foil_part, nt, nfoil ? pf.nt_pad : 0, dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, du, dw);
+    if (hilo)
+      hipLaunchKernelGGL(finish_wake_advect_sym<true>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, nt,
+                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw);
+    else
+      hipLaunchKernelGGL(finish_wake_advect_sym<false>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, nt,
+                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw);
     HIPCHK(c, hipGetLastError());
     return LUDVM_OK;
   }
@@ -1025,7 +1013,7 @@ int ludvm_wake_step(ludvm_ctx* c, const double* new_x, const double* new_z, cons
   c->timing = was;
   CHK(rc);
   const double* slab = static_cast<const double*>(c->part.p);
-  hipLaunchKernelGGL(chord_finish_f64, dim3(blocks_for((long long)(2 * nt))), dim3(kBlock), 0, c->stream,
+  hipLaunchKernelGGL(chord_finish_f64, dim3(blocks_for((long long)(2 * nt * 64))), dim3(kBlock), 0, c->stream,
                      p.nsplit > 1 ? slab : (const double*)nullptr, p.nt_pad, p.nsplit, slab, d_xt, d_zt, (long long)nt, c->x64,
                      c->z64, (long long)n, (int)tail_count, lev_from_prev, d_geo, v2 * v2, dout, d_sums);
   HIPCHK(c, hipGetLastError());

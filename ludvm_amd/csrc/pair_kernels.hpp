@@ -474,18 +474,23 @@ __global__ void place_next_shed(const double* x64, const double* z64, long long 
 }
 
 // One launch for the three small jobs that follow a time step's roll-up (ludvm_wake_step):
-//   (a) sum the fp64 wake->chord partial slabs in split order        -> out_sums[0 .. 2 nt)
+//   (a) sum the fp64 wake->chord partial slabs                        -> out_sums[0 .. 2 nt)
 //   (b) report the newest `tail` vortices and place the next TEV / candidate LEV (as place_next_shed)
 //                                                                     -> out_head = [tail x | tail z | unit[4]]
 //   (c) velocities induced at the chord points by those two unit vortices (as unit_influence_f64)
 //                                                                     -> out_sums[2 nt .. 6 nt)
-// Every thread recomputes the two placements it needs (a handful of flops) instead of waiting for another
-// kernel to publish them.  grid covers 2 * nt threads.
+// One WAVEFRONT per output column (k, p), k = 0: u / unit TEV, k = 1: w / unit LEV: lane l sums the
+// splits s = l, l + 64, ... and the 64 partials are combined by a fixed shuffle tree (deterministic;
+// a column of ~500 splits costs ~8 loads per lane instead of 500 dependent ones).  Lane 0 of the column
+// also evaluates (c); the placements are recomputed by whoever needs them (a handful of flops).
+// grid covers 2 * nt * 64 threads.
 __global__ void __launch_bounds__(kBlock)
 chord_finish_f64(const double* part, long long nt_pad, int nsplit, const double* direct_u, const double* xt, const double* zt,
                  long long nt, const double* x64, const double* z64, long long n, int tail, int lev_from_prev,
                  const double* geo, double vc4, double* out_head, double* out_sums) {
-  const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const long long gtid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const long long col = gtid >> 6;
+  const int lane = threadIdx.x & 63;
   const double tex = geo[0], tez = geo[1], lex = geo[2], lez = geo[3];
   const long long it = n - tail;
   double ux[2], uz[2];
@@ -498,13 +503,25 @@ chord_finish_f64(const double* part, long long nt_pad, int nsplit, const double*
     ux[1] = lex;
     uz[1] = lez;
   }
-  if (idx == 0) {
+  if (gtid == 0) {
     for (int t = 0; t < tail; ++t) { out_head[t] = x64[n - tail + t]; out_head[tail + t] = z64[n - tail + t]; }
     double* unit = out_head + 2 * tail;
     unit[0] = ux[0]; unit[1] = ux[1]; unit[2] = uz[0]; unit[3] = uz[1];
   }
-  if (idx >= 2 * nt) return;
-  const long long k = idx / nt, p = idx - k * nt;
+  if (col >= 2 * nt) return;   // whole wavefronts leave together
+  const long long k = col / nt, p = col - k * nt;
+  // (a) component k (0: u, 1: w) of the wake sum at chord point p
+  double acc = 0.0;
+  if (part != nullptr) {
+    const double* c0 = part + k * nt_pad + p;
+    for (int sidx = lane; sidx < nsplit; sidx += 64) acc += c0[(long long)sidx * 2 * nt_pad];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  } else if (nsplit == 1) {          // one split: the pair kernel wrote u | w directly
+    acc = direct_u[k * nt_pad + p];
+  }
+  if (lane != 0) return;
+  out_sums[k * nt + p] = acc;
   // (c) unit vortex k at chord point p
   const double dx = xt[p] - ux[k];
   const double dz = zt[p] - uz[k];
@@ -512,14 +529,6 @@ chord_finish_f64(const double* part, long long nt_pad, int nsplit, const double*
   const double s = kInv2PiD * rsqrt_f64(__builtin_fma(r2, r2, vc4));
   out_sums[2 * nt + (k * 2 + 0) * nt + p] = dz * s;
   out_sums[2 * nt + (k * 2 + 1) * nt + p] = -dx * s;
-  // (a) component k (0: u, 1: w) of the wake sum at chord point p
-  if (nsplit == 0) {                 // empty wake
-    out_sums[k * nt + p] = 0.0;
-  } else if (part == nullptr) {      // one split: the pair kernel wrote u | w directly
-    out_sums[k * nt + p] = direct_u[k * nt_pad + p];
-  } else {
-    out_sums[k * nt + p] = sum_column(part + k * nt_pad + p, 2 * nt_pad, nsplit);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------

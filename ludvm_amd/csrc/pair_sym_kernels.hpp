@@ -266,21 +266,42 @@ finish_sym_advect(const float* sum_u, const float* sum_w, const float* x, const 
   z_out[i] = __builtin_fmaf(dt, -sum_w[i] * s, z[t_first + i]);
 }
 
-// Resident-wake Euler step from the symmetric kernel's raw sums plus the (already scaled) velocities
-// induced by the bound vortices (direct kernel, `foil` = [2][nt_pad] slab or nullptr): float64 update
-// of the master copy, refresh of the fp32 mirrors (LUDVM.py:1108-1127).
+// Resident-wake Euler step from the symmetric kernel's raw sums, plus the velocity induced by the nfoil
+// bound vortices staged behind the wake at index n (LUDVM.py:1106, :1115, :1124: <= 256 sources, so the
+// sum is done right here, one target per thread, instead of in a launch of its own): float64 update of
+// the master copy, refresh of the fp32 mirrors (LUDVM.py:1108-1127).  HILO as in the pair kernels.
+template <bool HILO>
 __global__ void __launch_bounds__(kBlock)
-finish_wake_advect_sym(const float* acc_u, const float* acc_w, const float* foil, long long nt, long long nt_pad, double dt,
-                       double* x64, double* z64, float* xh, float* xl, float* zh, float* zl, double* u_out,
+finish_wake_advect_sym(const float* acc_u, const float* acc_w, long long nt, int nfoil, float vc4, double dt, double* x64,
+                       double* z64, float* xh, float* xl, float* zh, float* zl, const float* g32, double* u_out,
                        double* w_out) {
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  __shared__ float fx[kBlock], fz[kBlock], fg[kBlock], fxl[HILO ? kBlock : 1], fzl[HILO ? kBlock : 1];
+  const int tid = threadIdx.x;
+  if (tid < nfoil) {
+    fx[tid] = xh[nt + tid]; fz[tid] = zh[nt + tid]; fg[tid] = g32[nt + tid];
+    if (HILO) { fxl[tid] = xl[nt + tid]; fzl[tid] = zl[nt + tid]; }
+  }
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * kBlock + tid;
   if (i >= nt) return;
   const float s = (float)kInv2PiD;
-  float su = acc_u[i] * s, sw = -acc_w[i] * s;
-  if (foil) { su += foil[i]; sw += foil[nt_pad + i]; }
+  float fu = 0.0f, fw = 0.0f;
+  const float xi = xh[i], zi = zh[i];
+  const float xil = HILO ? xl[i] : 0.0f, zil = HILO ? zl[i] : 0.0f;
+  for (int j = 0; j < nfoil; ++j) {
+    float dx = xi - fx[j], dz = zi - fz[j];
+    if (HILO) { dx += xil - fxl[j]; dz += zil - fzl[j]; }
+    const float r2 = __builtin_fmaf(dz, dz, dx * dx);
+    const float k = fg[j] * __builtin_amdgcn_rsqf(__builtin_fmaf(r2, r2, vc4));
+    fu = __builtin_fmaf(dz, k, fu);
+    fw = __builtin_fmaf(dx, k, fw);
+  }
+  const float su = (acc_u[i] + fu) * s, sw = -(acc_w[i] + fw) * s;
   if (u_out) { u_out[i] = (double)su; w_out[i] = (double)sw; }
   const double xn = x64[i] + dt * (double)su;
   const double zn = z64[i] + dt * (double)sw;
+  // all reads of the old mirrors by this block happened above (own entry only); other blocks read the foil
+  // entries [nt, nt + nfoil), which are not written here
   x64[i] = xn;
   z64[i] = zn;
   split_hilo(xn, xh[i], xl[i]);
