@@ -305,6 +305,7 @@ constexpr long long kSymMinN = 16384;   // below this the direct kernel's launch
 constexpr int kSymT = 4;                // vortices per lane of the symmetric kernel (tile = 256)
 static_assert(64 * kSymT == LUDVM_SYM_TILE, "header and kernel disagree on the symmetric tile");
 constexpr long long kSymTargetWaves = 65536;
+constexpr long long kSymMaxSplit = 64;
 
 bool use_symmetric(const ludvm_ctx* c, long long n) {
   if (c->sym_mode == 0) return false;
@@ -326,7 +327,7 @@ int launch_sym_tiles(ludvm_ctx* c, const float* x, const float* z, const float* 
   a.i_count = i_count;
   const long long dtot = a.dmax + ((a.ntiles % 2 == 0 && a.ntiles > 1) ? 1 : 0);
   long long ys = c->tune_split > 0 ? c->tune_split : (kSymTargetWaves + i_count - 1) / i_count;
-  ys = std::max<long long>(1, std::min<long long>(std::min<long long>(ys, 64), std::max<long long>(dtot, 1)));
+  ys = std::max<long long>(1, std::min<long long>(std::min<long long>(ys, kSymMaxSplit), std::max<long long>(dtot, 1)));
   a.ysplit = (int)ys;
   a.acc_u = acc_u;
   a.acc_w = acc_w;
