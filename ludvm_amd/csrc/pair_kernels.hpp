@@ -451,32 +451,13 @@ stage_step_inputs(const double* pack, long long n0, int n_new, int n_foil, doubl
   g32[i] = (float)g;
 }
 
-// After the roll-up: report the newest `tail` wake vortices and place the next time step's TEV and
-// candidate LEV from them (LUDVM.py:680-681, :797-800): one third of the way from the shedding edge to
-// the newest TEV / LEV.  geo = [te_x, te_z, le_x, le_z]; the newest TEV is vortex n - tail, the newest
-// LEV vortex n - 1 (when tail == 2).  out = [tail_x(tail) | tail_z(tail) | tev_x, lev_x, tev_z, lev_z].
-__global__ void place_next_shed(const double* x64, const double* z64, long long n, int tail, int lev_from_prev,
-                                const double* geo, double* out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  for (int t = 0; t < tail; ++t) { out[t] = x64[n - tail + t]; out[tail + t] = z64[n - tail + t]; }
-  double* unit = out + 2 * tail;
-  const double tex = geo[0], tez = geo[1], lex = geo[2], lez = geo[3];
-  const long long it = n - tail;
-  unit[0] = tex + (x64[it] - tex) / 3;
-  unit[2] = tez + (z64[it] - tez) / 3;
-  if (lev_from_prev && tail == 2) {
-    unit[1] = lex + (x64[n - 1] - lex) / 3;
-    unit[3] = lez + (z64[n - 1] - lez) / 3;
-  } else {
-    unit[1] = lex;
-    unit[3] = lez;
-  }
-}
-
 // One launch for the three small jobs that follow a time step's roll-up (ludvm_wake_step):
 //   (a) sum the fp64 wake->chord partial slabs                        -> out_sums[0 .. 2 nt)
-//   (b) report the newest `tail` vortices and place the next TEV / candidate LEV (as place_next_shed)
-//                                                                     -> out_head = [tail x | tail z | unit[4]]
+//   (b) report the newest `tail` wake vortices and place the next time step's TEV and candidate LEV from
+//       them (LUDVM.py:680-681, :797-800): one third of the way from the shedding edge to the newest TEV /
+//       LEV.  geo = [te_x, te_z, le_x, le_z]; the newest TEV is vortex n - tail, the newest LEV vortex
+//       n - 1 (when tail == 2 and lev_from_prev), else the candidate sits on the leading edge
+//                                                       -> out_head = [tail x | tail z | tev_x, lev_x, tev_z, lev_z]
 //   (c) velocities induced at the chord points by those two unit vortices (as unit_influence_f64)
 //                                                                     -> out_sums[2 nt .. 6 nt)
 // One WAVEFRONT per output column (k, p), k = 0: u / unit TEV, k = 1: w / unit LEV: lane l sums the
