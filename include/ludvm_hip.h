@@ -112,7 +112,7 @@ int ludvm_advect_dev_f32(ludvm_ctx* ctx, const float* d_xs, const float* d_zs, c
  * u = acc_u / (2 pi), w = -acc_w / (2 pi).  ludvm_advect_from_sums_dev_f32 turns the summed values of
  * targets [t_first, t_first + nt) (d_sum_*[i] belongs to target t_first + i) into the Euler step
  * x_out[i] = x[t_first + i] + dt * u, z_out likewise (LUDVM.py:1108-1109). */
-#define LUDVM_SYM_TILE 256
+#define LUDVM_SYM_TILE 512
 int ludvm_sym_accumulate_dev_f32(ludvm_ctx* ctx, const float* d_x, const float* d_z, const float* d_g, size_t n,
                                  size_t tile_first, size_t tile_count, float vcore, float* d_acc_u,
                                  float* d_acc_w);

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libludvm_hip.so")
 
 OK, E_ARG, E_HIP, E_NOMEM, E_NODEVICE, E_STATE = range(6)
 PREC_F32, PREC_F32X2, PREC_F64 = 0, 1, 2
-SYM_TILE = 256
+SYM_TILE = 512
 ABI_VERSION = 1
 
 _pd, _pf = POINTER(c_double), POINTER(c_float)

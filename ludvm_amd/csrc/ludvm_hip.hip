@@ -302,8 +302,11 @@ int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, i
 }
 
 constexpr long long kSymMinN = 16384;   // below this the direct kernel's launch is as fast
-constexpr int kSymT = 4;                // vortices per lane of the symmetric kernel (tile = 256)
-static_assert(64 * kSymT == LUDVM_SYM_TILE, "header and kernel disagree on the symmetric tile");
+// Vortices per lane of the symmetric kernel: 8 (tile 512, 2 waves/SIMD) from ~1e5 vortices up, where halving
+// the rotation / LDS-read cost per pair wins 5-7 %; 4 (tile 256, 5 waves/SIMD) below, where more and smaller
+// tiles balance better, and for hi+lo positions (8 would not fit the register file).
+constexpr long long kSymT8MinN = 98304;
+static_assert(64 * 8 == LUDVM_SYM_TILE, "the multi-GPU entry points always use the 512-vortex tile");
 constexpr long long kSymTargetWaves = 65536;
 constexpr long long kSymMaxSplit = 64;
 
@@ -314,13 +317,15 @@ bool use_symmetric(const ludvm_ctx* c, long long n) {
 
 // Symmetric kernel over I tiles [i_first, i_first + i_count) of the tile ring of (x, z, g)[0, n); raw sums
 // are ADDED into acc_u / acc_w (n floats each, zeroed by the caller).
-int launch_sym_tiles(ludvm_ctx* c, const float* x, const float* z, const float* g, long long n, long long i_first,
+int launch_sym_tiles(ludvm_ctx* c, int T, const float* x, const float* z, const float* g, long long n, long long i_first,
                      long long i_count, double vc4, float* acc_u, float* acc_w, const float* xl = nullptr,
                      const float* zl = nullptr) {
   SymArgs a{};
   a.x = x; a.z = z; a.g = g; a.n = n;
   a.xl = xl; a.zl = zl;
-  const long long W = 64LL * kSymT;
+  const bool hilo = xl && zl;
+  if (hilo) T = 4;
+  const long long W = 64LL * T;
   a.ntiles = (n + W - 1) / W;
   a.dmax = (a.ntiles - 1) / 2;
   a.i_first = i_first;
@@ -336,10 +341,13 @@ int launch_sym_tiles(ludvm_ctx* c, const float* x, const float* z, const float* 
   TimedLaunch t{};
   bool active = false;
   CHK(timed_begin(c, t, active));
-  if (xl && zl)
-    hipLaunchKernelGGL((pair_sym_f32<kSymT, true>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, c->stream, a);
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  if (hilo)
+    hipLaunchKernelGGL((pair_sym_f32<4, true>), grid, dim3(kBlock), 0, c->stream, a);
+  else if (T == 8)
+    hipLaunchKernelGGL((pair_sym_f32<8, false>), grid, dim3(kBlock), 0, c->stream, a);
   else
-    hipLaunchKernelGGL((pair_sym_f32<kSymT, false>), dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, c->stream, a);
+    hipLaunchKernelGGL((pair_sym_f32<4, false>), grid, dim3(kBlock), 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
   CHK(timed_end(c, t, active));
   return LUDVM_OK;
@@ -353,8 +361,9 @@ int launch_sym(ludvm_ctx* c, const float* x, const float* z, const float* g, lon
   CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(float)));
   HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(float), c->stream));
   float* acc = static_cast<float*>(c->acc.p);
-  const long long ntiles = (n + 64LL * kSymT - 1) / (64LL * kSymT);
-  CHK(launch_sym_tiles(c, x, z, g, n, 0, ntiles, vc4, acc, acc + nt_pad, xl, zl));
+  const int T = (n >= kSymT8MinN && !(xl && zl)) ? 8 : 4;
+  const long long ntiles = (n + 64LL * T - 1) / (64LL * T);
+  CHK(launch_sym_tiles(c, T, x, z, g, n, 0, ntiles, vc4, acc, acc + nt_pad, xl, zl));
   *nt_pad_out = nt_pad;
   return LUDVM_OK;
 }
@@ -678,8 +687,8 @@ int ludvm_sym_accumulate_dev_f32(ludvm_ctx* c, const float* d_x, const float* d_
   if (tile_count == 0) return LUDVM_OK;
   HIPCHK(c, hipSetDevice(c->device));
   const double v2 = (double)vcore * (double)vcore;
-  return launch_sym_tiles(c, d_x, d_z, d_g, (long long)n, (long long)tile_first, (long long)tile_count, v2 * v2, d_acc_u,
-                          d_acc_w);
+  return launch_sym_tiles(c, 8, d_x, d_z, d_g, (long long)n, (long long)tile_first, (long long)tile_count, v2 * v2,
+                          d_acc_u, d_acc_w);
 }
 
 int ludvm_advect_from_sums_dev_f32(ludvm_ctx* c, const float* d_sum_u, const float* d_sum_w, const float* d_x,

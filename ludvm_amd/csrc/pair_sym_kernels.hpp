@@ -47,16 +47,33 @@ __device__ __forceinline__ float dpp_rol1(float v) {
 }
 __device__ __forceinline__ f32x2 dpp_rol1(f32x2 v) { return (f32x2){dpp_rol1(v.x), dpp_rol1(v.y)}; }
 
-// T = 4: 256-vortex tiles.  Per rotation step a lane evaluates T*T = 16 unordered pairs with
-// 88 packed ops + 16 v_rsq_f32; the J tile's (x, z, Gamma) sit in a wave-private LDS slab and are
-// read with a per-lane rotating address (ds_read_b128, off the VALU pipe); only the J accumulators
-// travel between lanes (8 v_mov_b32_dpp, 4 issue cycles each on gfx950).
+// Slab helpers: a wave's LDS slab holds T floats per home lane and component.
+template <int T>
+__device__ __forceinline__ void slab_store(float* l, int lane, const float (&v)[T]) {
+#pragma unroll
+  for (int q = 0; q < T / 4; ++q)
+    *reinterpret_cast<f32x4*>(&l[lane * T + 4 * q]) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+template <int T>
+__device__ __forceinline__ void slab_load(const float* l, int pos, f32x2 (&out)[T / 2]) {
+#pragma unroll
+  for (int q = 0; q < T / 4; ++q) {
+    const f32x4 V = *reinterpret_cast<const f32x4*>(&l[pos + 4 * q]);
+    out[2 * q] = (f32x2){V.x, V.y};
+    out[2 * q + 1] = (f32x2){V.z, V.w};
+  }
+}
+
+// T vortices per lane on both sides (tile = 64*T).  Per rotation step a lane evaluates T*T unordered
+// pairs with 5.5*T*T packed ops + T*T v_rsq_f32; the J tile's (x, z, Gamma) sit in a wave-private LDS slab
+// and are read with a per-lane rotating address (T/4 ds_read_b128 per component, off the VALU pipe); only
+// the 2*T J-accumulator registers travel between lanes (v_mov_b32_dpp, 4 issue cycles each on gfx950).
 // HILO: positions are hi+lo fp32 pairs, dx = (xh_i - xh_j) + (xl_i - xl_j), +4 packed ops
 // per two unordered pairs; everything after the difference is plain fp32.
 template <int T, bool HILO = false>
 __global__ void __launch_bounds__(kBlock)
 pair_sym_f32(SymArgs a) {
-  static_assert(T == 4, "the LDS slab is laid out for 4 vortices (one ds_read_b128) per lane");
+  static_assert(T == 4 || T == 8, "T vortices per lane, read as T/4 ds_read_b128 per component");
   constexpr int H = T / 2;
   constexpr int kWaves = kBlock / 64;
   constexpr int kComp = HILO ? 5 : 3;
@@ -84,66 +101,43 @@ pair_sym_f32(SymArgs a) {
 
   // my targets (duplicated into register pairs: the packed ops pair two SOURCES against one target)
   f32x2 xp[T], zp[T], gp[T], au[T], aw[T], xpl[T], zpl[T];
-  f32x4 X, Z, G, XL, ZL;
-  {
-    float x[T], z[T], g[T], xl[T], zl[T];
+  float x0[T], z0[T], g0[T], xl0[T], zl0[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const long long i = I * W + lane + 64LL * t;
-      const bool ok = i < a.n;
-      x[t] = ok ? a.x[i] : kPadPosF; z[t] = ok ? a.z[i] : kPadPosF; g[t] = ok ? a.g[i] : 0.0f;
-      xl[t] = (HILO && ok) ? a.xl[i] : 0.0f; zl[t] = (HILO && ok) ? a.zl[i] : 0.0f;
-      xp[t] = (f32x2){x[t], x[t]}; zp[t] = (f32x2){z[t], z[t]}; gp[t] = (f32x2){g[t], g[t]};
-      xpl[t] = (f32x2){xl[t], xl[t]}; zpl[t] = (f32x2){zl[t], zl[t]};
-      au[t] = (f32x2){0.f, 0.f}; aw[t] = (f32x2){0.f, 0.f};
-    }
-    X = (f32x4){x[0], x[1], x[2], x[3]}; Z = (f32x4){z[0], z[1], z[2], z[3]}; G = (f32x4){g[0], g[1], g[2], g[3]};
-    XL = (f32x4){xl[0], xl[1], xl[2], xl[3]}; ZL = (f32x4){zl[0], zl[1], zl[2], zl[3]};
+  for (int t = 0; t < T; ++t) {
+    const long long i = I * W + lane + 64LL * t;
+    const bool ok = i < a.n;
+    x0[t] = ok ? a.x[i] : kPadPosF; z0[t] = ok ? a.z[i] : kPadPosF; g0[t] = ok ? a.g[i] : 0.0f;
+    xl0[t] = (HILO && ok) ? a.xl[i] : 0.0f; zl0[t] = (HILO && ok) ? a.zl[i] : 0.0f;
+    xp[t] = (f32x2){x0[t], x0[t]}; zp[t] = (f32x2){z0[t], z0[t]}; gp[t] = (f32x2){g0[t], g0[t]};
+    xpl[t] = (f32x2){xl0[t], xl0[t]}; zpl[t] = (f32x2){zl0[t], zl0[t]};
+    au[t] = (f32x2){0.f, 0.f}; aw[t] = (f32x2){0.f, 0.f};
   }
   const f32x2 vc4 = {a.vc4, a.vc4};
 
   // ---- diagonal tile: ordered evaluation, i-side only (contains the self pairs) ----------------
   if (y == 0) {
-    *reinterpret_cast<f32x4*>(&lx[lane * T]) = X;
-    *reinterpret_cast<f32x4*>(&lz[lane * T]) = Z;
-    *reinterpret_cast<f32x4*>(&lg[lane * T]) = G;
-    if (HILO) {
-      *reinterpret_cast<f32x4*>(&lxl[lane * T]) = XL;
-      *reinterpret_cast<f32x4*>(&lzl[lane * T]) = ZL;
-    }
+    slab_store<T>(lx, lane, x0); slab_store<T>(lz, lane, z0); slab_store<T>(lg, lane, g0);
+    if (HILO) { slab_store<T>(lxl, lane, xl0); slab_store<T>(lzl, lane, zl0); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int k = 0; k < 64; ++k) {
       const int pos = ((lane + k) & 63) * T;
-      const f32x4 XJ = *reinterpret_cast<const f32x4*>(&lx[pos]);
-      const f32x4 ZJ = *reinterpret_cast<const f32x4*>(&lz[pos]);
-      const f32x4 GJ = *reinterpret_cast<const f32x4*>(&lg[pos]);
-      f32x4 XJL, ZJL;
-      if (HILO) {
-        XJL = *reinterpret_cast<const f32x4*>(&lxl[pos]);
-        ZJL = *reinterpret_cast<const f32x4*>(&lzl[pos]);
-      }
+      f32x2 xj[H], zj[H], gj[H], xjl[H], zjl[H];
+      slab_load<T>(lx, pos, xj); slab_load<T>(lz, pos, zj); slab_load<T>(lg, pos, gj);
+      if (HILO) { slab_load<T>(lxl, pos, xjl); slab_load<T>(lzl, pos, zjl); }
 #pragma unroll
       for (int m = 0; m < H; ++m) {
-        const f32x2 xj = m ? (f32x2){XJ.z, XJ.w} : (f32x2){XJ.x, XJ.y};
-        const f32x2 zj = m ? (f32x2){ZJ.z, ZJ.w} : (f32x2){ZJ.x, ZJ.y};
-        const f32x2 gj = m ? (f32x2){GJ.z, GJ.w} : (f32x2){GJ.x, GJ.y};
-        f32x2 xjl, zjl;
-        if (HILO) {
-          xjl = m ? (f32x2){XJL.z, XJL.w} : (f32x2){XJL.x, XJL.y};
-          zjl = m ? (f32x2){ZJL.z, ZJL.w} : (f32x2){ZJL.x, ZJL.y};
-        }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          f32x2 dx = xp[t] - xj;
-          f32x2 dz = zp[t] - zj;
-          if (HILO) { dx = dx + (xpl[t] - xjl); dz = dz + (zpl[t] - zjl); }
+          f32x2 dx = xp[t] - xj[m];
+          f32x2 dz = zp[t] - zj[m];
+          if (HILO) { dx = dx + (xpl[t] - xjl[m]); dz = dz + (zpl[t] - zjl[m]); }
           f32x2 r2 = dx * dx;
           r2 = __builtin_elementwise_fma(dz, dz, r2);
           const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
           f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
-          s = s * gj;
+          s = s * gj[m];
           au[t] = __builtin_elementwise_fma(dz, s, au[t]);
           aw[t] = __builtin_elementwise_fma(dx, s, aw[t]);
         }
@@ -167,13 +161,8 @@ pair_sym_f32(SymArgs a) {
         x[t] = ok ? a.x[j] : kPadPosF; z[t] = ok ? a.z[j] : kPadPosF; g[t] = ok ? a.g[j] : 0.0f;
         xl[t] = (HILO && ok) ? a.xl[j] : 0.0f; zl[t] = (HILO && ok) ? a.zl[j] : 0.0f;
       }
-      *reinterpret_cast<f32x4*>(&lx[lane * T]) = (f32x4){x[0], x[1], x[2], x[3]};
-      *reinterpret_cast<f32x4*>(&lz[lane * T]) = (f32x4){z[0], z[1], z[2], z[3]};
-      *reinterpret_cast<f32x4*>(&lg[lane * T]) = (f32x4){g[0], g[1], g[2], g[3]};
-      if (HILO) {
-        *reinterpret_cast<f32x4*>(&lxl[lane * T]) = (f32x4){xl[0], xl[1], xl[2], xl[3]};
-        *reinterpret_cast<f32x4*>(&lzl[lane * T]) = (f32x4){zl[0], zl[1], zl[2], zl[3]};
-      }
+      slab_store<T>(lx, lane, x); slab_store<T>(lz, lane, z); slab_store<T>(lg, lane, g);
+      if (HILO) { slab_store<T>(lxl, lane, xl); slab_store<T>(lzl, lane, zl); }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -187,34 +176,21 @@ pair_sym_f32(SymArgs a) {
     for (int k = 0; k < 64; ++k) {
       // at step k this lane holds the accumulators of the J vortices whose home lane is (lane + k) % 64
       const int pos = ((lane + k) & 63) * T;
-      const f32x4 XJ = *reinterpret_cast<const f32x4*>(&lx[pos]);
-      const f32x4 ZJ = *reinterpret_cast<const f32x4*>(&lz[pos]);
-      const f32x4 GJ = *reinterpret_cast<const f32x4*>(&lg[pos]);
-      f32x4 XJL, ZJL;
-      if (HILO) {
-        XJL = *reinterpret_cast<const f32x4*>(&lxl[pos]);
-        ZJL = *reinterpret_cast<const f32x4*>(&lzl[pos]);
-      }
+      f32x2 xj[H], zj[H], gj[H], xjl[H], zjl[H];
+      slab_load<T>(lx, pos, xj); slab_load<T>(lz, pos, zj); slab_load<T>(lg, pos, gj);
+      if (HILO) { slab_load<T>(lxl, pos, xjl); slab_load<T>(lzl, pos, zjl); }
 #pragma unroll
       for (int m = 0; m < H; ++m) {
-        const f32x2 xj = m ? (f32x2){XJ.z, XJ.w} : (f32x2){XJ.x, XJ.y};
-        const f32x2 zj = m ? (f32x2){ZJ.z, ZJ.w} : (f32x2){ZJ.x, ZJ.y};
-        const f32x2 gj = m ? (f32x2){GJ.z, GJ.w} : (f32x2){GJ.x, GJ.y};
-        f32x2 xjl, zjl;
-        if (HILO) {
-          xjl = m ? (f32x2){XJL.z, XJL.w} : (f32x2){XJL.x, XJL.y};
-          zjl = m ? (f32x2){ZJL.z, ZJL.w} : (f32x2){ZJL.x, ZJL.y};
-        }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          f32x2 dx = xp[t] - xj;
-          f32x2 dz = zp[t] - zj;
-          if (HILO) { dx = dx + (xpl[t] - xjl); dz = dz + (zpl[t] - zjl); }
+          f32x2 dx = xp[t] - xj[m];
+          f32x2 dz = zp[t] - zj[m];
+          if (HILO) { dx = dx + (xpl[t] - xjl[m]); dz = dz + (zpl[t] - zjl[m]); }
           f32x2 r2 = dx * dx;
           r2 = __builtin_elementwise_fma(dz, dz, r2);
           const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
           const f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
-          const f32x2 sj = s * gj;         // strength of j acting on i
+          const f32x2 sj = s * gj[m];      // strength of j acting on i
           const f32x2 si = s * gp[t];      // strength of i acting on j
           au[t] = __builtin_elementwise_fma(dz, sj, au[t]);
           aw[t] = __builtin_elementwise_fma(dx, sj, aw[t]);
@@ -227,7 +203,7 @@ pair_sym_f32(SymArgs a) {
       for (int m = 0; m < H; ++m) { bu[m] = dpp_rol1(bu[m]); bw[m] = dpp_rol1(bw[m]); }
     }
     // 64 rotations: the J accumulators are home again; j feels the opposite of what i feels.
-    // home lane l holds vortices J*W + l + 64*t as packed elements t = 0..3
+    // home lane l holds vortices J*W + l + 64*t as packed elements t = 0..T-1
 #pragma unroll
     for (int m = 0; m < H; ++m) {
       const long long j0 = J * W + lane + 64LL * (2 * m), j1 = j0 + 64;

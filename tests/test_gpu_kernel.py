@@ -323,10 +323,10 @@ def test_full_size_config3_properties(eng):
         eng.set_stream(None)
 
 
-@pytest.mark.parametrize("n", [16384, 16385, 20000, 65536 + 255, 131072])
+@pytest.mark.parametrize("n", [16384, 16385, 20000, 65536 + 255, 98304, 98305, 131072, 131072 + 511, 200000])
 def test_symmetric_kernel_tile_edges(eng, n):
-    """Symmetric self-interaction at sizes around its 256-vortex tiling (odd and even tile counts,
-    ragged last tile) against the C oracle and the direct kernel."""
+    """Symmetric self-interaction at sizes around its tilings (256-vortex tiles below 98 304 vortices,
+    512 from there; odd and even tile counts, ragged last tile) against the C oracle and the direct kernel."""
     import torch
     rng = np.random.default_rng(n)
     x = rng.uniform(-10, 0, n).astype(np.float32)
@@ -364,7 +364,7 @@ def test_symmetric_tile_ring_partition(eng, ranks, n):
     separate accumulators, add up to the full self-interaction (what the reduce-scatter does), and one
     owner's block step equals the direct advection of that block."""
     import torch
-    tile = 256
+    from ludvm_amd._ffi import SYM_TILE as tile
     n_loc = ((n + ranks - 1) // ranks + tile - 1) // tile * tile
     n_pad = n_loc * ranks
     rng = np.random.default_rng(n)

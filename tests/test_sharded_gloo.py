@@ -28,7 +28,8 @@ class OracleShardKernel:
 
     def sym_accumulate(self, xs, zs, gs, tile_first, tile_count, v_core, acc_u, acc_w):
         x, z, g = xs.numpy().astype(np.float64), zs.numpy().astype(np.float64), gs.numpy().astype(np.float64)
-        n, W = len(x), 256
+        from ludvm_amd._ffi import SYM_TILE
+        n, W = len(x), SYM_TILE
         nt = (n + W - 1) // W
         even = nt % 2 == 0 and nt > 1
         dtot = (nt - 1) // 2 + (1 if even else 0)
@@ -89,7 +90,7 @@ def _worker(rank, world, port, n, steps, out, symmetric):
         x, z, g = _wake(n)
         wake = ShardedWake(x, z, g, 0.065, 5e-2, OracleShardKernel(), torch.device("cpu"), symmetric=symmetric)
         per = (n + world - 1) // world
-        assert wake.n_loc == ((per + 255) // 256 * 256 if symmetric else per) and wake.lo == rank * wake.n_loc
+        assert wake.n_loc == ((per + 511) // 512 * 512 if symmetric else per) and wake.lo == rank * wake.n_loc
         assert wake.pairs_per_step == float(n) * n
         for _ in range(steps):
             wake.step()
@@ -109,7 +110,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,n,symmetric", [(2, 600, False), (3, 601, False), (2, 600, True), (3, 601, True),
-                                               (2, 1500, True)])
+                                               (2, 2500, True)])
 def test_sharded_steps_equal_serial(tmp_path, world, n, symmetric):
     out = str(tmp_path / "pos.npy")
     mp.spawn(_worker, args=(world, _free_port(), n, 3, out, symmetric), nprocs=world, join=True)

@@ -10,7 +10,7 @@
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 using namespace ludvm;
 
-template <int T, bool PF, bool NOATOM>
+template <int T>
 void run(const char* name, long long N, int ysplit, int reps, float* dx, float* dz, float* dg, float* au, float* aw, float* du,
          float* dw, const std::vector<long long>& idx, const std::vector<double>& ru, const std::vector<double>& rw) {
   SymArgs a{};
@@ -18,6 +18,7 @@ void run(const char* name, long long N, int ysplit, int reps, float* dx, float* 
   const long long W = 64LL * T;
   a.ntiles = (N + W - 1) / W;
   a.dmax = (a.ntiles - 1) / 2;
+  a.i_first = 0; a.i_count = a.ntiles;
   a.ysplit = ysplit;
   a.acc_u = au; a.acc_w = aw;
   const float vc = 0.065f;
@@ -27,7 +28,7 @@ void run(const char* name, long long N, int ysplit, int reps, float* dx, float* 
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&]() {
     CK(hipMemsetAsync(au, 0, N * 4)); CK(hipMemsetAsync(aw, 0, N * 4));
-    hipLaunchKernelGGL((pair_sym_f32<T, PF, NOATOM>), grid, dim3(kBlock), 0, 0, a);
+    hipLaunchKernelGGL((pair_sym_f32<T, false>), grid, dim3(kBlock), 0, 0, a);
     hipLaunchKernelGGL(finish_sym, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, au, aw, N, du, dw);
   };
   launch(); CK(hipDeviceSynchronize());
@@ -79,8 +80,16 @@ int main(int argc, char** argv) {
     }
     ru[c] = su; rw[c] = sw;
   }
-  for (int ys : {8, 16, 32}) run<4, false, false>("sym nopf", N, ys, reps, dx, dz, dg, au, aw, du, dw, idx, ru, rw);
-  for (int ys : {8, 16, 32}) run<4, true, false>("sym pf", N, ys, reps, dx, dz, dg, au, aw, du, dw, idx, ru, rw);
-  for (int ys : {16}) run<4, true, true>("sym pf noatomics(wrong)", N, ys, reps, dx, dz, dg, au, aw, du, dw, idx, ru, rw);
+  auto ys_for = [&](int T) {
+    long long ntiles = (N + 64LL * T - 1) / (64LL * T);
+    long long dtot = (ntiles - 1) / 2 + ((ntiles % 2 == 0 && ntiles > 1) ? 1 : 0);
+    long long ys = (65536 + ntiles - 1) / ntiles;
+    ys = std::max<long long>(1, std::min<long long>(std::min<long long>(ys, 64), std::max<long long>(dtot, 1)));
+    return (int)ys;
+  };
+  for (int rep = 0; rep < 3; ++rep) {
+    run<4>("sym T4", N, ys_for(4), reps, dx, dz, dg, au, aw, du, dw, idx, ru, rw);
+    run<8>("sym T8", N, ys_for(8), reps, dx, dz, dg, au, aw, du, dw, idx, ru, rw);
+  }
   return 0;
 }
