@@ -33,8 +33,8 @@ FLOP_PER_PAIR = 13                # sub sub mul fma fma rsq mul fma fma (FMA = 2
 # HBM-side bytes per launch of the dominant kernel at config 3 (N = 1e6), from separate rocprofv3 --pmc
 # passes of this same command (profiles/r01_bench_cfg3_{direct,sym}_pmc_{fetch,write}.csv): FETCH_SIZE +
 # WRITE_SIZE in bytes.  Uncalibrated for these access widths (MI355X_MICROARCH.md, HBM section); the
-# symmetric kernel's write side is its float atomics (2.46e8 64-B requests).  Not measured in this run.
-PMC_TRAFFIC_BYTES_CFG3 = {"direct": 73.2e6 + 72.0e6, "symmetric": 2.38e9 + 15.76e9}
+# symmetric kernel's write side is its float atomics (1.26e8 64-B requests).  Not measured in this run.
+PMC_TRAFFIC_BYTES_CFG3 = {"direct": 73.2e6 + 72.0e6, "symmetric": 1.50e9 + 8.08e9}
 V_CORE = 0.065
 DT = 5e-2
 
@@ -188,7 +188,7 @@ def main():
                        "source_splits": args.splits or "auto"},
             "roofline": {
                 "bound": "valu",
-                "kernel": ("ludvm::pair_sym_f32 (each unordered pair once: 9 executed FLOP per ordered pair; "
+                "kernel": ("ludvm::pair_sym_f32<8> (each unordered pair once: 9 executed FLOP per ordered pair; "
                            "packed fp32 vector ALU; no MFMA, not HBM-bound)") if symmetric else
                           "ludvm::pair_f32 (direct, packed fp32 vector ALU; no MFMA, not HBM-bound)",
                 "executed_flop_per_pair": 9 if symmetric else 13,

@@ -47,18 +47,20 @@ __device__ __forceinline__ float dpp_rol1(float v) {
 }
 __device__ __forceinline__ f32x2 dpp_rol1(f32x2 v) { return (f32x2){dpp_rol1(v.x), dpp_rol1(v.y)}; }
 
-// Slab helpers: a wave's LDS slab holds T floats per home lane and component.
+// Slab helpers: a wave's LDS slab holds T floats per home lane and component, as T/4 planes of
+// [64 home lanes][4 floats]: every ds_read_b128 / ds_write_b128 of a wave then covers 64 consecutive
+// 16-byte slots (conflict-free); `home4` is 4 * home lane.
 template <int T>
-__device__ __forceinline__ void slab_store(float* l, int lane, const float (&v)[T]) {
+__device__ __forceinline__ void slab_store(float* l, int home4, const float (&v)[T]) {
 #pragma unroll
   for (int q = 0; q < T / 4; ++q)
-    *reinterpret_cast<f32x4*>(&l[lane * T + 4 * q]) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    *reinterpret_cast<f32x4*>(&l[q * 256 + home4]) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
 template <int T>
-__device__ __forceinline__ void slab_load(const float* l, int pos, f32x2 (&out)[T / 2]) {
+__device__ __forceinline__ void slab_load(const float* l, int home4, f32x2 (&out)[T / 2]) {
 #pragma unroll
   for (int q = 0; q < T / 4; ++q) {
-    const f32x4 V = *reinterpret_cast<const f32x4*>(&l[pos + 4 * q]);
+    const f32x4 V = *reinterpret_cast<const f32x4*>(&l[q * 256 + home4]);
     out[2 * q] = (f32x2){V.x, V.y};
     out[2 * q + 1] = (f32x2){V.z, V.w};
   }
@@ -116,13 +118,13 @@ pair_sym_f32(SymArgs a) {
 
   // ---- diagonal tile: ordered evaluation, i-side only (contains the self pairs) ----------------
   if (y == 0) {
-    slab_store<T>(lx, lane, x0); slab_store<T>(lz, lane, z0); slab_store<T>(lg, lane, g0);
-    if (HILO) { slab_store<T>(lxl, lane, xl0); slab_store<T>(lzl, lane, zl0); }
+    slab_store<T>(lx, lane * 4, x0); slab_store<T>(lz, lane * 4, z0); slab_store<T>(lg, lane * 4, g0);
+    if (HILO) { slab_store<T>(lxl, lane * 4, xl0); slab_store<T>(lzl, lane * 4, zl0); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int k = 0; k < 64; ++k) {
-      const int pos = ((lane + k) & 63) * T;
+      const int pos = ((lane + k) & 63) * 4;
       f32x2 xj[H], zj[H], gj[H], xjl[H], zjl[H];
       slab_load<T>(lx, pos, xj); slab_load<T>(lz, pos, zj); slab_load<T>(lg, pos, gj);
       if (HILO) { slab_load<T>(lxl, pos, xjl); slab_load<T>(lzl, pos, zjl); }
@@ -161,8 +163,8 @@ pair_sym_f32(SymArgs a) {
         x[t] = ok ? a.x[j] : kPadPosF; z[t] = ok ? a.z[j] : kPadPosF; g[t] = ok ? a.g[j] : 0.0f;
         xl[t] = (HILO && ok) ? a.xl[j] : 0.0f; zl[t] = (HILO && ok) ? a.zl[j] : 0.0f;
       }
-      slab_store<T>(lx, lane, x); slab_store<T>(lz, lane, z); slab_store<T>(lg, lane, g);
-      if (HILO) { slab_store<T>(lxl, lane, xl); slab_store<T>(lzl, lane, zl); }
+      slab_store<T>(lx, lane * 4, x); slab_store<T>(lz, lane * 4, z); slab_store<T>(lg, lane * 4, g);
+      if (HILO) { slab_store<T>(lxl, lane * 4, xl); slab_store<T>(lzl, lane * 4, zl); }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -175,7 +177,7 @@ pair_sym_f32(SymArgs a) {
     // waves per SIMD the LDS latency is already covered)
     for (int k = 0; k < 64; ++k) {
       // at step k this lane holds the accumulators of the J vortices whose home lane is (lane + k) % 64
-      const int pos = ((lane + k) & 63) * T;
+      const int pos = ((lane + k) & 63) * 4;
       f32x2 xj[H], zj[H], gj[H], xjl[H], zjl[H];
       slab_load<T>(lx, pos, xj); slab_load<T>(lz, pos, zj); slab_load<T>(lg, pos, gj);
       if (HILO) { slab_load<T>(lxl, pos, xjl); slab_load<T>(lzl, pos, zjl); }
