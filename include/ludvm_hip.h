@@ -75,7 +75,7 @@ int ludvm_set_tuning(ludvm_ctx* ctx, int targets_per_lane, int source_splits);
 
 /* Self-interaction launches (targets are exactly the sources: wake roll-up, all-pairs calls on one
  * array) may use the symmetric kernel, which evaluates each unordered pair once (K(i->j) = -K(j->i))
- * and accumulates with float atomics: ~1.4x faster, reproducible to rounding but not bitwise.
+ * and accumulates with float atomics: ~1.5x faster, reproducible to rounding but not bitwise.
  * mode 0 = never (direct kernel, bitwise reproducible), 1 = automatic (default; fp32, N >= 16384),
  * mode >= 2 = automatic with that value as the smallest N that takes the symmetric kernel. */
 int ludvm_set_symmetric(ludvm_ctx* ctx, int mode);

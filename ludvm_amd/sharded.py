@@ -12,7 +12,7 @@ direct (symmetric=False) -- what the north star describes:
     2. ONE all-gather of the [2, n_loc] blocks -> [G, 2, n_loc]; one strided device copy lays them out
        as the next contiguous x[N], z[N] (Gamma never moves).
 
-symmetric (default) -- each unordered pair evaluated once, chip-wide 1.4x faster:
+symmetric (default) -- each unordered pair evaluated once, chip-wide 1.5x faster:
     1. symmetric kernel over the rank's own I-tiles of the global tile ring: J = I + d (mod NT),
        d <= NT/2, so a rank's work depends only on how many tiles it owns (exactly 1/G of the job) and
        touches its own block plus the next half of the ring; raw (u, w) sums of BOTH partners are
