@@ -166,3 +166,37 @@ def test_checkpoint_resume_is_bitwise_with_a_deterministic_engine(tmp_path, sim1
             assert np.array_equal(np.asarray(ra), np.asarray(rc)), (key, s)
     with pytest.raises(ValueError):
         LUDVM(**kw, verbose=False, engine=FakeEngine(), checkpoint_every=10)
+
+
+def test_dat_section_and_sin_motion(tmp_path):
+    # a symmetric section in Selig format (upper surface TE -> LE, then lower LE -> TE): mean line ~ 0
+    xs = 0.5 * (1 - np.cos(np.linspace(0, np.pi, 41)))
+    yt = 0.6 * (0.2969 * np.sqrt(xs) - 0.126 * xs - 0.3516 * xs**2 + 0.2843 * xs**3 - 0.1015 * xs**4)
+    pts = np.r_[np.c_[xs[::-1], yt[::-1]], np.c_[xs[1:], -yt[1:]]]
+    dat = tmp_path / "sym.dat"
+    dat.write_text("SYMMETRIC TEST SECTION\n" + "\n".join(f"{a:.6f} {b:.6f}" for a, b in pts) + "\n")
+    s = LUDVM(**dict(CONFIG1, tf=0.5, Naca=None, foil_filename=str(dat)), engine=FakeEngine(), verbose=False)
+    assert np.abs(s.airfoil["eta"]).max() < 1e-6 and s.airfoil["x"].shape == (81,)
+    ref = LUDVM(**dict(CONFIG1, tf=0.5), engine=FakeEngine(), verbose=False)
+    np.testing.assert_allclose(s.Cl, ref.Cl, rtol=0, atol=1e-4)
+    # cambered NACA digits run (parity unpinned) and give a lifting mean line
+    c = LUDVM(**dict(CONFIG1, tf=0.5, Naca="2412"), engine=FakeEngine(), verbose=False)
+    assert abs(c.airfoil["eta"].max() - 0.02) < 2e-4 and np.all(np.isfinite(c.Cl))
+    # motion='sin' (LUDVM.py:417-421)
+    m = LUDVM(**dict(CONFIG1, tf=0.5), engine=FakeEngine(), verbose=False, run=False)
+    m.motion_sinusoidal(alpha_m=0, alpha_max=10, h_max=1, k=0.2 * np.pi, phi=90, h0=0, x0=0, motion="sin")
+    assert abs(m.hpiv[0]) < 1e-15 and abs(m.alpha[0] - np.deg2rad(10)) < 1e-12
+    with pytest.raises(ValueError):
+        m.motion_sinusoidal(motion="saw")
+
+
+def test_animation_builds_headless(sim1):
+    import matplotlib
+    matplotlib.use("Agg", force=True)
+    ani = sim1.animation(step=100, ani_interval=1)
+    assert ani is not None
+    import matplotlib.pyplot as plt
+    plt.close("all")
+    sp = LUDVM(**dict(CONFIG1, tf=0.5), engine=FakeEngine(), verbose=False, history="sparse")
+    with pytest.raises(RuntimeError):
+        sp.animation()
