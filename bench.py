@@ -152,6 +152,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # RCCL builds its communicators on the first collective of each kind: do that outside the measurement
+        # even when --warmup is 0
+        probe = torch.zeros(world * 4, dtype=torch.float32, device=device)
+        piece = torch.ones(4, dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(probe, piece)
+        if backend == "nccl":
+            dist.reduce_scatter_tensor(piece, probe, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(probe)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
