@@ -4,7 +4,9 @@ There is no CPU implementation behind this module: if the shared library is miss
 loaded, `load()` raises, and so does every product entry point that needs it.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -72,6 +74,33 @@ class LudvmHipError(RuntimeError):
         self.code = code
 
 
+def _pin_hip_runtime():
+    """Keep ONE HIP runtime in the process.  PyTorch-ROCm wheels carry their own libamdhip64.so /
+    libhsa-runtime64.so (SONAME libamdhip64.so.7, like /opt/rocm's).  If torch is loaded first the
+    engine's DT_NEEDED entry resolves to torch's copy and everything shares one runtime; if the engine
+    were loaded first it would bring in /opt/rocm's copy, torch would later map its own next to it, and
+    stream handles / device init would cross two runtimes (torch then reports "No HIP GPUs are
+    available").  So when a torch install is present its runtime is mapped before the engine, whatever
+    the import order.  Without torch the engine uses the system ROCm runtime."""
+    if "torch" in sys.modules:
+        return
+    with open("/proc/self/maps") as f:
+        if any("libamdhip64" in line for line in f):
+            return                              # a runtime is already mapped: the loader will reuse it
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        try:
+            ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass                                # unusable torch install: fall back to the system runtime
+
+
 def load(path=None):
     """dlopen the engine and set the prototypes.  Raises OSError when the library is absent."""
     global _lib
@@ -81,6 +110,7 @@ def load(path=None):
     if not os.path.exists(p):
         raise OSError(f"{p} not found: build it with `make -C ludvm_amd/csrc` (or __graft_entry__.build()); "
                       "there is no CPU fallback")
+    _pin_hip_runtime()
     lib = ctypes.CDLL(p)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -59,3 +59,22 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("the oracle", "").replace("oracle to cover", "") or f == "sharded.py", f
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_single_hip_runtime_whatever_the_import_order():
+    """PyTorch-ROCm bundles its own libamdhip64.so; the engine must share it rather than map the system
+    copy next to it (two runtimes in one process: torch cannot initialise its device afterwards, stream
+    handles cross runtimes).  Load the engine first, torch second, and count the mapped runtimes."""
+    import subprocess
+    import sys
+    code = (
+        "from ludvm_amd import _ffi\n"
+        "_ffi.load()\n"
+        "import torch\n"
+        "libs = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l or 'libhsa-runtime64' in l}\n"
+        "print(len(libs))\n"
+        "print(sorted(libs))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.splitlines()[0] == "2", out.stdout      # one HIP runtime + one HSA runtime
