@@ -105,7 +105,8 @@ def main():
     # Rehearsal on a one-GPU box (not a measurement): LUDVM_BENCH_BACKEND=gloo lets several ranks share
     # a card so the multi-rank control flow can be exercised; the driver's runs use RCCL, one GPU each.
     backend = os.environ.get("LUDVM_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    # modulo the visible devices: also right when a launcher shows each rank only its own card
+    dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:

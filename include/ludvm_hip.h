@@ -187,6 +187,42 @@ int ludvm_wake_step(ludvm_ctx* ctx, const double* new_x, const double* new_z, co
                     size_t tail_count, const double* xt, const double* zt, size_t nt, double* tail_x, double* tail_z,
                     double* unit_x, double* unit_z, double* u_wake, double* w_wake, double* u_unit, double* w_unit);
 
+/* ---- device-resident time march: many steps of LUDVM.time_loop per call (LUDVM.py:597-1171) --------
+ *
+ * ludvm_wake_step still costs one host round trip per time step, because the Gamma solve between two
+ * roll-ups (LUDVM.py:743-1090) runs on the host.  These two calls move that solve to the device ('Faure'
+ * method: closed-form Gamma_TEV :758-760, the 2x2 TEV/LEV system :944-954, Fourier coefficients :765-773,
+ * LESP criterion :781-805, bound vorticity :987-1010, loads :1035-1090), so `count` consecutive steps are
+ * enqueued back to back; whether a LEV is shed -- and hence the wake size -- is decided on the device.
+ *
+ * ludvm_march_setup uploads what does not change during a run:
+ *   scalars[8] = Uinf, chord, rho, dt, piv, v_core, IC (:647), sum(Gamma_free);
+ *   tables     = detadx_panel[np] | eta_panel[np] | x_panel[np] | cm1[np] | wq[np] | opcs[np] | hcsd[np] | wx[np]
+ *                | cproj[nc][np] | ssin[nc-1][np]
+ *                with np = npan, nc = ncoef and, on theta_panel with trapezoid weights wq:
+ *                cm1 = (cos(theta) - 1) wq, opcs = (1 + cos)/sin, hcsd = c/2 sin(theta) dtheta, wx = trapezoid
+ *                weights on x_panel, cproj[0] = -wq/pi, cproj[n] = 2/pi cos(n theta) wq, ssin[n-1] = sin(n theta);
+ *   kin        = one row per time step i, [alpha, alpha_dot, h_dot, te_x, te_z, le_x, le_z, xg[np], zg[np]]
+ *                (airfoil_gamma_points and the edges of path['airfoil'] at step i).
+ * 1 <= npan <= 256, 4 <= ncoef <= 64.
+ *
+ * ludvm_march_run advances the resident wake through time steps [first_step, first_step + count), all inside
+ * the kinematics table.  state (16 + ncoef doubles, in and out):
+ *   [0] wake size (in: must equal ludvm_wake_size)   [1] TEVs shed   [2] LEVs shed
+ *   [3] a LEV was shed in the previous step          [4] LESPcrit with its current sign (:802-805)
+ *   [5] sum Gamma_TEV   [6] sum Gamma_LEV            [7..10] tev_x, lev_x, tev_z, lev_z of the coming step
+ *   [11] out: vortices shed by the last step (1 or 2)
+ *   [12..15] out: x[size-2], x[size-1], z[size-2], z[size-1] after the last roll-up
+ *   [16..16+ncoef) Fourier coefficients of the previous step.
+ * rows (out): count rows of 10 + 2 ncoef + 2 npan doubles:
+ *   g_tev, g_lev, shed(0/1), bound, LESP_prev, LESP, Fn, Fs, M, wake slot of the new TEV,
+ *   A[ncoef], dA/dt[ncoef], gamma[npan], dGamma[npan].
+ * Synchronous: returns when the last step has finished.  `precision` selects the roll-up arithmetic as in
+ * ludvm_wake_advect; the solve is float64. */
+int ludvm_march_setup(ludvm_ctx* ctx, int npan, int ncoef, const double* scalars, const double* tables, const double* kin,
+                      size_t kin_rows);
+int ludvm_march_run(ludvm_ctx* ctx, long long first_step, long long count, int precision, double* state, double* rows);
+
 /* ---- flow field: backs LUDVM.flowfield (LUDVM.py:1186-1298) -------------------------------- */
 
 /* Grid targets generated on the device, x-major ravel like np.meshgrid(indexing='ij')

@@ -4,6 +4,7 @@
 #include "../../include/ludvm_hip.h"
 #include "pair_kernels.hpp"
 #include "pair_sym_kernels.hpp"
+#include "march_kernels.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -52,6 +53,16 @@ struct ludvm_ctx {
   size_t wake_cap = 0, wake_n = 0;
   double *x64 = nullptr, *z64 = nullptr, *g64 = nullptr;
   float *xh = nullptr, *xl = nullptr, *zh = nullptr, *zl = nullptr, *g32 = nullptr;
+
+  // device-resident march (ludvm_march_setup / ludvm_march_run)
+  Buf march_tab, march_kin, march_rows, march_state;
+  MarchSetup msetup{};
+  size_t march_kin_rows = 0;
+  double march_vcore = 0.0;
+  bool march_ready = false;
+  unsigned long long* progress = nullptr;      // host-mapped: (step << 32 | wake size) after each solve
+  unsigned long long* progress_dev = nullptr;
+  hipEvent_t march_ev[2] = {nullptr, nullptr};
 
   // kernel timing
   bool timing = false;
@@ -319,9 +330,10 @@ bool use_symmetric(const ludvm_ctx* c, long long n) {
 // are ADDED into acc_u / acc_w (n floats each, zeroed by the caller).
 int launch_sym_tiles(ludvm_ctx* c, int T, const float* x, const float* z, const float* g, long long n, long long i_first,
                      long long i_count, double vc4, float* acc_u, float* acc_w, const float* xl = nullptr,
-                     const float* zl = nullptr) {
+                     const float* zl = nullptr, const long long* n_dev = nullptr) {
   SymArgs a{};
   a.x = x; a.z = z; a.g = g; a.n = n;
+  a.n_dev = n_dev;     // march: n is an upper bound for the launch geometry, the kernel reads the real one
   a.xl = xl; a.zl = zl;
   const bool hilo = xl && zl;
   if (hilo) T = 4;
@@ -356,14 +368,14 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const float* x, const float* z, const 
 // Symmetric self-interaction of all of (x, z, g)[0, n): zero the context's accumulators, run the kernel.
 // The raw sums are left in c->acc as [acc_u | acc_w], each nt_pad floats.
 int launch_sym(ludvm_ctx* c, const float* x, const float* z, const float* g, long long n, double vc4, long long* nt_pad_out,
-               const float* xl = nullptr, const float* zl = nullptr) {
+               const float* xl = nullptr, const float* zl = nullptr, const long long* n_dev = nullptr) {
   const long long nt_pad = (n + 63) / 64 * 64;
   CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(float)));
   HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(float), c->stream));
   float* acc = static_cast<float*>(c->acc.p);
   const int T = (n >= kSymT8MinN && !(xl && zl)) ? 8 : 4;
   const long long ntiles = (n + 64LL * T - 1) / (64LL * T);
-  CHK(launch_sym_tiles(c, T, x, z, g, n, 0, ntiles, vc4, acc, acc + nt_pad, xl, zl));
+  CHK(launch_sym_tiles(c, T, x, z, g, n, 0, ntiles, vc4, acc, acc + nt_pad, xl, zl, n_dev));
   *nt_pad_out = nt_pad;
   return LUDVM_OK;
 }
@@ -452,9 +464,13 @@ int ludvm_destroy(ludvm_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& t : c->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   for (auto& t : c->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
-  void* bufs[] = {c->part.p, c->acc.p, c->arena.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32};
+  void* bufs[] = {c->part.p, c->acc.p, c->arena.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32,
+                  c->march_tab.p, c->march_kin.p, c->march_rows.p, c->march_state.p};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
+  for (auto& e : c->march_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->progress) (void)hipHostFree(c->progress);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_out) (void)hipHostFree(c->pin_out);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -884,30 +900,36 @@ int ludvm_wake_advect_tail(ludvm_ctx* c, double dt, const double* foil_x, const 
 
 // Roll-up launch on the resident wake (n vortices) with `nfoil` bound vortices already staged behind it
 // at [n, n + nfoil) (masters and mirrors): pair kernel(s) + Euler finisher.  du/dw: optional device
-// arrays receiving the induced velocities.
-static int advect_launch(ludvm_ctx* c, double dt, size_t nfoil, double vcore, int precision, double* du, double* dw) {
-  const size_t n = c->wake_n;
+// arrays receiving the induced velocities.  n_dev (march): the wake size is read on the device and `n` is
+// only an upper bound that sizes the launch.
+static int advect_launch(ludvm_ctx* c, size_t n, const long long* n_dev, double dt, size_t nfoil, double vcore,
+                         int precision, double* du, double* dw) {
   const long long ns = (long long)(n + nfoil), nt = (long long)n;
   const double v2 = vcore * vcore;
   if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt)) {
     // wake x wake: each unordered pair once; bound vortices -> wake: direct kernel into slab row 0
     const bool hilo = precision == LUDVM_PREC_F32X2;
     long long nt_pad = 0;
-    CHK(launch_sym(c, c->xh, c->zh, c->g32, nt, v2 * v2, &nt_pad, hilo ? c->xl : nullptr, hilo ? c->zl : nullptr));
+    CHK(launch_sym(c, c->xh, c->zh, c->g32, nt, v2 * v2, &nt_pad, hilo ? c->xl : nullptr, hilo ? c->zl : nullptr, n_dev));
     if (nfoil > (size_t)kBlock) return fail(c, LUDVM_E_ARG, "too many bound vortices for the fused roll-up");
     const float* acc = static_cast<const float*>(c->acc.p);
     if (hilo)
       hipLaunchKernelGGL(finish_wake_advect_sym<true>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, nt,
-                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw);
+                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw, n_dev);
     else
       hipLaunchKernelGGL(finish_wake_advect_sym<false>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, nt,
-                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw);
+                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw, n_dev);
     HIPCHK(c, hipGetLastError());
     return LUDVM_OK;
   }
   PairArgs a{};
   a.ns = ns;
   a.nt = nt;
+  if (n_dev) {          // sizes relative to the device-side wake size
+    a.n_dev = n_dev; a.ns_dev = 1; a.nt_dev = 1;
+    a.ns = (long long)nfoil;
+    a.nt = 0;
+  }
   a.vc4 = v2 * v2;
   if (precision == LUDVM_PREC_F64) {
     a.xs = c->x64; a.zs = c->z64; a.gs = c->g64; a.xt = c->x64; a.zt = c->z64;
@@ -920,11 +942,11 @@ static int advect_launch(ludvm_ctx* c, double dt, size_t nfoil, double vcore, in
   if (precision == LUDVM_PREC_F64)
     hipLaunchKernelGGL(finish_wake_advect<double>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
                        static_cast<const double*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->xh, c->xl,
-                       c->zh, c->zl, du, dw);
+                       c->zh, c->zl, du, dw, n_dev);
   else
     hipLaunchKernelGGL(finish_wake_advect<float>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
                        static_cast<const float*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->xh, c->xl,
-                       c->zh, c->zl, du, dw);
+                       c->zh, c->zl, du, dw, n_dev);
   HIPCHK(c, hipGetLastError());
   return LUDVM_OK;
 }
@@ -953,7 +975,7 @@ int ludvm_wake_advect(ludvm_ctx* c, double dt, const double* foil_x, const doubl
     du = ar.take<double>(n);
     dw = ar.take<double>(n);
   }
-  CHK(advect_launch(c, dt, nfoil, vcore, precision, du, dw));
+  CHK(advect_launch(c, n, nullptr, dt, nfoil, vcore, precision, du, dw));
   if (u_out) {
     HIPCHK(c, hipMemcpyAsync(u_out, du, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(w_out, dw, n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1003,7 +1025,7 @@ int ludvm_wake_step(ludvm_ctx* c, const double* new_x, const double* new_z, cons
     HIPCHK(c, hipGetLastError());
   }
   c->wake_n = n;
-  CHK(advect_launch(c, dt, nfoil, vcore, precision, nullptr, nullptr));
+  CHK(advect_launch(c, c->wake_n, nullptr, dt, nfoil, vcore, precision, nullptr, nullptr));
   const double* d_xt = din + n_stage;
   const double* d_zt = d_xt + nt;
   const double* d_geo = d_zt + nt;
@@ -1041,6 +1063,189 @@ int ludvm_wake_step(ludvm_ctx* c, const double* new_x, const double* new_z, cons
     std::memcpy(u_unit + k * nt, hs + 2 * nt + (2 * k) * nt, nt * 8);
     std::memcpy(w_unit + k * nt, hs + 2 * nt + (2 * k + 1) * nt, nt * 8);
   }
+  return LUDVM_OK;
+}
+
+/* ---- device-resident time march ------------------------------------------------------------- */
+
+int ludvm_march_setup(ludvm_ctx* c, int npan, int ncoef, const double* scalars, const double* tables, const double* kin,
+                      size_t kin_rows) {
+  if (!c) return LUDVM_E_ARG;
+  c->march_ready = false;
+  if (!scalars || !tables || !kin) return fail(c, LUDVM_E_ARG, "null array");
+  if (npan < 1 || npan > kMarchMaxPan || ncoef < 4 || ncoef > kMarchMaxCoef)
+    return fail(c, LUDVM_E_ARG, "march: 1 <= Npanels <= 256 and 4 <= Ncoeffs <= 64");
+  if (kin_rows < 2) return fail(c, LUDVM_E_ARG, "march: kinematics table too short");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t P = (size_t)npan;
+  const size_t tab_doubles = 8 * P + (size_t)ncoef * P + (size_t)(ncoef - 1) * P;
+  const size_t kin_doubles = kin_rows * (7 + 2 * P);
+  CHK(ensure(c, c->march_tab, tab_doubles * 8));
+  CHK(ensure(c, c->march_kin, kin_doubles * 8));
+  CHK(ensure(c, c->march_state, sizeof(MarchState)));
+  HIPCHK(c, hipMemcpyAsync(c->march_tab.p, tables, tab_doubles * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->march_kin.p, kin, kin_doubles * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  MarchSetup& m = c->msetup;
+  m.npan = npan; m.ncoef = ncoef;
+  m.U = scalars[0]; m.chord = scalars[1]; m.rho = scalars[2]; m.dt = scalars[3]; m.piv = scalars[4];
+  c->march_vcore = scalars[5];
+  m.kelvin0 = scalars[7] - scalars[6];          // sum(Gamma_free) - IC
+  const double* t = static_cast<const double*>(c->march_tab.p);
+  m.detadx = t; m.eta = t + P; m.xpan = t + 2 * P; m.cm1 = t + 3 * P; m.wq = t + 4 * P; m.opcs = t + 5 * P;
+  m.hcsd = t + 6 * P; m.wx = t + 7 * P; m.cproj = t + 8 * P; m.ssin = t + 8 * P + (size_t)ncoef * P;
+  c->march_kin_rows = kin_rows;
+  if (!c->progress) {
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->progress), 64, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->progress_dev), c->progress, 0));
+  }
+  for (auto& e : c->march_ev)
+    if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  c->march_ready = true;
+  return LUDVM_OK;
+}
+
+namespace {
+
+// fp64 wake -> chord partial sums for time step `step` (its chord points are row `step` of the kinematics
+// table), then the finisher that leaves sums, unit influences and placements in the device state.
+int march_chord_launch(ludvm_ctx* c, long long step, long long n_ub) {
+  const MarchSetup& m = c->msetup;
+  const size_t P = (size_t)m.npan;
+  const double* krow = static_cast<const double*>(c->march_kin.p) + (size_t)step * (7 + 2 * P);
+  MarchState* S = static_cast<MarchState*>(c->march_state.p);
+  const double v2 = c->march_vcore * c->march_vcore;
+  PairArgs a{};
+  a.xs = c->x64; a.zs = c->z64; a.gs = c->g64;
+  a.ns = 0; a.n_dev = &S->n; a.ns_dev = 1; a.nt_dev = 0;
+  a.xt = krow + 7; a.zt = krow + 7 + P; a.nt = (long long)P;
+  a.vc4 = v2 * v2;
+  Plan p = make_plan(c, (long long)P, std::max<long long>(n_ub, 1), LUDVM_PREC_F64);
+  const bool was = c->timing;
+  c->timing = false;   // the chord sums are not the dominant kernel
+  int rc = launch_pair(c, a, p, LUDVM_PREC_F64, nullptr, nullptr);
+  c->timing = was;
+  CHK(rc);
+  const double* slab = static_cast<const double*>(c->part.p);
+  hipLaunchKernelGGL(march_chord_finish, dim3(blocks_for((long long)(2 * P * 64))), dim3(kBlock), 0, c->stream,
+                     p.nsplit > 1 ? slab : (const double*)nullptr, p.nt_pad, p.nsplit, slab, krow + 7, krow + 7 + P,
+                     (long long)P, c->x64, c->z64, S, krow + 3, v2 * v2);
+  HIPCHK(c, hipGetLastError());
+  return LUDVM_OK;
+}
+
+// workspace a march step may need when the wake holds at most n_ub vortices
+void march_workspace(const ludvm_ctx* c, long long n_ub, int precision, size_t nfoil, size_t& part_bytes, size_t& acc_bytes) {
+  const long long nt = std::max<long long>(n_ub, 1);
+  if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt)) {
+    acc_bytes = std::max(acc_bytes, (size_t)2 * (size_t)((nt + 63) / 64 * 64) * sizeof(float));
+  } else {
+    Plan p = make_plan(c, nt, nt + (long long)nfoil, precision);
+    const size_t elt = precision == LUDVM_PREC_F64 ? 8 : 4;
+    part_bytes = std::max(part_bytes, (size_t)p.nsplit * 2 * (size_t)p.nt_pad * elt);
+  }
+  Plan q = make_plan(c, (long long)nfoil, nt, LUDVM_PREC_F64);
+  part_bytes = std::max(part_bytes, (size_t)q.nsplit * 2 * (size_t)q.nt_pad * 8);
+}
+
+}  // namespace
+
+int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int precision, double* state, double* rows) {
+  if (!c) return LUDVM_E_ARG;
+  if (!c->march_ready) return fail(c, LUDVM_E_STATE, "ludvm_march_setup has not been called");
+  if (!valid_precision(precision)) return fail(c, LUDVM_E_ARG, "unknown precision");
+  if (!state || !rows) return fail(c, LUDVM_E_ARG, "null array");
+  if (count < 1 || first_step < 1 || (size_t)(first_step + count) > c->march_kin_rows)
+    return fail(c, LUDVM_E_ARG, "march: steps outside the kinematics table");
+  const MarchSetup& m = c->msetup;
+  const size_t P = (size_t)m.npan, nfoil = P;
+  const size_t row_doubles = kMarchRowHead + 2 * (size_t)m.ncoef + 2 * P;
+  const long long n0 = (long long)c->wake_n;
+  if ((long long)state[0] != n0) return fail(c, LUDVM_E_ARG, "march: state[0] must be the current wake size");
+  if (n0 + 2 * count + (long long)nfoil >= (1LL << 32)) return fail(c, LUDVM_E_ARG, "march: wake too large");
+  HIPCHK(c, hipSetDevice(c->device));
+  // everything that could reallocate happens before the first launch: the steps then run without a host sync
+  CHK(wake_grow(c, (size_t)(n0 + 2 * count) + nfoil));
+  size_t part_bytes = 0, acc_bytes = 0;
+  for (long long k = 0; k <= count; k += std::max<long long>(1, count / 256))
+    march_workspace(c, n0 + 2 * k, precision, nfoil, part_bytes, acc_bytes);
+  march_workspace(c, n0 + 2 * count, precision, nfoil, part_bytes, acc_bytes);
+  CHK(ensure(c, c->part, part_bytes + (1 << 20)));
+  if (acc_bytes) CHK(ensure(c, c->acc, acc_bytes + (1 << 20)));
+  CHK(ensure(c, c->march_rows, (size_t)count * row_doubles * 8));
+
+  MarchState hs{};
+  hs.n = n0;
+  hs.itev = (long long)state[1];
+  hs.ilev = (long long)state[2];
+  hs.shed = state[3] != 0.0;
+  hs.tail = 0;
+  hs.lesp_crit = state[4]; hs.sum_tev = state[5]; hs.sum_lev = state[6];
+  for (int k = 0; k < 4; ++k) hs.place[k] = state[7 + k];
+  for (int k = 0; k < m.ncoef; ++k) hs.prevA[k] = state[16 + k];
+  MarchState* S = static_cast<MarchState*>(c->march_state.p);
+  HIPCHK(c, hipMemcpyAsync(S, &hs, sizeof(MarchState), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // hs lives on this stack frame
+  *c->progress = ((unsigned long long)(first_step - 1) << 32) | (unsigned long long)n0;
+
+  // chord sums of the first step, with the placements the caller supplied (tail == 0)
+  CHK(march_chord_launch(c, first_step, n0));
+
+  double* drows = static_cast<double*>(c->march_rows.p);
+  const double* kin = static_cast<const double*>(c->march_kin.p);
+  bool ev_used[2] = {false, false};
+  constexpr long long kSyncEvery = 64;
+  long long p_step = first_step - 1, p_n = n0;
+  for (long long s = first_step; s < first_step + count; ++s) {
+    const long long rel = s - first_step;
+    if (rel % kSyncEvery == 0) {
+      // stay at most 2 * kSyncEvery steps ahead of the device, so that the upper bound on the wake size that
+      // sizes the launches stays within a few hundred vortices of the real one
+      const int slot = (int)((rel / kSyncEvery) & 1);
+      if (ev_used[slot]) HIPCHK(c, hipEventSynchronize(c->march_ev[slot]));
+      const unsigned long long w = __atomic_load_n(c->progress, __ATOMIC_RELAXED);
+      p_step = (long long)(w >> 32);
+      p_n = (long long)(w & 0xffffffffULL);
+      HIPCHK(c, hipEventRecord(c->march_ev[slot], c->stream));
+      ev_used[slot] = true;
+    }
+    // Upper bound of the wake size after this step's solve; it sizes the launches and, for the direct kernels,
+    // fixes how the sources are split -- i.e. the summation order.  n_det depends on the call's arguments only,
+    // so runs repeat bit for bit wherever the direct kernels do; the tighter bound from the progress word
+    // depends on how far the host runs ahead and is used only once the symmetric kernel (float atomics, not
+    // bitwise anyway) has taken over.
+    const long long n_det = n0 + 2 * (rel + 1);
+    long long n_ub = n_det;
+    if (precision != LUDVM_PREC_F64 && use_symmetric(c, n_det)) {
+      const long long thr = c->sym_mode == 1 ? kSymMinN : (long long)c->sym_mode;
+      n_ub = std::max<long long>(std::min<long long>(p_n + 2 * (s - p_step), n_det), thr);
+    }
+    hipLaunchKernelGGL(march_solve, dim3(1), dim3(kBlock), 0, c->stream, m, S, kin + (size_t)s * (7 + 2 * P),
+                       drows + (size_t)rel * row_doubles, s, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32,
+                       c->progress_dev);
+    HIPCHK(c, hipGetLastError());
+    CHK(advect_launch(c, (size_t)n_ub, &S->n, m.dt, nfoil, c->march_vcore, precision, nullptr, nullptr));
+    if ((size_t)(s + 1) < c->march_kin_rows) CHK(march_chord_launch(c, s + 1, n_ub));
+  }
+  // results: per-step rows, final state, the two newest wake vortices
+  HIPCHK(c, hipMemcpyAsync(rows, drows, (size_t)count * row_doubles * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&hs, S, sizeof(MarchState), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (hs.n < n0 + count || hs.n > n0 + 2 * count) return fail(c, LUDVM_E_STATE, "march: inconsistent wake size on the device");
+  c->wake_n = (size_t)hs.n;
+  state[0] = (double)hs.n; state[1] = (double)hs.itev; state[2] = (double)hs.ilev; state[3] = (double)hs.shed;
+  state[4] = hs.lesp_crit; state[5] = hs.sum_tev; state[6] = hs.sum_lev;
+  for (int k = 0; k < 4; ++k) state[7 + k] = hs.place[k];
+  state[11] = (double)hs.tail;
+  double tailbuf[4] = {0, 0, 0, 0};
+  const size_t nn = (size_t)hs.n;
+  if (nn >= 2) {
+    HIPCHK(c, hipMemcpy(tailbuf, c->x64 + nn - 2, 16, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(tailbuf + 2, c->z64 + nn - 2, 16, hipMemcpyDeviceToHost));
+  }
+  for (int k = 0; k < 4; ++k) state[12 + k] = tailbuf[k];
+  for (int k = 0; k < m.ncoef; ++k) state[16 + k] = hs.prevA[k];
+  if (c->timing) CHK(drain_timing(c));
   return LUDVM_OK;
 }
 

@@ -53,7 +53,23 @@ struct PairArgs {
   long long nt_pad;
   long long chunk;            // sources per split (a multiple of the LDS tile)
   double vc4;                 // v_core^4 (0 when inviscid)
+  // Device-resident time march: the wake size is decided on the device (LEV shedding), so a launch may take
+  // it from memory: ns += *n_dev when ns_dev, nt += *n_dev when nt_dev.  The grid, `chunk` and `nt_pad` come
+  // from the host's upper bound; surplus blocks find nothing to do.
+  const long long* n_dev;
+  int ns_dev, nt_dev;
 };
+
+struct PairSizes { long long ns, nt; };
+__device__ __forceinline__ PairSizes pair_sizes(const PairArgs& a) {
+  PairSizes r{a.ns, a.nt};
+  if (a.n_dev) {
+    const long long nd = *a.n_dev;
+    if (a.ns_dev) r.ns += nd;
+    if (a.nt_dev) r.nt += nd;
+  }
+  return r;
+}
 
 __device__ __forceinline__ void grid_point(const PairArgs& a, long long p, double& x, double& z) {
   const long long i = p / a.grid_nz;
@@ -88,19 +104,23 @@ pair_f32(PairArgs a) {
   const float* __restrict__ gs = static_cast<const float*>(a.gs);
 
   const int tid = threadIdx.x;
+  const PairSizes sz = pair_sizes(a);
+  // a launch sized from an upper bound of the target count (march): blocks without targets leave at once
+  // (uniform over the block, before any barrier)
+  if ((long long)blockIdx.x * kBlock * TPL >= sz.nt) return;
   // targets of this lane: tid, tid+256, ... of the block's slab; or TPL consecutive points (GRIDROW)
   const long long t0 = GRIDROW ? ((long long)blockIdx.x * kBlock + tid) * TPL : ((long long)blockIdx.x * kBlock) * TPL + tid;
   constexpr long long kTStride = GRIDROW ? 1 : kBlock;
   const long long s_begin = (long long)blockIdx.y * a.chunk;
   long long s_end = s_begin + a.chunk;
-  if (s_end > a.ns) s_end = a.ns;
+  if (s_end > sz.ns) s_end = sz.ns;
 
   f32x2 xp[TPL], zp[TPL], xpl[TPL], zpl[TPL], au[TPL], aw[TPL];
 #pragma unroll
   for (int t = 0; t < TPL; ++t) {
     const long long ti = t0 + (long long)t * kTStride;
     float x = 0.0f, z = 0.0f, xl = 0.0f, zl = 0.0f;
-    if (ti < a.nt) {
+    if (ti < sz.nt) {
       if (a.grid_nz > 0) {
         double xd, zd;
         grid_point(a, ti, xd, zd);
@@ -208,7 +228,7 @@ pair_f32(PairArgs a) {
 #pragma unroll
   for (int t = 0; t < TPL; ++t) {
     const long long ti = t0 + (long long)t * kTStride;
-    if (ti < a.nt) {
+    if (ti < sz.nt) {
       const float uu = (au[t].x + au[t].y) * scale;
       const float ww = -(aw[t].x + aw[t].y) * scale;
       if (gridDim.y == 1) {
@@ -255,13 +275,15 @@ pair_f64(PairArgs a) {
   const double* __restrict__ gs = static_cast<const double*>(a.gs);
 
   const int tid = threadIdx.x;
+  const PairSizes sz = pair_sizes(a);
+  if ((long long)blockIdx.x * kBlock >= sz.nt) return;   // no targets in this block (launch sized from a bound)
   const long long ti = (long long)blockIdx.x * kBlock + tid;
   const long long s_begin = (long long)blockIdx.y * a.chunk;
   long long s_end = s_begin + a.chunk;
-  if (s_end > a.ns) s_end = a.ns;
+  if (s_end > sz.ns) s_end = sz.ns;
 
   double xp = 0.0, zp = 0.0;
-  if (ti < a.nt) {
+  if (ti < sz.nt) {
     if (a.grid_nz > 0) {
       grid_point(a, ti, xp, zp);
     } else {
@@ -298,7 +320,7 @@ pair_f64(PairArgs a) {
     }
   }
 
-  if (ti < a.nt) {
+  if (ti < sz.nt) {
     const double uu = au * kInv2PiD;
     const double ww = -aw * kInv2PiD;
     if (gridDim.y == 1) {
@@ -373,8 +395,10 @@ __device__ __forceinline__ void split_hilo(double v, float& hi, float& lo) {
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 finish_wake_advect(const T* part, long long nt, long long nt_pad, int nsplit, double dt, double* x64, double* z64,
-                   float* xh, float* xl, float* zh, float* zl, double* u_out, double* w_out) {
+                   float* xh, float* xl, float* zh, float* zl, double* u_out, double* w_out,
+                   const long long* n_dev = nullptr) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (n_dev) nt = *n_dev;          // device-resident march: the wake size lives on the device
   if (i >= nt) return;
   T su, sw;
   sum_splits(part, i, nt_pad, nsplit, su, sw);

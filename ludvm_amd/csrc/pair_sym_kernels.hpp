@@ -38,6 +38,9 @@ struct SymArgs {
   int ysplit;            // number of d-chunks (gridDim.x = ceil(i_count*ysplit / 4))
   float* acc_u; float* acc_w;  // raw sums: u = acc_u/(2 pi), w = -acc_w/(2 pi)
   float vc4;
+  // Device-resident march (single GPU, all tiles): n is read from memory and ntiles / dmax / i_count follow
+  // from it; the grid and ysplit come from the host's upper bound, surplus waves leave at once.
+  const long long* n_dev;
 };
 
 // lane l receives the value of lane l+1 (wrapping): data moves one lane down
@@ -76,6 +79,12 @@ template <int T, bool HILO = false>
 __global__ void __launch_bounds__(kBlock)
 pair_sym_f32(SymArgs a) {
   static_assert(T == 4 || T == 8, "T vortices per lane, read as T/4 ds_read_b128 per component");
+  if (a.n_dev) {
+    a.n = *a.n_dev;
+    a.ntiles = (a.n + 64LL * T - 1) / (64LL * T);
+    a.dmax = (a.ntiles - 1) / 2;
+    a.i_count = a.ntiles;
+  }
   constexpr int H = T / 2;
   constexpr int kWaves = kBlock / 64;
   constexpr int kComp = HILO ? 5 : 3;
@@ -252,9 +261,10 @@ template <bool HILO>
 __global__ void __launch_bounds__(kBlock)
 finish_wake_advect_sym(const float* acc_u, const float* acc_w, long long nt, int nfoil, float vc4, double dt, double* x64,
                        double* z64, float* xh, float* xl, float* zh, float* zl, const float* g32, double* u_out,
-                       double* w_out) {
+                       double* w_out, const long long* n_dev = nullptr) {
   __shared__ float fx[kBlock], fz[kBlock], fg[kBlock], fxl[HILO ? kBlock : 1], fzl[HILO ? kBlock : 1];
   const int tid = threadIdx.x;
+  if (n_dev) nt = *n_dev;          // device-resident march: the wake size lives on the device
   if (tid < nfoil) {
     fx[tid] = xh[nt + tid]; fz[tid] = zh[nt + tid]; fg[tid] = g32[nt + tid];
     if (HILO) { fxl[tid] = xl[nt + tid]; fzl[tid] = zl[nt + tid]; }

@@ -246,6 +246,33 @@ class Engine:
                                                 float(v_core), _prec(precision), _pd(u), _pd(w)))
         return (u, w) if return_velocity else None
 
+    # -- device-resident time march ----------------------------------------------------------------
+    MARCH_ROW_HEAD = 10
+    MARCH_STATE_HEAD = 16
+
+    def march_setup(self, npan, ncoef, scalars, tables, kin):
+        """Upload what a run keeps constant (ludvm_march_setup): scalars [Uinf, chord, rho, dt, piv, v_core, IC,
+        sum(Gamma_free)], the packed chord tables and the per-step kinematics rows [nt, 7 + 2 npan]."""
+        sc, tb = _f64(scalars), _f64(tables)
+        kin = np.ascontiguousarray(kin, dtype=np.float64)
+        if kin.ndim != 2 or kin.shape[1] != 7 + 2 * npan or len(sc) != 8:
+            raise ValueError("march_setup: kin must be [nt, 7 + 2 npan] and scalars 8 long")
+        if len(tb) != 8 * npan + ncoef * npan + (ncoef - 1) * npan:
+            raise ValueError("march_setup: wrong table length")
+        self._check(self._lib.ludvm_march_setup(self._ctx, int(npan), int(ncoef), _pd(sc), _pd(tb), _pd(kin), kin.shape[0]))
+        self._march_dims = (int(npan), int(ncoef))
+
+    def march_run(self, first_step, count, precision, state):
+        """Advance the resident wake through time steps [first_step, first_step + count) without a host round
+        trip per step (ludvm_march_run).  `state` (16 + ncoef float64) is updated in place; returns the
+        per-step rows [count, 10 + 2 ncoef + 2 npan]."""
+        npan, ncoef = self._march_dims
+        if state.dtype != np.float64 or not state.flags.c_contiguous or len(state) != self.MARCH_STATE_HEAD + ncoef:
+            raise ValueError("march_run: state must be contiguous float64 of length 16 + ncoef")
+        rows = np.empty([int(count), self.MARCH_ROW_HEAD + 2 * ncoef + 2 * npan])
+        self._check(self._lib.ludvm_march_run(self._ctx, int(first_step), int(count), _prec(precision), _pd(state), _pd(rows)))
+        return rows
+
     # -- flow field ------------------------------------------------------------------------------
     def flowfield(self, xmin, zmin, dr, nx, nz, circulation, xw, zw, v_core):
         """(u, w) float32 [nx, nz] on the grid (xmin + i*dr, zmin + j*dr) (LUDVM.py:1193-1195)."""

@@ -84,6 +84,9 @@ class LUDVM:
       run        False builds geometry and kinematics only
       checkpoint_every, checkpoint_path   write an .npz checkpoint every so many steps (0 = never);
                  `LUDVM.resume(path)` continues such a run (the reference has no checkpointing)
+      march      True (default): stretches of time steps whose history row is not recorded run as a
+                 device-resident march (Gamma solve on the GPU, no host round trip per step; 'Faure' method);
+                 False: one device round trip per step throughout
     """
 
     def __init__(self, t0=0, tf=12, dt=1.5e-2, chord=1, rho=1.225, Uinf=1,
@@ -93,7 +96,7 @@ class LUDVM:
                  verbose=True, method='Faure',
                  circulation_freevort=None, xy_freevort=None, *,
                  engine=None, device=0, precision='f32', history='auto', snapshot_steps=(), run=True,
-                 checkpoint_every=0, checkpoint_path=None):
+                 checkpoint_every=0, checkpoint_path=None, march=True):
         self._ctor = dict(t0=t0, tf=tf, dt=dt, chord=chord, rho=rho, Uinf=Uinf, Npoints=Npoints, Ncoeffs=Ncoeffs,
                           LESPcrit=LESPcrit, Naca=Naca, foil_filename=foil_filename, G=G, T=T, alpha_m=alpha_m,
                           alpha_max=alpha_max, k=k, phi=phi, h_max=h_max, method=method, precision=precision,
@@ -132,6 +135,7 @@ class LUDVM:
         self.history = ('full' if self.nt <= _FULL_HISTORY_MAX_NT else 'sparse') if history == 'auto' else history
         self.snapshot_steps = {int(s) for s in snapshot_steps}
         self.checkpoint_every, self.checkpoint_path = int(checkpoint_every), checkpoint_path
+        self.march = bool(march)
         if self.checkpoint_every and not checkpoint_path:
             raise ValueError("checkpoint_every needs a checkpoint_path")
         self.engine = engine if engine is not None else Engine(device)  # raises without the HIP library / GPU
@@ -413,7 +417,85 @@ class LUDVM:
         vc_f, dt_f = float(vc), float(dt)
         have_next = False     # sb already holds step i's placement and chord sums (from the previous wake_step)
 
-        for i in range(first_step, nt):
+        # Device-resident march (ludvm_march_setup / ludvm_march_run): stretches of steps whose history row is
+        # not recorded run without a host round trip per step; the per-step path below serves recorded steps,
+        # the 'Ramesh' method and engines without the march.
+        can_march = (self.march and self.method == 'Faure' and hasattr(eng, 'march_run') and npan <= 256
+                     and 4 <= self.Ncoeffs <= 64)
+        if can_march:
+            tables = np.concatenate([detadx, self.airfoil['eta_panel'], x_gamma, cm1, wq, one_plus_cos_over_sin,
+                                     half_c_sin_dth, wx, cproj.ravel(), ssin.ravel()])
+            kin = np.concatenate([self.alpha[:, None], self.alpha_dot[:, None], self.h_dot[:, None], foil[:, :, -1],
+                                  foil[:, :, 0], gpts[:, 0, :], gpts[:, 1, :]], axis=1)
+            eng.march_setup(npan, self.Ncoeffs, [U, c, rho, dt, self.piv, vc, C['IC'], sum_free], tables, kin)
+        nc = self.Ncoeffs
+        march_chunk = int(getattr(self, '_march_chunk', 32768))   # steps per ludvm_march_run call (bounds the returned rows)
+
+        i = first_step
+        while i < nt:
+            if can_march and not self._record_row(i):
+                j = i
+                while j < nt and not self._record_row(j) and j - i < march_chunk:
+                    j += 1
+                    if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
+                        break
+                if j - i >= 2:
+                    n_wake = nf + itev + ilev
+                    if have_next:
+                        place = [sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1]]
+                    else:
+                        te, le = foil[i, :, -1], foil[i, :, 0]
+                        tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
+                        lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
+                        place = [tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]]
+                    st = np.zeros(16 + nc)
+                    st[:11] = [n_wake, itev, ilev, float(LEV_shed[i - 1] != -1), lesp_crit, sum_tev, sum_lev] + place
+                    st[16:] = self.fourier[i - 1, 0, :]
+                    R = eng.march_run(i, j - i, prec_code, st)
+                    cnt = j - i
+                    steps = np.arange(i, j)
+                    tix = itev + np.arange(cnt)
+                    shed_v = R[:, 2] != 0
+                    slot = R[:, 9].astype(np.int64)
+                    C['TEV'][tix] = R[:, 0]
+                    C['bound'][tix] = R[:, 3]
+                    self.LESP_prev[tix], self.LESP[tix] = R[:, 4], R[:, 5]
+                    self.Fn[steps], self.Fs[steps], self.M[steps] = R[:, 6], R[:, 7], R[:, 8]
+                    ca_, sa_ = np.cos(self.alpha[steps]), np.sin(self.alpha[steps])
+                    self.L[steps] = self.Fn[steps] * ca_ + self.Fs[steps] * sa_
+                    self.D[steps] = self.Fn[steps] * sa_ - self.Fs[steps] * ca_
+                    self.T[steps] = -self.D[steps]
+                    tev_slot[tix] = slot
+                    lix = ilev + np.cumsum(shed_v)[shed_v] - 1
+                    C['LEV'][lix] = R[shed_v, 1]
+                    lev_slot[lix] = slot[shed_v] + 1
+                    LEV_shed[steps[shed_v]] = lix
+                    self.fourier[steps, 0, :] = R[:, 10:10 + nc]
+                    self.fourier[steps, 1, :] = R[:, 10 + nc:10 + 2 * nc]
+                    C['gamma_airfoil'][tix] = R[:, 10 + 2 * nc:10 + 2 * nc + npan]
+                    C['airfoil'][tix] = R[:, 10 + 2 * nc + npan:]
+                    C['Gamma_airfoil'][tix] = np.cumsum(C['airfoil'][tix], axis=1)
+                    last_shed = bool(shed_v[-1])
+                    if int(st[1]) != itev + cnt or int(st[0]) != n_wake + cnt + int(shed_v.sum()):
+                        raise RuntimeError("device march returned an inconsistent state")
+                    self.itev, self.ilev, self.LEV_shed = itev + cnt - 1, ilev + int(shed_v.sum()) - int(last_shed), LEV_shed
+                    itev, ilev = itev + cnt, ilev + int(shed_v.sum())
+                    lesp_crit, sum_tev, sum_lev = float(st[4]), float(st[5]), float(st[6])
+                    if last_shed:
+                        last_tev, last_lev = np.array([st[12], st[14]]), np.array([st[13], st[15]])
+                    else:
+                        last_tev = np.array([st[13], st[15]])
+                    have_next = False
+                    if self.verbose == True:  # noqa: E712
+                        for q in steps:
+                            if q == 1 or q == nt - 1 or q / print_dt == int(q / print_dt):
+                                print('Step {} out of {}. Elapsed time {}'.format(q, nt - 1,
+                                                                                   timeit.default_timer() - self.start_time))
+                    if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0 and j - 1 < nt - 1:
+                        self._write_checkpoint(j, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
+                                               tev_slot, lev_slot)
+                    i = j
+                    continue
             if (i == 1 or i == nt - 1 or i / print_dt == int(i / print_dt)) and self.verbose == True:  # noqa: E712
                 print('Step {} out of {}. Elapsed time {}'.format(i, nt - 1, timeit.default_timer() - self.start_time))
             xg, zg = gpts[i, 0, :], gpts[i, 1, :]
@@ -584,6 +666,7 @@ class LUDVM:
             if self.checkpoint_every and i % self.checkpoint_every == 0 and i < nt - 1:
                 self._write_checkpoint(i + 1, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
                                        tev_slot, lev_slot)
+            i += 1
         return None
 
     # ------------------------------------------------------------------------------------------

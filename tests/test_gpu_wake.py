@@ -327,3 +327,129 @@ def test_config2_regime_first_300_steps(eng):
             assert np.abs(getattr(sim, name) - getattr(ref, name)).max() <= tol_load * max(1.0, np.abs(getattr(ref, name)).max()), (prec, name)
         assert np.abs(sim.path["TEV"][-1] - ref.path["TEV"][-1]).max() <= tol_pos, prec
         assert np.abs(sim.circulation["TEV"] - ref.circulation["TEV"]).max() <= tol_load, prec
+
+
+# ---- device-resident march (ludvm_march_setup / ludvm_march_run) -------------------------------------------
+
+MARCH_KW = dict(history="sparse", snapshot_steps=[1, 2, 10, 50])
+
+
+def test_march_config1_fp64_against_golden(eng, g2):
+    """The README case with the Gamma solve on the device (sparse history, so the stretches between the
+    recorded steps 1, 2, 10, 50 and 400 run as marches): same bounds against the reference's golden run as
+    the per-step path (test_time_loop_config1_fp64_mode_tier_T3)."""
+    from ludvm_amd import LUDVM
+    sim = LUDVM(**CONFIG1, verbose=False, engine=eng, precision="f64", **MARCH_KW)
+    assert (sim.nt, sim.itev, sim.ilev) == (401, 399, 202)
+    assert np.array_equal(sim.LEV_shed, g2["LEV_shed"])
+    for name in ("Cl", "Cd", "Cm"):
+        d = np.abs(getattr(sim, name) - g2[name])
+        assert d[:100].max() <= 1e-9 and d[:200].max() <= 1e-7 and d.max() <= 1e-3, name
+        assert abs(getattr(sim, name)[200:].mean() - g2[name][200:].mean()) <= 1e-4, name
+    np.testing.assert_allclose(sim.circulation["TEV"][:200], g2["circ_TEV"][:200], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(sim.fourier[:200], g2["fourier"][:200], rtol=0, atol=1e-6)
+    for s in (1, 2, 10, 50):
+        for key in ("TEV", "LEV", "FREE"):
+            row, gold = sim.path[key][s], g2[f"{key}_{s}"]      # sparse rows are compact, the reference's zero-padded
+            k = row.shape[1]
+            np.testing.assert_allclose(row, gold[:, :k], rtol=0, atol=1e-9, err_msg=f"{key}@{s}")
+            assert not gold[:, k:].any(), f"{key}@{s}"
+    c = sim.circulation
+    assert abs(c["bound"][399] + c["TEV"].sum() + c["LEV"].sum() - c["IC"]) < 1e-9      # Kelvin
+    assert np.abs(sim.LESP).max() <= 0.2 + 1e-9
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-10), ("f32", 1e-9), ("f32x2", 1e-9)])
+def test_march_fills_every_result_like_the_per_step_path(eng, precision, tol):
+    """Same run with march=True and march=False: every result attribute the per-step path fills is filled
+    alike (first 100 steps to rounding; the chaotic growth afterwards is the flow's, see T3)."""
+    from ludvm_amd import LUDVM
+    kw = dict(CONFIG1, tf=8)
+    a = LUDVM(**kw, verbose=False, engine=eng, precision=precision, history="sparse", march=True)
+    b = LUDVM(**kw, verbose=False, engine=eng, precision=precision, history="sparse", march=False)
+    assert np.array_equal(a.LEV_shed, b.LEV_shed)
+    assert (a.itev, a.ilev) == (b.itev, b.ilev)
+    n = 100
+    for name in ("Cl", "Cd", "Cm", "Cn", "Cs", "Ct", "L", "D", "T", "M", "Fn", "Fs", "LESP", "LESP_prev"):
+        assert np.abs(getattr(a, name)[:n] - getattr(b, name)[:n]).max() <= tol, name
+    assert np.abs(a.fourier[:n] - b.fourier[:n]).max() <= 100 * tol           # d/dt rows divide by dt
+    for key in ("TEV", "LEV", "bound", "airfoil", "gamma_airfoil", "Gamma_airfoil"):
+        assert np.abs(a.circulation[key][:n] - b.circulation[key][:n]).max() <= 10 * tol, key
+        assert np.any(a.circulation[key] != 0), key
+    assert a.circulation["IC"] == b.circulation["IC"]
+    assert np.abs(a.path["TEV"][a.nt - 1][:, :n] - b.path["TEV"][b.nt - 1][:, :n]).max() <= 1e-3
+    assert a.path["TEV"][a.nt - 1].shape == b.path["TEV"][b.nt - 1].shape
+    assert a.path["LEV"][a.nt - 1].shape == b.path["LEV"][b.nt - 1].shape
+
+
+def test_march_repeats_bit_for_bit_in_the_direct_regime(eng):
+    """Wakes below the symmetric threshold use the direct kernels, whose summation order the march fixes from
+    the call's arguments alone (not from how far the host runs ahead of the device): two runs agree to the
+    last bit, as the per-step path does."""
+    from ludvm_amd import LUDVM
+    kw = dict(CONFIG1, tf=10)
+    a = LUDVM(**kw, verbose=False, engine=eng, precision="f32", history="sparse")
+    b = LUDVM(**kw, verbose=False, engine=eng, precision="f32", history="sparse")
+    for name in ("Cl", "Cd", "Cm", "LESP"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.array_equal(a.path["TEV"][a.nt - 1], b.path["TEV"][b.nt - 1])
+    assert np.array_equal(a.circulation["TEV"], b.circulation["TEV"])
+
+
+def test_march_in_several_calls_continues_the_state(eng):
+    """A stretch cut into several ludvm_march_run calls (state handed from one to the next) against one call."""
+    from ludvm_amd import LUDVM
+    kw = dict(CONFIG1, tf=8)
+    one = LUDVM(**kw, verbose=False, engine=eng, precision="f64", history="sparse")
+    cut = LUDVM(**kw, verbose=False, engine=eng, precision="f64", history="sparse", run=False)
+    cut._march_chunk = 37
+    cut.time_loop()
+    cut.compute_coefficients()
+    assert np.array_equal(one.LEV_shed, cut.LEV_shed)
+    for name in ("Cl", "Cd", "Cm"):
+        assert np.abs(getattr(one, name)[:100] - getattr(cut, name)[:100]).max() <= 1e-10, name
+    assert np.abs(one.circulation["TEV"][:100] - cut.circulation["TEV"][:100]).max() <= 1e-10
+    assert (one.itev, one.ilev) == (cut.itev, cut.ilev)
+
+
+def test_march_checkpoint_and_resume(eng, tmp_path):
+    """Checkpoints cut the marches at their steps; a resumed run continues with a march of its own."""
+    from ludvm_amd import LUDVM
+    ck = str(tmp_path / "ck_march.npz")
+    kw = dict(CONFIG1, tf=6)
+    a = LUDVM(**kw, verbose=False, engine=eng, precision="f64", history="sparse")
+    LUDVM(**kw, verbose=False, engine=eng, precision="f64", history="sparse", checkpoint_every=50, checkpoint_path=ck)
+    c = LUDVM.resume(ck, engine=eng, verbose=False)
+    assert c.history == "sparse" and np.array_equal(a.LEV_shed, c.LEV_shed)
+    for name in ("Cl", "Cd", "Cm", "LESP"):
+        assert np.abs(getattr(a, name) - getattr(c, name))[:100].max() <= 1e-10, name
+        assert np.abs(getattr(a, name) - getattr(c, name)).max() <= 1e-6, name
+    assert a.path["TEV"][a.nt - 1].shape == c.path["TEV"][c.nt - 1].shape
+
+
+def test_march_config2_regime_against_the_oracle(eng):
+    """BASELINE config 2's parameters (dt = 1e-3) over the first 300 steps, marched, against the oracle."""
+    from ludvm_amd import LUDVM
+    kw = dict(CONFIG1, dt=1e-3, tf=0.3)
+    ref = O.OracleLUDVM(**kw)
+    for prec, tol_load, tol_pos in (("f64", 1e-9, 1e-11), ("f32x2", 1e-5, 1e-6), ("f32", 1e-3, 1e-4)):
+        sim = LUDVM(**kw, verbose=False, engine=eng, precision=prec, history="sparse")
+        assert np.array_equal(sim.LEV_shed, ref.LEV_shed), prec
+        for name in ("Cl", "Cd", "Cm"):
+            assert np.abs(getattr(sim, name) - getattr(ref, name)).max() <= tol_load * max(1.0, np.abs(getattr(ref, name)).max()), (prec, name)
+        assert np.abs(sim.path["TEV"][sim.nt - 1] - ref.path["TEV"][-1]).max() <= tol_pos, prec
+        assert np.abs(sim.circulation["TEV"] - ref.circulation["TEV"]).max() <= tol_load, prec
+
+
+def test_march_rejects_bad_calls(eng):
+    from ludvm_amd import LudvmHipError
+    st = np.zeros(16 + 30)
+    eng.wake_clear()
+    with pytest.raises(LudvmHipError):       # setup with too few Fourier coefficients
+        eng.march_setup(80, 3, np.ones(8), np.zeros(8 * 80 + 3 * 80 + 2 * 80), np.zeros([10, 7 + 160]))
+    eng.march_setup(80, 30, np.ones(8), np.zeros(8 * 80 + 30 * 80 + 29 * 80), np.zeros([10, 7 + 160]))
+    with pytest.raises(LudvmHipError):       # steps outside the kinematics table
+        eng.march_run(5, 6, "f32", st)
+    st[0] = 3                                # not the current wake size
+    with pytest.raises(LudvmHipError):
+        eng.march_run(1, 2, "f32", st)

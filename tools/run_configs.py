@@ -69,7 +69,7 @@ def cfg2(args):
     t0 = time.perf_counter()
     sim = LUDVM(t0=0, tf=args.tf, dt=1e-3, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2,
                 Naca="0012", verbose=args.verbose, engine=eng, precision=args.precision, history="sparse",
-                snapshot_steps=[])
+                snapshot_steps=[], march=not args.no_march)
     el = time.perf_counter() - t0
     kms, nl = eng.kernel_time_ms(True)
     ntev, nlev = sim.itev + 1, sim.ilev + (1 if sim.LEV_shed[-1] != -1 else 0)
@@ -77,6 +77,7 @@ def cfg2(args):
     sizes = 1 + np.arange(1, sim.nt) + np.cumsum(sim.LEV_shed[1:] != -1)
     pairs = float(np.sum((sizes + 80.0) * sizes))
     print(json.dumps({"config": f"cfg2 time_loop dt=1e-3 tf={args.tf} precision={args.precision}", "steps": sim.nt - 1,
+                      "path": "per-step round trips" if args.no_march else "device-resident march",
                       "wall_s": el, "final_wake": int(sizes[-1]), "tev": int(ntev), "lev": int(nlev),
                       "rollup_pairs": pairs, "pairs_per_s_wall": pairs / el, "kernel_launches": nl,
                       "kernel_ms_total": kms * nl, "Cl_last": float(sim.Cl[-1]), "Cl_mean_last_period": float(np.mean(sim.Cl[-10000:])),
@@ -93,5 +94,6 @@ if __name__ == "__main__":
     ap.add_argument("--tf", type=float, default=50.0)
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--no-march", action="store_true", help="cfg2: one device round trip per time step")
     a = ap.parse_args()
     {"cfg5": cfg5, "cfg2": cfg2}[a.which](a)
