@@ -79,6 +79,10 @@ int ludvm_set_tuning(ludvm_ctx* ctx, int targets_per_lane, int source_splits);
  * mode 0 = never (direct kernel, bitwise reproducible), 1 = automatic (default; fp32, N >= 16384),
  * mode >= 2 = automatic with that value as the smallest N that takes the symmetric kernel. */
 int ludvm_set_symmetric(ludvm_ctx* ctx, int mode);
+/* Tuning of the symmetric kernel (tools and tests; 0 = the library's heuristics): vortices per lane (4: 256-vortex
+ * tiles, 8: 512-vortex tiles; plain fp32 positions only) and the number of wavefronts (1, 2, 4) that share the 64
+ * rotation steps of one tile pair.  Results change only in the order of the float atomics. */
+int ludvm_set_sym_tuning(ludvm_ctx* ctx, int vortices_per_lane, int rotation_split);
 
 /* ---- stateless pair sum: backs LUDVM.induced_velocity (LUDVM.py:549-570) ------------------ */
 

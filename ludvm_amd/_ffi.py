@@ -31,6 +31,7 @@ SIGNATURES = {
     "ludvm_synchronize": [c_void_p],
     "ludvm_set_tuning": [c_void_p, c_int, c_int],
     "ludvm_set_symmetric": [c_void_p, c_int],
+    "ludvm_set_sym_tuning": [c_void_p, c_int, c_int],
     "ludvm_induce_f64": [c_void_p, _pd, _pd, _pd, c_size_t, _pd, _pd, c_size_t, c_double, c_int, _pd, _pd],
     "ludvm_induce_f32": [c_void_p, _pf, _pf, _pf, c_size_t, _pf, _pf, c_size_t, c_float, _pf, _pf],
     "ludvm_induce_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,

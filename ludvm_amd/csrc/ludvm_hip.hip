@@ -40,6 +40,7 @@ struct ludvm_ctx {
   int tune_tpl = 0;
   int tune_split = 0;
   int sym_mode = 1;
+  int tune_sym_t = 0, tune_sym_rsplit = 0;   // ludvm_set_sym_tuning (0 = heuristics)
 
   Buf part;   // partial slabs of the split reduction
   Buf acc;    // raw (u, w) sums of the symmetric kernel: [2][nt_pad] floats
@@ -313,13 +314,16 @@ int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, i
 }
 
 constexpr long long kSymMinN = 16384;   // below this the direct kernel's launch is as fast
-// Vortices per lane of the symmetric kernel: 8 (tile 512, 2 waves/SIMD) from ~1e5 vortices up, where halving
-// the rotation / LDS-read cost per pair wins 5-7 %; 4 (tile 256, 5 waves/SIMD) below, where more and smaller
-// tiles balance better, and for hi+lo positions (8 would not fit the register file).
-constexpr long long kSymT8MinN = 98304;
+// Vortices per lane of the symmetric kernel: 8 (tile 512, 2 waves/SIMD) from ~4e4 vortices up, where halving
+// the rotation / LDS-read cost per pair wins 2-7 % (with the rotation steps of a tile pair shared by two waves
+// below ~8e4); 4 (tile 256, 5 waves/SIMD) below, where more and smaller tiles balance better, and for hi+lo
+// positions (8 would not fit the register file).
+constexpr long long kSymT8MinN = 40960;
 static_assert(64 * 8 == LUDVM_SYM_TILE, "the multi-GPU entry points always use the 512-vortex tile");
 constexpr long long kSymTargetWaves = 65536;
 constexpr long long kSymMaxSplit = 64;
+constexpr long long kSymMaxRsplit = 4;
+constexpr long long kSymMinItems = 9000;    // measured (profiles/r01_sym_kernel_rotation_split.txt)
 
 bool use_symmetric(const ludvm_ctx* c, long long n) {
   if (c->sym_mode == 0) return false;
@@ -346,10 +350,18 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const float* x, const float* z, const 
   long long ys = c->tune_split > 0 ? c->tune_split : (kSymTargetWaves + i_count - 1) / i_count;
   ys = std::max<long long>(1, std::min<long long>(std::min<long long>(ys, kSymMaxSplit), std::max<long long>(dtot, 1)));
   a.ysplit = (int)ys;
+  // too few (I, d-chunk) items to keep every SIMD busy to the end: share each tile pair's rotation steps
+  long long rs = 1;
+  if (c->tune_sym_rsplit == 1 || c->tune_sym_rsplit == 2 || c->tune_sym_rsplit == 4) {
+    rs = c->tune_sym_rsplit;
+  } else {
+    while (rs < kSymMaxRsplit && i_count * ys * rs < kSymMinItems) rs *= 2;
+  }
+  a.rsplit = (int)rs;
   a.acc_u = acc_u;
   a.acc_w = acc_w;
   a.vc4 = (float)vc4;
-  const long long waves = i_count * ys;
+  const long long waves = i_count * ys * rs;
   TimedLaunch t{};
   bool active = false;
   CHK(timed_begin(c, t, active));
@@ -373,7 +385,8 @@ int launch_sym(ludvm_ctx* c, const float* x, const float* z, const float* g, lon
   CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(float)));
   HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(float), c->stream));
   float* acc = static_cast<float*>(c->acc.p);
-  const int T = (n >= kSymT8MinN && !(xl && zl)) ? 8 : 4;
+  int T = (n >= kSymT8MinN && !(xl && zl)) ? 8 : 4;
+  if ((c->tune_sym_t == 4 || c->tune_sym_t == 8) && !(xl && zl)) T = c->tune_sym_t;
   const long long ntiles = (n + 64LL * T - 1) / (64LL * T);
   CHK(launch_sym_tiles(c, T, x, z, g, n, 0, ntiles, vc4, acc, acc + nt_pad, xl, zl, n_dev));
   *nt_pad_out = nt_pad;
@@ -516,6 +529,17 @@ int ludvm_set_tuning(ludvm_ctx* c, int targets_per_lane, int source_splits) {
   if (source_splits < 0 || source_splits > kMaxSplit) return fail(c, LUDVM_E_ARG, "source_splits out of range");
   c->tune_tpl = targets_per_lane;
   c->tune_split = source_splits;
+  return LUDVM_OK;
+}
+
+int ludvm_set_sym_tuning(ludvm_ctx* c, int vortices_per_lane, int rotation_split) {
+  if (!c) return LUDVM_E_ARG;
+  if (vortices_per_lane != 0 && vortices_per_lane != 4 && vortices_per_lane != 8)
+    return fail(c, LUDVM_E_ARG, "vortices_per_lane must be 0 (heuristic), 4 or 8");
+  if (rotation_split != 0 && rotation_split != 1 && rotation_split != 2 && rotation_split != 4)
+    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (heuristic), 1, 2 or 4");
+  c->tune_sym_t = vortices_per_lane;
+  c->tune_sym_rsplit = rotation_split;
   return LUDVM_OK;
 }
 

@@ -35,7 +35,8 @@ struct SymArgs {
   long long dmax;        // floor((ntiles-1)/2): symmetric offsets 1..dmax (+ ntiles/2 when even)
   long long i_first;     // this launch owns I tiles [i_first, i_first + i_count): one GPU's block of the
   long long i_count;     //   global tile ring (multi-GPU), or all tiles
-  int ysplit;            // number of d-chunks (gridDim.x = ceil(i_count*ysplit / 4))
+  int ysplit;            // number of d-chunks (gridDim.x = ceil(i_count*ysplit*rsplit / 4))
+  int rsplit;            // 1, 2 or 4: the 64 rotation steps of a tile pair are shared by this many waves
   float* acc_u; float* acc_w;  // raw sums: u = acc_u/(2 pi), w = -acc_w/(2 pi)
   float vc4;
   // Device-resident march (single GPU, all tiles): n is read from memory and ntiles / dmax / i_count follow
@@ -93,9 +94,16 @@ pair_sym_f32(SymArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const long long wid = (long long)blockIdx.x * kWaves + wv;
-  if (wid >= a.i_count * a.ysplit) return;   // whole waves leave together; no block-wide barrier is used
+  if (wid >= a.i_count * a.ysplit * a.rsplit) return;   // whole waves leave together; no block-wide barrier is used
   const long long I = a.i_first + wid % a.i_count;
-  const int y = (int)(wid / a.i_count);
+  const int yr = (int)(wid / a.i_count);
+  const int y = yr / a.rsplit;
+  // Mid-size launches have too few tile pairs to keep every SIMD busy to the end, so a tile pair's 64 rotation
+  // steps can be shared by rsplit waves: this one does steps [k_lo, k_hi).  A J accumulator set that starts in
+  // lane l at step k_lo belongs to home lane (l + k_lo) and, one lane per step, sits in lane (home - k_hi) after
+  // the last step -- it is added to its vortices from there (the sums are atomics anyway).
+  const int k_lo = (yr % a.rsplit) * (64 / a.rsplit);
+  const int k_hi = k_lo + 64 / a.rsplit;
   const long long W = 64LL * T;
   float* const lx = slab[wv][0];
   float* const lz = slab[wv][1];
@@ -132,7 +140,7 @@ pair_sym_f32(SymArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int k = 0; k < 64; ++k) {
+    for (int k = k_lo; k < k_hi; ++k) {
       const int pos = ((lane + k) & 63) * 4;
       f32x2 xj[H], zj[H], gj[H], xjl[H], zjl[H];
       slab_load<T>(lx, pos, xj); slab_load<T>(lz, pos, zj); slab_load<T>(lg, pos, gj);
@@ -184,7 +192,7 @@ pair_sym_f32(SymArgs a) {
 
     // (issuing the reads of step k+1 ahead of the arithmetic of step k measured no gain: with 4-5
     // waves per SIMD the LDS latency is already covered)
-    for (int k = 0; k < 64; ++k) {
+    for (int k = k_lo; k < k_hi; ++k) {
       // at step k this lane holds the accumulators of the J vortices whose home lane is (lane + k) % 64
       const int pos = ((lane + k) & 63) * 4;
       f32x2 xj[H], zj[H], gj[H], xjl[H], zjl[H];
@@ -213,11 +221,13 @@ pair_sym_f32(SymArgs a) {
 #pragma unroll
       for (int m = 0; m < H; ++m) { bu[m] = dpp_rol1(bu[m]); bw[m] = dpp_rol1(bw[m]); }
     }
-    // 64 rotations: the J accumulators are home again; j feels the opposite of what i feels.
-    // home lane l holds vortices J*W + l + 64*t as packed elements t = 0..T-1
+    // after step k_hi - 1 and its rotation this lane holds the set of home lane (lane + k_hi) % 64 (with all 64
+    // steps done: its own); j feels the opposite of what i feels.
+    // home lane h holds vortices J*W + h + 64*t as packed elements t = 0..T-1
+    const int home = (lane + k_hi) & 63;
 #pragma unroll
     for (int m = 0; m < H; ++m) {
-      const long long j0 = J * W + lane + 64LL * (2 * m), j1 = j0 + 64;
+      const long long j0 = J * W + home + 64LL * (2 * m), j1 = j0 + 64;
       if (j0 < a.n) { atomicAdd(&a.acc_u[j0], -bu[m].x); atomicAdd(&a.acc_w[j0], -bw[m].x); }
       if (j1 < a.n) { atomicAdd(&a.acc_u[j1], -bu[m].y); atomicAdd(&a.acc_w[j1], -bw[m].y); }
     }

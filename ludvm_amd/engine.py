@@ -94,6 +94,11 @@ class Engine:
     def set_tuning(self, targets_per_lane=0, source_splits=0):
         self._check(self._lib.ludvm_set_tuning(self._ctx, int(targets_per_lane), int(source_splits)))
 
+    def set_sym_tuning(self, vortices_per_lane=0, rotation_split=0):
+        """Tuning of the symmetric kernel (0 = heuristics): tile = 64 * vortices_per_lane (4 or 8), wavefronts
+        sharing one tile pair's rotation steps (1, 2, 4)."""
+        self._check(self._lib.ludvm_set_sym_tuning(self._ctx, int(vortices_per_lane), int(rotation_split)))
+
     def set_symmetric(self, mode=1):
         """0: always the direct kernel (bitwise reproducible); 1: self-interaction launches may use the
         symmetric kernel (each unordered pair once; float atomics)."""

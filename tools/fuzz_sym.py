@@ -7,7 +7,8 @@ eng = Engine(0); dev = torch.device("cuda", 0)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 rng = np.random.default_rng(12345)
 worst = 0.0
-sizes = [16384, 16385, 16639, 16640, 98303, 98304, 98305, 98815, 98816, 99328] + [int(v) for v in rng.integers(16384, 400000, 50)]
+sizes = ([16384, 16385, 16639, 16640, 40959, 40960, 40961, 41471, 41472, 98303, 98304, 98305, 98815, 98816, 99328]
+         + [int(v) for v in rng.integers(16384, 100000, 40)] + [int(v) for v in rng.integers(100000, 400000, 20)])
 for n in sizes:
     x = torch.from_numpy(rng.uniform(-10, 0, n).astype(np.float32)).to(dev)
     z = torch.from_numpy(rng.uniform(-2, 2, n).astype(np.float32)).to(dev)

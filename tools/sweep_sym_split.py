@@ -1,0 +1,62 @@
+"""Symmetric kernel at mid sizes: tile (T = 4 / 8 vortices per lane) x rotation split (1 / 2 / 4 waves per tile
+pair), one self-advection step, interleaved rounds, best of each; the velocities of every variant are also checked against the
+direct kernel (run on the GPU box)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ludvm_amd import Engine  # noqa: E402
+
+eng = Engine(0)
+dev = torch.device("cuda", 0)
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+eng.set_symmetric(2)
+rng = np.random.default_rng(1)
+variants = [(4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4), (0, 0)]
+sizes = [int(a) for a in sys.argv[1:]] or [16384, 24576, 32768, 49152, 65536, 90000, 131072, 262144]
+for n in sizes:
+    x = torch.from_numpy(rng.uniform(-10, 0, n).astype(np.float32)).to(dev)
+    z = torch.from_numpy(rng.uniform(-2, 2, n).astype(np.float32)).to(dev)
+    g = torch.from_numpy((rng.standard_normal(n) / n).astype(np.float32)).to(dev)
+    xo, zo = torch.empty_like(x), torch.empty_like(z)
+
+    def run(v, reps):
+        eng.set_sym_tuning(*v)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.advect_dev(x.data_ptr(), z.data_ptr(), g.data_ptr(), n, 0, n, 0.065, 1e-3, xo.data_ptr(), zo.data_ptr())
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    # velocities of every variant against the direct kernel (the Euler step of dt = 1e-3 is a few ulps of x)
+    uo, wo = torch.empty_like(x), torch.empty_like(z)
+
+    def velocities(v):
+        eng.set_sym_tuning(*v)
+        eng.induce_dev(x.data_ptr(), z.data_ptr(), g.data_ptr(), n, x.data_ptr(), z.data_ptr(), n, 0.065, uo.data_ptr(),
+                       wo.data_ptr())
+        torch.cuda.synchronize()
+        return uo.clone(), wo.clone()
+
+    eng.set_symmetric(0)
+    ref = velocities((0, 0))
+    eng.set_symmetric(2)
+    scale = max(float(ref[0].abs().max()), float(ref[1].abs().max()))
+    err = {}
+    for v in variants:
+        u, w = velocities(v)
+        err[v] = max(float((u - ref[0]).abs().max()), float((w - ref[1]).abs().max())) / scale
+    reps = max(5, min(40, int(2e-2 / (n * n / 8e12))))
+    best = {v: 1e9 for v in variants}
+    for rnd in range(5):
+        for v in variants:
+            best[v] = min(best[v], run(v, reps))
+    print(json.dumps({"n": n, **{"T%dR%d" % v: float("%.3e" % (n * n / best[v])) for v in variants},
+                      "max_rel_diff_vs_direct": float("%.2e" % max(err.values()))}), flush=True)
+eng.set_sym_tuning(0, 0)
