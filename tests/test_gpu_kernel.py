@@ -323,9 +323,9 @@ def test_full_size_config3_properties(eng):
         eng.set_stream(None)
 
 
-@pytest.mark.parametrize("n", [16384, 16385, 20000, 65536 + 255, 98304, 98305, 131072, 131072 + 511, 200000])
+@pytest.mark.parametrize("n", [16384, 16385, 20000, 40959, 40960, 40961, 65536 + 255, 98304, 98305, 131072, 131072 + 511, 200000])
 def test_symmetric_kernel_tile_edges(eng, n):
-    """Symmetric self-interaction at sizes around its tilings (256-vortex tiles below 98 304 vortices,
+    """Symmetric self-interaction at sizes around its tilings (256-vortex tiles below 40 960 vortices,
     512 from there; odd and even tile counts, ragged last tile) against the C oracle and the direct kernel."""
     import torch
     rng = np.random.default_rng(n)
@@ -511,4 +511,50 @@ def test_full_size_config4_self_advection_step(eng):
             drift = abs(np.sum(gd * (a1.astype(float) - a0)))
             assert drift < 1e-3 * np.sum(np.abs(gd) * np.abs(a1.astype(float) - a0)) + 1e-9
     finally:
+        eng.set_stream(None)
+
+
+@pytest.mark.parametrize("n", [16384 + 77, 50000])
+def test_symmetric_kernel_rotation_split_variants(eng, n):
+    """Every tiling of the symmetric kernel (256 / 512-vortex tiles) with a tile pair's 64 rotation steps done by
+    1, 2 or 4 wavefronts (ludvm_set_sym_tuning): sampled targets against the C oracle, all vortices against the
+    direct kernel."""
+    import torch
+    from ludvm_amd import LudvmHipError
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-10, 0, n).astype(np.float32)
+    z = rng.uniform(-2, 2, n).astype(np.float32)
+    g = (rng.standard_normal(n) / n).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
+    du, dw = torch.empty_like(dx), torch.empty_like(dx)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    sel = np.r_[0:200, n - 200:n, rng.choice(n, 300, replace=False)]
+    ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float), x[sel].astype(float),
+                                       z[sel].astype(float), 0.065)
+
+    def velocities():
+        du.fill_(float("nan")); dw.fill_(float("nan"))
+        eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, dx.data_ptr(), dz.data_ptr(), n, 0.065,
+                       du.data_ptr(), dw.data_ptr())
+        torch.cuda.synchronize()
+        return du.cpu().numpy().astype(float), dw.cpu().numpy().astype(float)
+
+    try:
+        eng.set_symmetric(0)
+        ud, wd = velocities()
+        eng.set_symmetric(2)
+        for t in (4, 8):
+            for r in (1, 2, 4):
+                eng.set_sym_tuning(t, r)
+                u, w = velocities()
+                assert _rel(u[sel], w[sel], ur, wr) < 1e-5, (t, r)
+                assert _rel(u, w, ud, wd) < 1e-5, (t, r)
+        with pytest.raises(LudvmHipError):
+            eng.set_sym_tuning(3, 1)
+        with pytest.raises(LudvmHipError):
+            eng.set_sym_tuning(4, 3)
+    finally:
+        eng.set_sym_tuning(0, 0)
+        eng.set_symmetric(1)
         eng.set_stream(None)
