@@ -131,7 +131,10 @@ class HipFlowfieldKernel:
 
 
 class ShardedWake:
-    def __init__(self, x, z, gamma, v_core, dt, kernel, device, group=None, symmetric=True):
+    def __init__(self, x, z, gamma, v_core, dt, kernel, device, group=None, symmetric=True, force_collectives=False):
+        # force_collectives: issue the collectives even in a one-rank group (they are then identities); lets a
+        # one-GPU box run the real RCCL calls with the layouts used at G > 1
+        self.force = bool(force_collectives)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -169,7 +172,7 @@ class ShardedWake:
     def _reduce_own_sums(self):
         """Sum the per-rank partial (u, w) sums and keep this rank's block: one reduce-scatter."""
         acc, own, g = self._acc, self._own, self.world
-        if g == 1:
+        if g == 1 and not self.force:
             return acc[0, : self.n_loc], acc[1, : self.n_loc]
         backend = dist.get_backend(self.group)
         if backend == "nccl":
@@ -192,7 +195,7 @@ class ShardedWake:
             self.kernel.advect_from_sums(su, sw, self.xs, self.zs, self.lo, self.n_loc, self.dt, send[0], send[1])
         else:
             self.kernel.advect(self.xs, self.zs, self.gs, self.lo, self.n_loc, self.v_core, self.dt, send[0], send[1])
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_gather_into_tensor(self._recv.view(-1), send.view(-1), group=self.group)
             # [G, 2, n_loc] -> [2, G*n_loc].  In-place reuse of _xz is safe: in stream order the pair
             # kernel that read it has finished before this copy starts.

@@ -49,3 +49,15 @@ def test_bench_config4_shape_on_one_gpu():
     d = _run("--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1", "--cpu-rows", "0")
     assert d["scaling"] == "strong" and "config 4" in d["config"]["workload"] and "cpu_baseline" not in d
     assert d["value"] > 1e11
+
+
+def test_sharded_wake_collectives_on_the_real_rccl_backend():
+    """One rank, backend "nccl" (= RCCL): the reduce-scatter / all-gather calls of the sharded step with the
+    layouts used at G > 1 (identities in a one-rank group) against the same step without collectives
+    (tools/rccl_one_rank.py, in a child process so that the process group does not outlive the test)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_one_rank.py")], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
