@@ -558,3 +558,36 @@ def test_symmetric_kernel_rotation_split_variants(eng, n):
         eng.set_sym_tuning(0, 0)
         eng.set_symmetric(1)
         eng.set_stream(None)
+
+
+@pytest.mark.parametrize("prec_code,tol100", [(2, 1e-9), (0, 1e-2)])
+def test_integration_md_binding_drives_the_reference_loop(prec_code, tol100):
+    """INTEGRATION.md option B as printed: the raw-ctypes binding of ludvm_induce_f64 is executed from the document
+    and bound over `induced_velocity` of the CPU restatement of the reference class (the reference file itself does
+    not travel to the GPU box); every call site of the reference's own time loop then runs through the C ABI.
+    Against the reference's golden README run: identical LEV shedding; fp64 mode to rounding over the first 100
+    steps, fp32 inside SURVEY's T2 bound (1e-2)."""
+    import os
+    import re
+    from conftest import CONFIG1, ROOT
+    from ludvm_amd import _ffi
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"## B\..*?```python\n(.*?)```", text, re.S).group(1)
+    assert "/path/to/ludvm_amd/csrc/libludvm_hip.so" in block and "v_core, 0, p(u), p(w))" in block
+    block = block.replace("/path/to/ludvm_amd/csrc/libludvm_hip.so", _ffi.LIB_PATH)
+    block = block.replace("v_core, 0, p(u), p(w))", f"v_core, {prec_code}, p(u), p(w))")
+    _ffi.load()                       # one HIP runtime in the process before the document's own CDLL call
+    ns = {}
+    exec(compile(block, "INTEGRATION.md#B", "exec"), ns)
+
+    class Bound(O.OracleLUDVM):
+        induced_velocity = ns["induced_velocity"]
+
+    g2 = load_golden("g2_config1.npz")
+    sim = Bound(**CONFIG1)
+    assert np.array_equal(sim.LEV_shed, g2["LEV_shed"])
+    for name in ("Cl", "Cd", "Cm"):
+        assert np.abs(getattr(sim, name)[:100] - g2[name][:100]).max() <= tol100, name
+    if prec_code == 2:
+        np.testing.assert_allclose(sim.path["TEV"][50], g2["TEV_50"], rtol=0, atol=1e-9)
+    ns["_hip"].ludvm_destroy(ns["_ctx"])
