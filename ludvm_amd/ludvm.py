@@ -428,7 +428,6 @@ class LUDVM:
             kin = np.concatenate([self.alpha[:, None], self.alpha_dot[:, None], self.h_dot[:, None], foil[:, :, -1],
                                   foil[:, :, 0], gpts[:, 0, :], gpts[:, 1, :]], axis=1)
             eng.march_setup(npan, self.Ncoeffs, [U, c, rho, dt, self.piv, vc, C['IC'], sum_free], tables, kin)
-        nc = self.Ncoeffs
         march_chunk = int(getattr(self, '_march_chunk', 32768))   # steps per ludvm_march_run call (bounds the returned rows)
 
         i = first_step
@@ -440,7 +439,6 @@ class LUDVM:
                     if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
                         break
                 if j - i >= 2:
-                    n_wake = nf + itev + ilev
                     if have_next:
                         place = [sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1]]
                     else:
@@ -448,46 +446,12 @@ class LUDVM:
                         tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
                         lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
                         place = [tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]]
-                    st = np.zeros(16 + nc)
-                    st[:11] = [n_wake, itev, ilev, float(LEV_shed[i - 1] != -1), lesp_crit, sum_tev, sum_lev] + place
-                    st[16:] = self.fourier[i - 1, 0, :]
-                    R = eng.march_run(i, j - i, prec_code, st)
-                    cnt = j - i
-                    steps = np.arange(i, j)
-                    tix = itev + np.arange(cnt)
-                    shed_v = R[:, 2] != 0
-                    slot = R[:, 9].astype(np.int64)
-                    C['TEV'][tix] = R[:, 0]
-                    C['bound'][tix] = R[:, 3]
-                    self.LESP_prev[tix], self.LESP[tix] = R[:, 4], R[:, 5]
-                    self.Fn[steps], self.Fs[steps], self.M[steps] = R[:, 6], R[:, 7], R[:, 8]
-                    ca_, sa_ = np.cos(self.alpha[steps]), np.sin(self.alpha[steps])
-                    self.L[steps] = self.Fn[steps] * ca_ + self.Fs[steps] * sa_
-                    self.D[steps] = self.Fn[steps] * sa_ - self.Fs[steps] * ca_
-                    self.T[steps] = -self.D[steps]
-                    tev_slot[tix] = slot
-                    lix = ilev + np.cumsum(shed_v)[shed_v] - 1
-                    C['LEV'][lix] = R[shed_v, 1]
-                    lev_slot[lix] = slot[shed_v] + 1
-                    LEV_shed[steps[shed_v]] = lix
-                    self.fourier[steps, 0, :] = R[:, 10:10 + nc]
-                    self.fourier[steps, 1, :] = R[:, 10 + nc:10 + 2 * nc]
-                    C['gamma_airfoil'][tix] = R[:, 10 + 2 * nc:10 + 2 * nc + npan]
-                    C['airfoil'][tix] = R[:, 10 + 2 * nc + npan:]
-                    C['Gamma_airfoil'][tix] = np.cumsum(C['airfoil'][tix], axis=1)
-                    last_shed = bool(shed_v[-1])
-                    if int(st[1]) != itev + cnt or int(st[0]) != n_wake + cnt + int(shed_v.sum()):
-                        raise RuntimeError("device march returned an inconsistent state")
-                    self.itev, self.ilev, self.LEV_shed = itev + cnt - 1, ilev + int(shed_v.sum()) - int(last_shed), LEV_shed
-                    itev, ilev = itev + cnt, ilev + int(shed_v.sum())
-                    lesp_crit, sum_tev, sum_lev = float(st[4]), float(st[5]), float(st[6])
-                    if last_shed:
-                        last_tev, last_lev = np.array([st[12], st[14]]), np.array([st[13], st[15]])
-                    else:
-                        last_tev = np.array([st[13], st[15]])
+                    (itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev) = self._march_stretch(
+                        i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed, tev_slot,
+                        lev_slot, prec_code)
                     have_next = False
                     if self.verbose == True:  # noqa: E712
-                        for q in steps:
+                        for q in range(i, j):
                             if q == 1 or q == nt - 1 or q / print_dt == int(q / print_dt):
                                 print('Step {} out of {}. Elapsed time {}'.format(q, nt - 1,
                                                                                    timeit.default_timer() - self.start_time))
@@ -668,6 +632,52 @@ class LUDVM:
                                        tev_slot, lev_slot)
             i += 1
         return None
+
+    def _march_stretch(self, i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
+                       tev_slot, lev_slot, prec_code):
+        """Time steps [i, j) as one device-resident march (Engine.march_run) and everything the per-step path
+        would have stored for them (LUDVM.py:765-1090): circulations, Fourier rows, LESP, loads, slot maps.
+        `place` = [tev_x, lev_x, tev_z, lev_z] of step i.  LEV_shed, tev_slot, lev_slot and the result arrays
+        are updated in place; returns the loop's scalars after step j - 1."""
+        C, nc, npan, cnt = self.circulation, self.Ncoeffs, self.Npoints - 1, j - i
+        n_wake = nf + itev + ilev
+        st = np.zeros(16 + nc)
+        st[:11] = [n_wake, itev, ilev, float(LEV_shed[i - 1] != -1), lesp_crit, sum_tev, sum_lev] + list(place)
+        st[16:] = self.fourier[i - 1, 0, :]
+        R = self.engine.march_run(i, cnt, prec_code, st)
+        steps = np.arange(i, j)
+        tix = itev + np.arange(cnt)
+        shed_v = R[:, 2] != 0
+        n_shed = int(shed_v.sum())
+        slot = R[:, 9].astype(np.int64)
+        if int(st[1]) != itev + cnt or int(st[0]) != n_wake + cnt + n_shed:
+            raise RuntimeError("device march returned an inconsistent state")
+        C['TEV'][tix] = R[:, 0]
+        C['bound'][tix] = R[:, 3]
+        self.LESP_prev[tix], self.LESP[tix] = R[:, 4], R[:, 5]
+        self.Fn[steps], self.Fs[steps], self.M[steps] = R[:, 6], R[:, 7], R[:, 8]
+        ca, sa = np.cos(self.alpha[steps]), np.sin(self.alpha[steps])
+        self.L[steps] = self.Fn[steps] * ca + self.Fs[steps] * sa             # :1077-1081
+        self.D[steps] = self.Fn[steps] * sa - self.Fs[steps] * ca
+        self.T[steps] = -self.D[steps]
+        tev_slot[tix] = slot
+        lix = ilev + np.cumsum(shed_v)[shed_v] - 1
+        C['LEV'][lix] = R[shed_v, 1]
+        lev_slot[lix] = slot[shed_v] + 1
+        LEV_shed[steps[shed_v]] = lix
+        self.fourier[steps, 0, :] = R[:, 10:10 + nc]
+        self.fourier[steps, 1, :] = R[:, 10 + nc:10 + 2 * nc]
+        C['gamma_airfoil'][tix] = R[:, 10 + 2 * nc:10 + 2 * nc + npan]
+        C['airfoil'][tix] = R[:, 10 + 2 * nc + npan:]
+        C['Gamma_airfoil'][tix] = np.cumsum(C['airfoil'][tix], axis=1)
+        last_shed = bool(shed_v[-1])
+        # as the per-step path leaves them: the counters before the last step's increment
+        self.itev, self.ilev, self.LEV_shed = itev + cnt - 1, ilev + n_shed - int(last_shed), LEV_shed
+        if last_shed:       # newest TEV at size - 2, newest LEV at size - 1
+            last_tev, last_lev = np.array([st[12], st[14]]), np.array([st[13], st[15]])
+        else:
+            last_tev = np.array([st[13], st[15]])
+        return itev + cnt, ilev + n_shed, float(st[4]), float(st[5]), float(st[6]), last_tev, last_lev
 
     # ------------------------------------------------------------------------------------------
     # checkpoint / resume (not in the reference; SURVEY 8(f)3)
