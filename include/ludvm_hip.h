@@ -222,7 +222,8 @@ int ludvm_wake_step(ludvm_ctx* ctx, const double* new_x, const double* new_z, co
  *   g_tev, g_lev, shed(0/1), bound, LESP_prev, LESP, Fn, Fs, M, wake slot of the new TEV,
  *   A[ncoef], dA/dt[ncoef], gamma[npan], dGamma[npan].
  * Synchronous: returns when the last step has finished.  `precision` selects the roll-up arithmetic as in
- * ludvm_wake_advect; the solve is float64. */
+ * ludvm_wake_advect; the solve is float64.  From the symmetric-kernel threshold on, a step's chord sums and solve run on
+ * a second stream beside the symmetric kernel (environment LUDVM_MARCH_OVERLAP=0 keeps every step serial). */
 int ludvm_march_setup(ludvm_ctx* ctx, int npan, int ncoef, const double* scalars, const double* tables, const double* kin,
                       size_t kin_rows);
 int ludvm_march_run(ludvm_ctx* ctx, long long first_step, long long count, int precision, double* state, double* rows);

@@ -64,6 +64,8 @@ struct ludvm_ctx {
   unsigned long long* progress = nullptr;      // host-mapped: (step << 32 | wake size) after each solve
   unsigned long long* progress_dev = nullptr;
   hipEvent_t march_ev[2] = {nullptr, nullptr};
+  hipStream_t stream_b = nullptr;              // the solve chain beside the roll-up (overlapped march steps)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   // kernel timing
   bool timing = false;
@@ -483,6 +485,9 @@ int ludvm_destroy(ludvm_ctx* c) {
     if (p) (void)hipFree(p);
   for (auto& e : c->march_ev)
     if (e) (void)hipEventDestroy(e);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
   if (c->progress) (void)hipHostFree(c->progress);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_out) (void)hipHostFree(c->pin_out);
@@ -927,7 +932,7 @@ int ludvm_wake_advect_tail(ludvm_ctx* c, double dt, const double* foil_x, const 
 // arrays receiving the induced velocities.  n_dev (march): the wake size is read on the device and `n` is
 // only an upper bound that sizes the launch.
 static int advect_launch(ludvm_ctx* c, size_t n, const long long* n_dev, double dt, size_t nfoil, double vcore,
-                         int precision, double* du, double* dw) {
+                         int precision, double* du, double* dw, TailDuty td = TailDuty{}) {
   const long long ns = (long long)(n + nfoil), nt = (long long)n;
   const double v2 = vcore * vcore;
   if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt)) {
@@ -939,10 +944,10 @@ static int advect_launch(ludvm_ctx* c, size_t n, const long long* n_dev, double 
     const float* acc = static_cast<const float*>(c->acc.p);
     if (hilo)
       hipLaunchKernelGGL(finish_wake_advect_sym<true>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, nt,
-                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw, n_dev);
+                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw, n_dev, td);
     else
       hipLaunchKernelGGL(finish_wake_advect_sym<false>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, nt,
-                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw, n_dev);
+                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw, n_dev, td);
     HIPCHK(c, hipGetLastError());
     return LUDVM_OK;
   }
@@ -966,11 +971,11 @@ static int advect_launch(ludvm_ctx* c, size_t n, const long long* n_dev, double 
   if (precision == LUDVM_PREC_F64)
     hipLaunchKernelGGL(finish_wake_advect<double>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
                        static_cast<const double*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->xh, c->xl,
-                       c->zh, c->zl, du, dw, n_dev);
+                       c->zh, c->zl, du, dw, n_dev, td);
   else
     hipLaunchKernelGGL(finish_wake_advect<float>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
                        static_cast<const float*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->xh, c->xl,
-                       c->zh, c->zl, du, dw, n_dev);
+                       c->zh, c->zl, du, dw, n_dev, td);
   HIPCHK(c, hipGetLastError());
   return LUDVM_OK;
 }
@@ -1115,6 +1120,7 @@ int ludvm_march_setup(ludvm_ctx* c, int npan, int ncoef, const double* scalars, 
   m.U = scalars[0]; m.chord = scalars[1]; m.rho = scalars[2]; m.dt = scalars[3]; m.piv = scalars[4];
   c->march_vcore = scalars[5];
   m.kelvin0 = scalars[7] - scalars[6];          // sum(Gamma_free) - IC
+  m.vc4 = (scalars[5] * scalars[5]) * (scalars[5] * scalars[5]);
   const double* t = static_cast<const double*>(c->march_tab.p);
   m.detadx = t; m.eta = t + P; m.xpan = t + 2 * P; m.cm1 = t + 3 * P; m.wq = t + 4 * P; m.opcs = t + 5 * P;
   m.hcsd = t + 6 * P; m.wx = t + 7 * P; m.cproj = t + 8 * P; m.ssin = t + 8 * P + (size_t)ncoef * P;
@@ -1125,35 +1131,41 @@ int ludvm_march_setup(ludvm_ctx* c, int npan, int ncoef, const double* scalars, 
   }
   for (auto& e : c->march_ev)
     if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  if (!c->ev_join) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  if (!c->stream_b) {
+    int least = 0, greatest = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // the solve chain is short and latency-critical: let it cut in front of the roll-up's workgroups
+    HIPCHK(c, hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, greatest));
+  }
   c->march_ready = true;
   return LUDVM_OK;
 }
 
 namespace {
 
-// fp64 wake -> chord partial sums for time step `step` (its chord points are row `step` of the kinematics
-// table), then the finisher that leaves sums, unit influences and placements in the device state.
-int march_chord_launch(ludvm_ctx* c, long long step, long long n_ub) {
+// fp64 partial sums of the wake at the npan + 2 targets staged in MarchState (chord points of the coming solve and
+// its two placements), then the finisher that leaves sums and unit influences in the device state.  Launches on
+// c->stream (the caller points it at the second stream for overlapped steps).
+int march_chord_launch(ludvm_ctx* c, long long n_ub) {
   const MarchSetup& m = c->msetup;
-  const size_t P = (size_t)m.npan;
-  const double* krow = static_cast<const double*>(c->march_kin.p) + (size_t)step * (7 + 2 * P);
+  const size_t P = (size_t)m.npan, NT = P + 2;
   MarchState* S = static_cast<MarchState*>(c->march_state.p);
-  const double v2 = c->march_vcore * c->march_vcore;
   PairArgs a{};
   a.xs = c->x64; a.zs = c->z64; a.gs = c->g64;
   a.ns = 0; a.n_dev = &S->n; a.ns_dev = 1; a.nt_dev = 0;
-  a.xt = krow + 7; a.zt = krow + 7 + P; a.nt = (long long)P;
-  a.vc4 = v2 * v2;
-  Plan p = make_plan(c, (long long)P, std::max<long long>(n_ub, 1), LUDVM_PREC_F64);
+  a.xt = S->tgt; a.zt = S->tgt + NT; a.nt = (long long)NT;
+  a.vc4 = m.vc4;
+  Plan p = make_plan(c, (long long)NT, std::max<long long>(n_ub, 1), LUDVM_PREC_F64);
   const bool was = c->timing;
   c->timing = false;   // the chord sums are not the dominant kernel
   int rc = launch_pair(c, a, p, LUDVM_PREC_F64, nullptr, nullptr);
   c->timing = was;
   CHK(rc);
   const double* slab = static_cast<const double*>(c->part.p);
-  hipLaunchKernelGGL(march_chord_finish, dim3(blocks_for((long long)(2 * P * 64))), dim3(kBlock), 0, c->stream,
-                     p.nsplit > 1 ? slab : (const double*)nullptr, p.nt_pad, p.nsplit, slab, krow + 7, krow + 7 + P,
-                     (long long)P, c->x64, c->z64, S, krow + 3, v2 * v2);
+  hipLaunchKernelGGL(march_chord_finish, dim3(blocks_for((long long)(2 * NT * 64))), dim3(kBlock), 0, c->stream,
+                     p.nsplit > 1 ? slab : (const double*)nullptr, p.nt_pad, p.nsplit, slab, (int)P, S, m.vc4);
   HIPCHK(c, hipGetLastError());
   return LUDVM_OK;
 }
@@ -1168,7 +1180,7 @@ void march_workspace(const ludvm_ctx* c, long long n_ub, int precision, size_t n
     const size_t elt = precision == LUDVM_PREC_F64 ? 8 : 4;
     part_bytes = std::max(part_bytes, (size_t)p.nsplit * 2 * (size_t)p.nt_pad * elt);
   }
-  Plan q = make_plan(c, (long long)nfoil, nt, LUDVM_PREC_F64);
+  Plan q = make_plan(c, (long long)nfoil + 2, nt, LUDVM_PREC_F64);
   part_bytes = std::max(part_bytes, (size_t)q.nsplit * 2 * (size_t)q.nt_pad * 8);
 }
 
@@ -1212,14 +1224,23 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   HIPCHK(c, hipStreamSynchronize(c->stream));   // hs lives on this stack frame
   *c->progress = ((unsigned long long)(first_step - 1) << 32) | (unsigned long long)n0;
 
-  // chord sums of the first step, with the placements the caller supplied (tail == 0)
-  CHK(march_chord_launch(c, first_step, n0));
-
   double* drows = static_cast<double*>(c->march_rows.p);
   const double* kin = static_cast<const double*>(c->march_kin.p);
+  const size_t krow = 7 + 2 * P;
+  hipLaunchKernelGGL(march_begin, dim3(1), dim3(kBlock), 0, c->stream, S, kin + (size_t)first_step * krow, (int)P,
+                     (int)(first_step & 1));
+  HIPCHK(c, hipGetLastError());
+
   bool ev_used[2] = {false, false};
   constexpr long long kSyncEvery = 64;
   long long p_step = first_step - 1, p_n = n0;
+  long long n_before = n0;          // upper bound of the wake size before the current step's solve
+  bool overlapped = false;          // the accumulators have been zeroed for the overlapped steps
+  // LUDVM_MARCH_OVERLAP=0 keeps every step serial (A/B measurements; results agree to fp32 rounding)
+  const char* ov_env = std::getenv("LUDVM_MARCH_OVERLAP");
+  const bool overlap_ok = !(ov_env && ov_env[0] == '0');
+  hipStream_t const main_stream = c->stream;
+  const double vc4 = m.vc4;
   for (long long s = first_step; s < first_step + count; ++s) {
     const long long rel = s - first_step;
     if (rel % kSyncEvery == 0) {
@@ -1239,17 +1260,64 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
     // depends on how far the host runs ahead and is used only once the symmetric kernel (float atomics, not
     // bitwise anyway) has taken over.
     const long long n_det = n0 + 2 * (rel + 1);
+    const bool symreg = precision != LUDVM_PREC_F64 && use_symmetric(c, n_det);
+    const bool fork = symreg && overlap_ok;
     long long n_ub = n_det;
-    if (precision != LUDVM_PREC_F64 && use_symmetric(c, n_det)) {
+    if (symreg) {
       const long long thr = c->sym_mode == 1 ? kSymMinN : (long long)c->sym_mode;
       n_ub = std::max<long long>(std::min<long long>(p_n + 2 * (s - p_step), n_det), thr);
+      n_before = std::min(n_before, n_ub);
     }
-    hipLaunchKernelGGL(march_solve, dim3(1), dim3(kBlock), 0, c->stream, m, S, kin + (size_t)s * (7 + 2 * P),
-                       drows + (size_t)rel * row_doubles, s, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32,
-                       c->progress_dev);
-    HIPCHK(c, hipGetLastError());
-    CHK(advect_launch(c, (size_t)n_ub, &S->n, m.dt, nfoil, c->march_vcore, precision, nullptr, nullptr));
-    if ((size_t)(s + 1) < c->march_kin_rows) CHK(march_chord_launch(c, s + 1, n_ub));
+    const double* krow_s = kin + (size_t)s * krow;
+    const double* krow_next = (size_t)(s + 1) < c->march_kin_rows ? kin + (size_t)(s + 1) * krow : nullptr;
+    const TailDuty td = make_tail_duty(S, s, krow_next, (int)P);
+    double* row = drows + (size_t)rel * row_doubles;
+    if (!fork) {
+      // serial step: chord sums -> solve -> roll-up (direct, or symmetric with its memset) and Euler finisher
+      CHK(march_chord_launch(c, n_before));
+      hipLaunchKernelGGL(march_solve, dim3(1), dim3(kBlock), 0, c->stream, m, S, krow_s, row, s, c->x64, c->z64, c->g64,
+                         c->xh, c->xl, c->zh, c->zl, c->g32, c->progress_dev);
+      HIPCHK(c, hipGetLastError());
+      CHK(advect_launch(c, (size_t)n_ub, &S->n, m.dt, nfoil, c->march_vcore, precision, nullptr, nullptr, td));
+    } else {
+      // overlapped step: the symmetric kernel on the wake as the last roll-up left it runs on the main stream
+      // while chord sums and solve run on the second one; they meet at the Euler finisher
+      const bool hilo = precision == LUDVM_PREC_F32X2;
+      const long long nt_pad = (n_ub + 63) / 64 * 64;
+      float* acc = static_cast<float*>(c->acc.p);
+      if (!overlapped) {
+        HIPCHK(c, hipMemsetAsync(c->acc.p, 0, c->acc.cap, c->stream));   // march_finish_sym re-zeroes what it reads
+        overlapped = true;
+      }
+      HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+      HIPCHK(c, hipStreamWaitEvent(c->stream_b, c->ev_fork, 0));
+      c->stream = c->stream_b;
+      int rc = march_chord_launch(c, n_before);
+      if (rc == LUDVM_OK) {
+        hipLaunchKernelGGL(march_solve, dim3(1), dim3(kBlock), 0, c->stream, m, S, krow_s, row, s, c->x64, c->z64, c->g64,
+                           c->xh, c->xl, c->zh, c->zl, c->g32, c->progress_dev);
+        if (hipGetLastError() != hipSuccess) rc = fail(c, LUDVM_E_HIP, "march_solve launch failed");
+      }
+      c->stream = main_stream;
+      CHK(rc);
+      HIPCHK(c, hipEventRecord(c->ev_join, c->stream_b));
+      const long long nb = std::max<long long>(n_before, 1);
+      const int T = (nb >= kSymT8MinN && !hilo) ? 8 : 4;
+      const long long ntiles = (nb + 64LL * T - 1) / (64LL * T);
+      CHK(launch_sym_tiles(c, T, c->xh, c->zh, c->g32, nb, 0, ntiles, vc4, acc, acc + nt_pad, hilo ? c->xl : nullptr,
+                           hilo ? c->zl : nullptr, &S->n_old[s & 1]));
+      HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+      if (hilo)
+        hipLaunchKernelGGL(march_finish_sym<true>, dim3(blocks_for(n_ub)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, S,
+                           &S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32,
+                           td);
+      else
+        hipLaunchKernelGGL(march_finish_sym<false>, dim3(blocks_for(n_ub)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, S,
+                           &S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32,
+                           td);
+      HIPCHK(c, hipGetLastError());
+    }
+    n_before = n_ub;
   }
   // results: per-step rows, final state, the two newest wake vortices
   HIPCHK(c, hipMemcpyAsync(rows, drows, (size_t)count * row_doubles * 8, hipMemcpyDeviceToHost, c->stream));

@@ -3,15 +3,21 @@
 // a host round trip.  All of it is float64 and small (Npanels = 80 chord points, Ncoeffs = 30): one
 // workgroup per step.
 //
-// Per step i the device runs
-//   march_solve         T1/T2/T3 downwash rows from the chord sums, Gamma_TEV (and Gamma_LEV when |A0| reaches
-//                       LESPcrit), Fourier coefficients, bound vorticity, loads; appends the shed vortices and
-//                       stages the bound vortices behind the wake                    (:743-1090)
-//   roll-up             the pair kernels of pair_kernels.hpp / pair_sym_kernels.hpp with the wake size taken
-//                       from MarchState (n_dev)                                      (:1095-1127)
-//   pair_f64<128>       fp64 wake -> chord partial sums for step i+1                 (:746, :921)
-//   march_chord_finish  sums the partials, places the next TEV / candidate LEV, unit influences (:672-681,
-//                       :751, :788-800, :926-931), all into MarchState
+// Per time step i the device runs, in this order,
+//   pair_f64<128>       fp64 partial sums of the wake at Npanels + 2 targets: the chord points of step i
+//                       (:746, :921) and the two points where step i will shed its TEV and candidate LEV
+//   march_chord_finish  sums the partials; unit influences of those two vortices at the chord points
+//                       (:751, :926-931)                                              -> MarchState
+//   march_solve         T1/T2/T3 downwash rows, Gamma_TEV (and Gamma_LEV when |A0| reaches LESPcrit), Fourier
+//                       coefficients, bound vorticity, loads; appends the shed vortices and stages the bound
+//                       vortices behind the wake                                     (:743-1090)
+//   roll-up             (:1095-1127) the pair kernels of pair_kernels.hpp / pair_sym_kernels.hpp with the wake
+//                       size taken from MarchState; their Euler finisher also places the TEV / LEV of step i + 1
+//                       (:680-681, :797-800) and stages its chord points (TailDuty)
+// Once the wake is large enough for the symmetric kernel the first three run on a second stream BESIDE the bulk of
+// the roll-up: old wake on old wake depends only on the positions after the previous roll-up, not on this step's
+// solve.  The shed vortices are then handled apart: what the old wake induces on them comes from the two extra
+// targets of the chord launch, what they induce on the old wake is added by march_finish_sym.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pair_kernels.hpp"
@@ -23,25 +29,39 @@ constexpr int kMarchMaxCoef = 64;
 
 struct MarchState {
   long long n;          // wake vortices (FREE + TEV + LEV, shedding order)
+  long long n_old[2];   // ... before a step's solve (= after the previous roll-up); step s reads slot s & 1 and
+                        // its finisher writes slot (s + 1) & 1 (blocks of one launch read and write it)
   long long itev, ilev; // TEV / LEV shed so far
   int shed;             // the step just solved shed a LEV (LEV_shed[i] != -1)
   int tail;             // vortices appended by the step just solved (1 or 2; 0 before the first one)
   double lesp_crit, sum_tev, sum_lev;
   double place[4];      // coming step: tev_x, lev_x, tev_z, lev_z
+  double pvel[4];       // what the wake induces there: u_tev, u_lev, w_tev, w_lev
+  double newv[6];       // vortices shed by the step just solved, before their roll-up: x0, x1, z0, z1, g0, g1
+  double newvel[4];     // ... and their velocities u0, u1, w0, w1 (wake + each other + bound vortices)
   double prevA[kMarchMaxCoef];
-  double chord[6 * kMarchMaxPan];   // coming step: u1 | w1 | u_tev | w_tev | u_lev | w_lev at the chord points
+  double chord[6 * kMarchMaxPan];          // coming step: u1 | w1 | u_tev | w_tev | u_lev | w_lev at the chord points
+  double tgt[2 * (kMarchMaxPan + 2)];      // targets of the chord launch: x[npan + 2] | z[npan + 2]
 };
 
 // Read-only description of a run, passed by value.
 struct MarchSetup {
   int npan, ncoef;
   double U, chord, rho, dt, piv, kelvin0;   // kelvin0 = sum(Gamma_free) - IC  (:758)
+  double vc4;
   // packed tables (device): see ludvm_march_setup in include/ludvm_hip.h
   const double* detadx; const double* eta; const double* xpan; const double* cm1; const double* wq;
   const double* opcs; const double* hcsd; const double* wx; const double* cproj; const double* ssin;
 };
 
 constexpr int kMarchRowHead = 10;   // g_tev, g_lev, shed, bound, LESP_prev, LESP, Fn, Fs, M, slot
+
+inline TailDuty make_tail_duty(MarchState* S, long long step, const double* kin_next, int npan) {
+  TailDuty td;
+  td.place = S->place; td.tgt = S->tgt; td.n_old = &S->n_old[(step + 1) & 1]; td.tail = &S->tail; td.shed = &S->shed;
+  td.kin_next = kin_next; td.npan = npan;
+  return td;
+}
 
 // Sum v over the workgroup (fixed tree: wavefront shuffles, then the 4 wave partials in order); every thread
 // gets the result.  `scratch` holds kBlock / 64 doubles.
@@ -69,6 +89,62 @@ __device__ __forceinline__ void solve2(double a00, double a01, double a10, doubl
   const double y1 = b1 - l * b0;
   x1 = y1 / u11;
   x0 = (b0 - a01 * x1) / a00;
+}
+
+// Vatistas pair: velocity at (xp, zp) per unit circulation of a vortex at (xs, zs)
+__device__ __forceinline__ void unit_pair_f64(double xp, double zp, double xs, double zs, double vc4, double& u, double& w) {
+  const double dx = xp - xs, dz = zp - zs;
+  const double r2 = __builtin_fma(dz, dz, dx * dx);
+  const double s = kInv2PiD * rsqrt_f64(__builtin_fma(r2, r2, vc4));
+  u = dz * s;
+  w = -dx * s;
+}
+
+// Start of a march call: the caller supplied the placements of the first step; stage its targets.
+__global__ void __launch_bounds__(kBlock)
+march_begin(MarchState* S, const double* kin, int npan, int slot) {
+  const int t = threadIdx.x;
+  if (t < npan) { S->tgt[t] = kin[7 + t]; S->tgt[npan + 2 + t] = kin[7 + npan + t]; }
+  if (t == 0) {
+    S->tgt[npan] = S->place[0]; S->tgt[npan + 1] = S->place[1];
+    S->tgt[npan + 2 + npan] = S->place[2]; S->tgt[npan + 2 + npan + 1] = S->place[3];
+    S->n_old[slot] = S->n;
+  }
+}
+
+// Sums the fp64 partial slabs of the chord launch (one WAVEFRONT per output column, fixed shuffle tree) and
+// evaluates the unit influences of the coming TEV / candidate LEV at the chord points.  Columns: component k
+// (0: u, 1: w) x target p; p < npan is a chord point, p = npan, npan + 1 the two placements.
+__global__ void __launch_bounds__(kBlock)
+march_chord_finish(const double* part, long long nt_pad, int nsplit, const double* direct_u, int npan, MarchState* S,
+                   double vc4) {
+  const long long gtid = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const long long col = gtid >> 6;
+  const int lane = threadIdx.x & 63;
+  const int ntt = npan + 2;
+  if (col >= 2 * ntt) return;   // whole wavefronts leave together
+  const int k = (int)(col / ntt), p = (int)(col - (long long)k * ntt);
+  double acc = 0.0;
+  if (part != nullptr) {
+    const double* c0 = part + k * nt_pad + p;
+    for (int sidx = lane; sidx < nsplit; sidx += 64) acc += c0[(long long)sidx * 2 * nt_pad];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  } else if (nsplit == 1) {
+    acc = direct_u[k * nt_pad + p];
+  }
+  if (lane != 0) return;
+  if (p >= npan) {
+    S->pvel[k * 2 + (p - npan)] = acc;
+    return;
+  }
+  double* out = S->chord;
+  out[k * npan + p] = acc;
+  // unit vortex k (0: TEV, 1: LEV candidate) at chord point p
+  double uu, ww;
+  unit_pair_f64(S->tgt[p], S->tgt[ntt + p], S->place[k], S->place[2 + k], vc4, uu, ww);
+  out[2 * npan + (k * 2 + 0) * npan + p] = uu;
+  out[2 * npan + (k * 2 + 1) * npan + p] = ww;
 }
 
 // One workgroup.  kin = this step's kinematics row [alpha, alpha_dot, h_dot, te_x, te_z, le_x, le_z,
@@ -170,6 +246,22 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
   const long long n0 = S->n;
   const int k = shed ? 2 : 1;
   const double tev_x = S->place[0], lev_x = S->place[1], tev_z = S->place[2], lev_z = S->place[3];
+  const double pu0 = S->pvel[0], pu1 = S->pvel[1], pw0 = S->pvel[2], pw1 = S->pvel[3];
+
+  // Velocity of the vortices shed now, for the roll-up that treats them apart (:1105-1124 restricted to them):
+  // the wake's part came with the chord sums; the bound vortices' part is summed here; plus each other.
+  double fu0 = 0, fw0 = 0, fu1 = 0, fw1 = 0;
+  if (on) {
+    double uu, ww;
+    unit_pair_f64(tev_x, tev_z, xg[j], zg[j], m.vc4, uu, ww);
+    fu0 = dgamma * uu; fw0 = dgamma * ww;
+    if (shed) {
+      unit_pair_f64(lev_x, lev_z, xg[j], zg[j], m.vc4, uu, ww);
+      fu1 = dgamma * uu; fw1 = dgamma * ww;
+    }
+  }
+  const double su0 = block_sum(fu0, scratch), sw0 = block_sum(fw0, scratch);
+  const double su1 = block_sum(fu1, scratch), sw1 = block_sum(fw1, scratch);
   __syncthreads();                                   // all reads of S are done; it is rewritten below
 
   if (j == 0) {
@@ -187,11 +279,21 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
     // the shed vortices join the wake (:1095-1098)
     x64[n0] = tev_x; z64[n0] = tev_z; g64[n0] = g_tev;
     split_hilo(tev_x, xh[n0], xl[n0]); split_hilo(tev_z, zh[n0], zl[n0]); g32[n0] = (float)g_tev;
+    double m01u = 0, m01w = 0, m10u = 0, m10w = 0;   // TEV <- LEV, LEV <- TEV
     if (shed) {
       const long long n1 = n0 + 1;
       x64[n1] = lev_x; z64[n1] = lev_z; g64[n1] = g_lev;
       split_hilo(lev_x, xh[n1], xl[n1]); split_hilo(lev_z, zh[n1], zl[n1]); g32[n1] = (float)g_lev;
+      double uu, ww;
+      unit_pair_f64(tev_x, tev_z, lev_x, lev_z, m.vc4, uu, ww);
+      m01u = g_lev * uu; m01w = g_lev * ww;
+      unit_pair_f64(lev_x, lev_z, tev_x, tev_z, m.vc4, uu, ww);
+      m10u = g_tev * uu; m10w = g_tev * ww;
     }
+    S->newv[0] = tev_x; S->newv[1] = lev_x; S->newv[2] = tev_z; S->newv[3] = lev_z;
+    S->newv[4] = g_tev; S->newv[5] = shed ? g_lev : 0.0;
+    S->newvel[0] = pu0 + su0 + m01u; S->newvel[2] = pw0 + sw0 + m01w;
+    S->newvel[1] = pu1 + su1 + m10u; S->newvel[3] = pw1 + sw1 + m10w;
     S->n = n0 + k;
     S->itev += 1;
     S->ilev += shed ? 1 : 0;
@@ -220,57 +322,69 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
   }
 }
 
-// chord_finish_f64 (pair_kernels.hpp) for the march: wake size, tail length and the LEV flag come from
-// MarchState, and the results (chord sums, unit influences, placements of the coming step) go back into it.
-// geo = [te_x, te_z, le_x, le_z] of the coming step; xt / zt its chord points.  tail == 0 (start of a
-// march): the placements already in S are used as they are.
+// Euler finisher of the overlapped roll-up.  The symmetric kernel ran on the wake as it was BEFORE this step's
+// solve ([0, n_old), raw sums in acc_u / acc_w); here every old vortex also feels the vortices shed this step
+// (S->newv) and the bound vortices (staged at [n, n + nfoil)), and the shed vortices move with the velocities
+// march_solve left in S->newvel.  The raw sums are zeroed after use, so the accumulators need no memset between
+// steps.  HILO as in the pair kernels.
+template <bool HILO>
 __global__ void __launch_bounds__(kBlock)
-march_chord_finish(const double* part, long long nt_pad, int nsplit, const double* direct_u, const double* xt,
-                   const double* zt, long long nt, const double* x64, const double* z64, MarchState* S, const double* geo,
-                   double vc4) {
-  const long long gtid = (long long)blockIdx.x * kBlock + threadIdx.x;
-  const long long col = gtid >> 6;
-  const int lane = threadIdx.x & 63;
-  const long long n = S->n;
-  const int tail = S->tail;
-  double ux[2], uz[2];
-  if (tail == 0) {
-    ux[0] = S->place[0]; ux[1] = S->place[1]; uz[0] = S->place[2]; uz[1] = S->place[3];
-  } else {
-    const double tex = geo[0], tez = geo[1], lex = geo[2], lez = geo[3];
-    const long long it = n - tail;
-    ux[0] = tex + (x64[it] - tex) / 3;
-    uz[0] = tez + (z64[it] - tez) / 3;
-    if (S->shed && tail == 2) {
-      ux[1] = lex + (x64[n - 1] - lex) / 3;
-      uz[1] = lez + (z64[n - 1] - lez) / 3;
-    } else {
-      ux[1] = lex;
-      uz[1] = lez;
+march_finish_sym(float* acc_u, float* acc_w, const MarchState* S, const long long* n_old_p, int nfoil, float vc4, double dt,
+                 double* x64, double* z64, float* xh, float* xl, float* zh, float* zl, const float* g32, TailDuty td) {
+  __shared__ float fx[kBlock + 2], fz[kBlock + 2], fg[kBlock + 2], fxl[HILO ? kBlock + 2 : 1], fzl[HILO ? kBlock + 2 : 1];
+  const int tid = threadIdx.x;
+  const long long n = S->n, n_old = *n_old_p;
+  const int k = (int)(n - n_old);
+  if (tid < nfoil) {
+    fx[tid] = xh[n + tid]; fz[tid] = zh[n + tid]; fg[tid] = g32[n + tid];
+    if (HILO) { fxl[tid] = xl[n + tid]; fzl[tid] = zl[n + tid]; }
+  }
+  if (tid < k) {
+    // the shed vortices as sources, from the copy the solve kept (their wake entries are moved by this kernel)
+    float h, l;
+    split_hilo(S->newv[tid], h, l);
+    fx[nfoil + tid] = h;
+    if (HILO) fxl[nfoil + tid] = l;
+    split_hilo(S->newv[2 + tid], h, l);
+    fz[nfoil + tid] = h;
+    if (HILO) fzl[nfoil + tid] = l;
+    fg[nfoil + tid] = (float)S->newv[4 + tid];
+  }
+  __syncthreads();
+  tail_duty_block0(td, n);
+  const long long i = (long long)blockIdx.x * kBlock + tid;
+  if (i >= n) return;
+  double su, sw;
+  if (i < n_old) {
+    const float s = (float)kInv2PiD;
+    float fu = 0.0f, fw = 0.0f;
+    const float xi = xh[i], zi = zh[i];
+    const float xil = HILO ? xl[i] : 0.0f, zil = HILO ? zl[i] : 0.0f;
+    const int nsrc = nfoil + k;
+    for (int j = 0; j < nsrc; ++j) {
+      float dx = xi - fx[j], dz = zi - fz[j];
+      if (HILO) { dx += xil - fxl[j]; dz += zil - fzl[j]; }
+      const float r2 = __builtin_fmaf(dz, dz, dx * dx);
+      const float kk = fg[j] * __builtin_amdgcn_rsqf(__builtin_fmaf(r2, r2, vc4));
+      fu = __builtin_fmaf(dz, kk, fu);
+      fw = __builtin_fmaf(dx, kk, fw);
     }
+    su = (double)((acc_u[i] + fu) * s);
+    sw = (double)(-(acc_w[i] + fw) * s);
+    acc_u[i] = 0.0f;
+    acc_w[i] = 0.0f;
+  } else {
+    const int q = (int)(i - n_old);
+    su = S->newvel[q];
+    sw = S->newvel[2 + q];
   }
-  // no hazard on S->place: it is read above only when tail == 0 and written here only when tail != 0
-  if (gtid == 0 && tail != 0) { S->place[0] = ux[0]; S->place[1] = ux[1]; S->place[2] = uz[0]; S->place[3] = uz[1]; }
-  if (col >= 2 * nt) return;   // whole wavefronts leave together
-  const long long k = col / nt, p = col - k * nt;
-  double acc = 0.0;
-  if (part != nullptr) {
-    const double* c0 = part + k * nt_pad + p;
-    for (int sidx = lane; sidx < nsplit; sidx += 64) acc += c0[(long long)sidx * 2 * nt_pad];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  } else if (nsplit == 1) {
-    acc = direct_u[k * nt_pad + p];
-  }
-  if (lane != 0) return;
-  double* out = S->chord;
-  out[k * nt + p] = acc;
-  const double dx = xt[p] - ux[k];
-  const double dz = zt[p] - uz[k];
-  const double r2 = __builtin_fma(dz, dz, dx * dx);
-  const double s = kInv2PiD * rsqrt_f64(__builtin_fma(r2, r2, vc4));
-  out[2 * nt + (k * 2 + 0) * nt + p] = dz * s;
-  out[2 * nt + (k * 2 + 1) * nt + p] = -dx * s;
+  const double xn = x64[i] + dt * su;
+  const double zn = z64[i] + dt * sw;
+  x64[i] = xn;
+  z64[i] = zn;
+  split_hilo(xn, xh[i], xl[i]);
+  split_hilo(zn, zh[i], zl[i]);
+  tail_duty(td, i, n, xn, zn);
 }
 
 }  // namespace ludvm

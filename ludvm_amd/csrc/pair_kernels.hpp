@@ -390,15 +390,63 @@ __device__ __forceinline__ void split_hilo(double v, float& hi, float& lo) {
   lo = (float)(v - (double)hi);
 }
 
+// Device-resident march: what the Euler finisher leaves for the coming time step (march_kernels.hpp), done by the
+// threads that have the data in their hands.  The thread that has just moved the newest TEV / LEV places the
+// next ones one third of the way from the shedding edge (LUDVM.py:680-681, :797-800); block 0 copies the coming
+// step's chord points next to them: tgt = x[npan + 2] | z[npan + 2] are the targets of the fp64 wake -> chord
+// launch (chord points, TEV placement, LEV placement).  kin_next = the coming step's kinematics row
+// [alpha, alpha_dot, h_dot, te_x, te_z, le_x, le_z, xg[npan], zg[npan]]; null S = not a march.
+struct TailDuty {
+  double* place;          // tev_x, lev_x, tev_z, lev_z of the coming step
+  double* tgt;
+  long long* n_old;       // wake size after this roll-up
+  const int* tail;        // vortices shed by the step being rolled up (1 or 2)
+  const int* shed;        // ... and whether a LEV was among them
+  const double* kin_next;
+  int npan;
+};
+
+__device__ __forceinline__ void tail_duty(const TailDuty& td, long long i, long long n, double xn, double zn) {
+  if (td.kin_next == nullptr) return;
+  const int np = td.npan;
+  const int tail = *td.tail;
+  if (i == n - tail) {
+    const double tex = td.kin_next[3], tez = td.kin_next[4];
+    const double px = tex + (xn - tex) / 3, pz = tez + (zn - tez) / 3;
+    td.place[0] = px; td.place[2] = pz;
+    td.tgt[np] = px; td.tgt[np + 2 + np] = pz;
+  }
+  if (i == n - 1) {
+    const double lex = td.kin_next[5], lez = td.kin_next[6];
+    double px = lex, pz = lez;
+    if (*td.shed && tail == 2) { px = lex + (xn - lex) / 3; pz = lez + (zn - lez) / 3; }
+    td.place[1] = px; td.place[3] = pz;
+    td.tgt[np + 1] = px; td.tgt[np + 2 + np + 1] = pz;
+  }
+}
+
+// The part of the duty that does not depend on a vortex: called by every thread of the finisher BEFORE the
+// threads without a vortex leave (a young wake is smaller than the number of chord points).
+__device__ __forceinline__ void tail_duty_block0(const TailDuty& td, long long n) {
+  if (td.kin_next == nullptr || blockIdx.x != 0) return;
+  const int np = td.npan;
+  for (int t = threadIdx.x; t < np; t += blockDim.x) {
+    td.tgt[t] = td.kin_next[7 + t];
+    td.tgt[np + 2 + t] = td.kin_next[7 + np + t];
+  }
+  if (threadIdx.x == 0) *td.n_old = n;
+}
+
 // Resident-wake Euler step (LUDVM.py:1108-1127): float64 update of the master copy from the summed
 // partials (T = float for the fp32 kernels, double for the fp64 one), refresh of the fp32 mirrors.
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 finish_wake_advect(const T* part, long long nt, long long nt_pad, int nsplit, double dt, double* x64, double* z64,
                    float* xh, float* xl, float* zh, float* zl, double* u_out, double* w_out,
-                   const long long* n_dev = nullptr) {
+                   const long long* n_dev = nullptr, TailDuty td = TailDuty{}) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (n_dev) nt = *n_dev;          // device-resident march: the wake size lives on the device
+  tail_duty_block0(td, nt);
   if (i >= nt) return;
   T su, sw;
   sum_splits(part, i, nt_pad, nsplit, su, sw);
@@ -409,6 +457,7 @@ finish_wake_advect(const T* part, long long nt, long long nt_pad, int nsplit, do
   z64[i] = zn;
   split_hilo(xn, xh[i], xl[i]);
   split_hilo(zn, zh[i], zl[i]);
+  tail_duty(td, i, nt, xn, zn);
 }
 
 // Refresh the fp32 mirrors of [first, first+count) after a host write of the float64 master.

@@ -271,7 +271,7 @@ template <bool HILO>
 __global__ void __launch_bounds__(kBlock)
 finish_wake_advect_sym(const float* acc_u, const float* acc_w, long long nt, int nfoil, float vc4, double dt, double* x64,
                        double* z64, float* xh, float* xl, float* zh, float* zl, const float* g32, double* u_out,
-                       double* w_out, const long long* n_dev = nullptr) {
+                       double* w_out, const long long* n_dev = nullptr, TailDuty td = TailDuty{}) {
   __shared__ float fx[kBlock], fz[kBlock], fg[kBlock], fxl[HILO ? kBlock : 1], fzl[HILO ? kBlock : 1];
   const int tid = threadIdx.x;
   if (n_dev) nt = *n_dev;          // device-resident march: the wake size lives on the device
@@ -280,6 +280,7 @@ finish_wake_advect_sym(const float* acc_u, const float* acc_w, long long nt, int
     if (HILO) { fxl[tid] = xl[nt + tid]; fzl[tid] = zl[nt + tid]; }
   }
   __syncthreads();
+  tail_duty_block0(td, nt);
   const long long i = (long long)blockIdx.x * kBlock + tid;
   if (i >= nt) return;
   const float s = (float)kInv2PiD;
@@ -304,6 +305,7 @@ finish_wake_advect_sym(const float* acc_u, const float* acc_w, long long nt, int
   z64[i] = zn;
   split_hilo(xn, xh[i], xl[i]);
   split_hilo(zn, zh[i], zl[i]);
+  tail_duty(td, i, nt, xn, zn);
 }
 
 }  // namespace ludvm

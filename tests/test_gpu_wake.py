@@ -453,3 +453,57 @@ def test_march_rejects_bad_calls(eng):
     st[0] = 3                                # not the current wake size
     with pytest.raises(LudvmHipError):
         eng.march_run(1, 2, "f32", st)
+
+
+@pytest.mark.parametrize("precision,win", [
+    ("f32", {50: 1e-5, 75: 1e-3, 100: 1e-1}),
+    ("f32x2", {50: 1e-6, 75: 1e-4, 100: 1e-2}),
+])
+def test_march_overlapped_steps_against_golden(precision, win, g2):
+    """Overlapped march steps (symmetric kernel on the old wake beside chord sums + solve on a second stream; the
+    shed vortices handled apart) normally start at 16 384 vortices; with the threshold lowered to 128 the README
+    case runs them from step ~100 on... so a second, lower threshold of 8 covers the golden windows too: same
+    bounds against the reference's golden run as the per-step fp32 tiers (test_time_loop_config1_fp32_tier_T2)."""
+    from ludvm_amd import Engine, LUDVM
+    e = Engine(0)
+    try:
+        e.set_symmetric(8)
+        sim = LUDVM(**CONFIG1, verbose=False, engine=e, precision=precision, history="sparse", snapshot_steps=[1, 2, 10, 50])
+        assert np.array_equal(sim.LEV_shed, g2["LEV_shed"])
+        for s in (1, 2, 10, 50):
+            for key in ("TEV", "LEV"):
+                row, gold = sim.path[key][s], g2[f"{key}_{s}"]
+                np.testing.assert_allclose(row, gold[:, :row.shape[1]], rtol=0, atol=1e-5, err_msg=f"{key}@{s}")
+        for name in ("Cl", "Cd", "Cm"):
+            for hi, tol in win.items():
+                assert np.abs(getattr(sim, name)[:hi] - g2[name][:hi]).max() <= tol, (name, hi)
+            assert abs(np.mean(getattr(sim, name)[200:]) - np.mean(g2[name][200:])) <= 5e-2, name
+        c = sim.circulation
+        assert abs(c["bound"][399] + c["TEV"].sum() + c["LEV"].sum() - c["IC"]) < 1e-9      # Kelvin
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("threshold", [8, 100, 300])
+def test_march_overlapped_steps_match_the_per_step_path(threshold):
+    """Same run, same symmetric threshold, marched (serial steps, then overlapped ones from `threshold` vortices)
+    and per step: results agree at the fp32 level while the flow has not amplified the difference (the march takes
+    the velocity of the vortices shed in a step from the fp64 chord launch, the per-step path from the fp32 pair
+    kernel), with identical LEV shedding."""
+    from ludvm_amd import Engine, LUDVM
+    e = Engine(0)
+    try:
+        e.set_symmetric(threshold)
+        kw = dict(CONFIG1, tf=12)
+        a = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse", march=True)
+        b = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse", march=False)
+        assert np.array_equal(a.LEV_shed, b.LEV_shed)
+        assert (a.itev, a.ilev) == (b.itev, b.ilev)
+        for name in ("Cl", "Cd", "Cm"):
+            d = np.abs(getattr(a, name) - getattr(b, name))
+            # by step 100 each fp32 trajectory is up to 2.6e-2 from the golden run (tier T2 allows 1e-1 there)
+            assert d[:60].max() <= 2e-5 and d[:100].max() <= 1e-1, (name, d[:60].max(), d[:100].max())
+        assert np.abs(a.circulation["TEV"][:60] - b.circulation["TEV"][:60]).max() <= 1e-5
+        assert a.path["TEV"][a.nt - 1].shape == b.path["TEV"][b.nt - 1].shape
+    finally:
+        e.close()

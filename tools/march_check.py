@@ -15,10 +15,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ludvm_amd import LUDVM  # noqa: E402
 
 
+ENG = None
+
+
 def run(march, a):
+    global ENG
+    if ENG is None:
+        from ludvm_amd import Engine
+        ENG = Engine(0)
+        if getattr(a, "sym_threshold", 0):
+            ENG.set_symmetric(a.sym_threshold)     # symmetric kernel (and overlapped march steps) from this wake size
     t0 = time.perf_counter()
     s = LUDVM(t0=0, tf=a.tf, dt=a.dt, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2, Naca='0012',
-              verbose=False, precision=a.precision, history='sparse', march=march)
+              verbose=False, precision=a.precision, history='sparse', march=march, engine=ENG)
     return s, time.perf_counter() - t0
 
 
@@ -27,12 +36,14 @@ def main():
     ap.add_argument("--tf", type=float, default=20.0)
     ap.add_argument("--dt", type=float, default=5e-2)
     ap.add_argument("--precision", default="f64")
+    ap.add_argument("--sym-threshold", type=int, default=0, help="wake size from which the symmetric kernel is used "
+                    "(0 = library default 16384); small values exercise the overlapped march steps on short runs")
     a = ap.parse_args()
-    run(True, argparse.Namespace(tf=1.0, dt=a.dt, precision=a.precision))   # warm-up (library load, allocations)
+    run(True, argparse.Namespace(tf=1.0, dt=a.dt, precision=a.precision, sym_threshold=a.sym_threshold))   # warm-up (library load, allocations)
     sm, tm = run(True, a)
     sp, tp = run(False, a)
     nt = sm.nt
-    out = {"nt": nt, "precision": a.precision, "wall_march_s": tm, "wall_per_step_s": tp,
+    out = {"nt": nt, "precision": a.precision, "sym_threshold": a.sym_threshold, "wall_march_s": tm, "wall_per_step_s": tp,
            "lev_pattern_identical": bool(np.array_equal(sm.LEV_shed != -1, sp.LEV_shed != -1)),
            "n_lev": int((sm.LEV_shed != -1).sum())}
     for lo, hi in ((1, 50), (50, 100), (100, 200), (200, nt)):
