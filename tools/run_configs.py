@@ -65,7 +65,7 @@ def cfg5(args):
 def cfg2(args):
     from ludvm_amd import LUDVM, Engine
     eng = Engine(0)
-    eng.kernel_timing(True)
+    eng.kernel_timing(not args.no_timing)    # per-launch events (two per pair-kernel launch)
     t0 = time.perf_counter()
     sim = LUDVM(t0=0, tf=args.tf, dt=1e-3, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2,
                 Naca="0012", verbose=args.verbose, engine=eng, precision=args.precision, history="sparse",
@@ -98,5 +98,6 @@ if __name__ == "__main__":
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--no-march", action="store_true", help="cfg2: one device round trip per time step")
+    ap.add_argument("--no-timing", action="store_true", help="cfg2: no per-launch timing events (kernel_ms_total reads 0)")
     a = ap.parse_args()
     {"cfg5": cfg5, "cfg2": cfg2}[a.which](a)
