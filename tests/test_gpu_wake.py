@@ -428,16 +428,24 @@ def test_march_checkpoint_and_resume(eng, tmp_path):
 
 
 def test_march_config2_regime_against_the_oracle(eng):
-    """BASELINE config 2's parameters (dt = 1e-3) over the first 300 steps, marched, against the oracle."""
+    """BASELINE config 2's parameters (dt = 1e-3) over the first 600 steps, marched, against the oracle.  600 steps is
+    as far as rounding-level agreement can be asked for here: two CPU float64 runs of the oracle that differ only
+    in summation order separate from there on (profiles/r01_oracle_sensitivity_cfg2.txt)."""
     from ludvm_amd import LUDVM
-    kw = dict(CONFIG1, dt=1e-3, tf=0.3)
+    kw = dict(CONFIG1, dt=1e-3, tf=0.6)
     ref = O.OracleLUDVM(**kw)
-    for prec, tol_load, tol_pos in (("f64", 1e-9, 1e-11), ("f32x2", 1e-5, 1e-6), ("f32", 1e-3, 1e-4)):
+    assert ref.nt == 601
+    # positions feel the growing mode first: at step 600 they differ by 8e-10 in fp64 mode while the loads still agree
+    # to 6e-13, and single vortices inside the wound-up starting vortex by 1e-3 in the fp32 modes (loads: 3e-7), so
+    # positions are bounded for fp64 only here (test_config2_regime_first_300_steps bounds them for the fp32 modes)
+    for prec, tol_load, tol_pos in (("f64", 1e-9, 1e-8), ("f32x2", 1e-5, None), ("f32", 1e-3, None)):
         sim = LUDVM(**kw, verbose=False, engine=eng, precision=prec, history="sparse")
         assert np.array_equal(sim.LEV_shed, ref.LEV_shed), prec
         for name in ("Cl", "Cd", "Cm"):
             assert np.abs(getattr(sim, name) - getattr(ref, name)).max() <= tol_load * max(1.0, np.abs(getattr(ref, name)).max()), (prec, name)
-        assert np.abs(sim.path["TEV"][sim.nt - 1] - ref.path["TEV"][-1]).max() <= tol_pos, prec
+        k = sim.itev + 1
+        if tol_pos is not None:
+            assert np.abs(sim.path["TEV"][sim.nt - 1] - ref.path["TEV"][-1][:, :k]).max() <= tol_pos, prec
         assert np.abs(sim.circulation["TEV"] - ref.circulation["TEV"]).max() <= tol_load, prec
 
 
