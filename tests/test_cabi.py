@@ -78,3 +78,25 @@ def test_single_hip_runtime_whatever_the_import_order():
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.splitlines()[0] == "2", out.stdout      # one HIP runtime + one HSA runtime
+
+
+def test_every_entry_point_rejects_a_null_context():
+    """No entry point may dereference a NULL context: all of them return LUDVM_E_ARG (none needs a GPU for that)."""
+    import ctypes
+    lib = _ffi.load()
+    skipped = {"ludvm_abi_version", "ludvm_create", "ludvm_last_error"}
+    for name, argtypes in _ffi.SIGNATURES.items():
+        if name in skipped:
+            continue
+        args = []
+        for t in argtypes[1:]:
+            if t in (ctypes.c_int, ctypes.c_longlong, ctypes.c_size_t):
+                args.append(0)
+            elif t in (ctypes.c_double, ctypes.c_float):
+                args.append(0.0)
+            else:
+                args.append(None)      # every pointer type, c_void_p and c_char_p included
+        rc = getattr(lib, name)(None, *args)
+        assert rc == _ffi.E_ARG, (name, rc)
+    assert lib.ludvm_last_error(None) == b"null context"
+    assert lib.ludvm_create(0, None) != _ffi.OK          # null output pointer
