@@ -12,7 +12,8 @@ A "step" is one pass of the hot path over the synthetic wake held in HBM:
     the positions (ludvm_amd/sharded.py).  Total work per step is fixed (N^2 pairs): strong scaling.
 value = ordered pair interactions (self pairs count) of all ranks / wall time, max over ranks.
 
-Prints ONE JSON line on rank 0.  Synthetic inputs follow SURVEY.md section 8(d):
+Prints ONE JSON line on rank 0's stdout (everything else that libraries print there, e.g. RCCL's version
+banner, is routed to stderr).  Synthetic inputs follow SURVEY.md section 8(d):
 rng = default_rng(20260101); x ~ U(-10,0), z ~ U(-2,2), Gamma ~ N(0,1)/N; v_core = 0.065.
 """
 import argparse
@@ -86,6 +87,13 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work at most")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON.  Libraries write there too (RCCL prints a version banner when a
+    # communicator is created, gloo likewise), so file descriptor 1 is pointed at stderr for the whole run and the
+    # JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from ludvm_amd import Engine
@@ -109,11 +117,18 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # LUDVM_BENCH_FORCE_DIST=1: create the process group even for one rank (tests: the real RCCL backend on a
+    # one-GPU box); the single-rank workload and its code path are unchanged
+    force_dist = world == 1 and os.environ.get("LUDVM_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_dist:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=backend)
+    if force_dist:
+        t1 = torch.ones(4, dtype=torch.float32, device=device)
+        dist.all_reduce(t1)                       # builds the communicator (and prints whatever RCCL prints)
+        torch.cuda.synchronize()
 
     workload = args.workload if args.workload != "auto" else ("cfg3" if world == 1 else "cfg4")
     n = args.vortices or (1_000_000 if workload == "cfg3" else 8_000_000)
@@ -223,8 +238,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(x, z, g, u_gpu, w_gpu, args.cpu_rows, args.cpu_budget)
         elif world == 1 and args.cpu_rows > 0:
             out["cpu_baseline"] = cpu_baseline(x, z, g, None, None, args.cpu_rows, args.cpu_budget)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

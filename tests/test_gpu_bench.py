@@ -61,3 +61,34 @@ def test_sharded_wake_collectives_on_the_real_rccl_backend():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_one_rank.py")], capture_output=True, text=True,
                        env=env, timeout=300)
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+def _launch(nproc, extra_env, *args):
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *args]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines           # exactly one line on stdout, whatever the libraries print
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_through_the_launcher():
+    """The driver's launch line for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), rehearsed with two
+    ranks sharing the one card over gloo (LUDVM_BENCH_BACKEND): config 4's sharded step, MAX-over-ranks timing, one
+    JSON line from rank 0."""
+    d = _launch(2, {"LUDVM_BENCH_BACKEND": "gloo"}, "--vortices", "120000", "--steps", "2", "--warmup", "1")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "config 4" in d["config"]["workload"]
+    assert d["config"]["collective_backend"] == "gloo" and d["config"]["kernel_variant"] == "symmetric"
+    assert abs(d["value"] - 120000.0**2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+
+
+def test_bench_stdout_is_one_line_with_the_rccl_backend_initialised():
+    """RCCL prints a version banner on stdout when a communicator is created; the JSON line must still be the only
+    thing there.  One rank, real "nccl" backend (LUDVM_BENCH_FORCE_DIST=1)."""
+    d = _launch(1, {"LUDVM_BENCH_FORCE_DIST": "1"}, "--vortices", "40000", "--steps", "2", "--warmup", "1", "--cpu-rows", "32")
+    assert d["n_gpus"] == 1 and "config 3" in d["config"]["workload"] and d["cpu_baseline"]["gpu_vs_oracle_max_rel_err"] < 1e-5
