@@ -515,3 +515,58 @@ def test_march_overlapped_steps_match_the_per_step_path(threshold):
         assert a.path["TEV"][a.nt - 1].shape == b.path["TEV"][b.nt - 1].shape
     finally:
         e.close()
+
+
+def test_march_variants_against_goldens_and_oracle(eng):
+    """Marched runs away from the README case: user free vortices and a non-zero mean angle against the reference's
+    golden runs (G5), and another panel / coefficient count against the oracle."""
+    from ludvm_amd import LUDVM
+    g = load_golden("g5_freevort.npz")
+    sim = LUDVM(**dict(CONFIG1, tf=5, circulation_freevort=g["gamma_freevort"], xy_freevort=g["xy_freevort"]),
+                verbose=False, engine=eng, precision="f64", history="sparse", snapshot_steps=[10])
+    assert np.array_equal(sim.LEV_shed, g["LEV_shed"])
+    for name in ("Cl", "Cd", "Cm"):
+        assert np.abs(getattr(sim, name) - g[name]).max() <= 1e-6, name
+    np.testing.assert_allclose(sim.path["FREE"][10], g["FREE_10"], rtol=0, atol=1e-9)
+
+    g = load_golden("g5_alpham.npz")
+    sim = LUDVM(**dict(CONFIG1, tf=5, alpha_m=5, alpha_max=15), verbose=False, engine=eng, precision="f64", history="sparse")
+    assert np.array_equal(sim.LEV_shed, g["LEV_shed"])
+    for name in ("Cl", "Cd", "Cm", "LESP"):
+        assert np.abs(getattr(sim, name) - g[name]).max() <= 1e-7, name
+
+    kw = dict(CONFIG1, tf=4, Npoints=41, Ncoeffs=12, LESPcrit=0.15)
+    ref = O.OracleLUDVM(**kw)
+    sim = LUDVM(**kw, verbose=False, engine=eng, precision="f64", history="sparse")
+    assert np.array_equal(sim.LEV_shed, ref.LEV_shed) and (ref.LEV_shed != -1).any()
+    for name in ("Cl", "Cd", "Cm"):
+        assert np.abs(getattr(sim, name) - getattr(ref, name)).max() <= 1e-9, name
+    assert np.abs(sim.fourier - ref.fourier).max() <= 1e-8
+    assert np.abs(sim.circulation["gamma_airfoil"] - ref.circulation["gamma_airfoil"]).max() <= 1e-8
+
+
+def test_march_overlapped_in_several_calls_and_resumed(tmp_path):
+    """Overlapped steps (symmetric threshold lowered to 8) cut into several ludvm_march_run calls, and continued from
+    a checkpoint: the accumulators, the double-buffered old wake size and the second stream start afresh in every
+    call."""
+    from ludvm_amd import Engine, LUDVM
+    e = Engine(0)
+    try:
+        e.set_symmetric(8)
+        kw = dict(CONFIG1, tf=8)
+        one = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse")
+        cut = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse", run=False)
+        cut._march_chunk = 23
+        cut.time_loop()
+        cut.compute_coefficients()
+        ck = str(tmp_path / "ck_ov.npz")
+        LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse", checkpoint_every=40, checkpoint_path=ck)
+        res = LUDVM.resume(ck, engine=e, verbose=False)
+        for other in (cut, res):
+            assert np.array_equal(one.LEV_shed, other.LEV_shed)
+            for name in ("Cl", "Cd", "Cm"):
+                d = np.abs(getattr(one, name) - getattr(other, name))
+                assert d[:60].max() <= 2e-5 and d.max() <= 1e-1, (name, d[:60].max(), d.max())
+            assert (one.itev, one.ilev) == (other.itev, other.ilev)
+    finally:
+        e.close()
