@@ -489,6 +489,31 @@ cvt_f32_to_f64(const float* in, double* out, long long n) {
   if (i < n) out[i] = (double)in[i];
 }
 
+// Small stateless calls: the five float64 input arrays arrive in one packed upload, in = xs[ns] | zs[ns] | gs[ns] |
+// xt[nt] | zt[nt]; one launch splits them into the fp32 (hi, lo) arrays the kernels read.
+__global__ void __launch_bounds__(kBlock)
+cvt_packed_inputs(const double* in, long long ns, long long nt, float* xs, float* xsl, float* zs, float* zsl, float* gs,
+                  float* xt, float* xtl, float* zt, float* ztl) {
+  const long long k = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= 3 * ns + 2 * nt) return;
+  const double v = in[k];
+  float h, l;
+  split_hilo(v, h, l);
+  if (k < ns) { xs[k] = h; xsl[k] = l; }
+  else if (k < 2 * ns) { zs[k - ns] = h; zsl[k - ns] = l; }
+  else if (k < 3 * ns) { gs[k - 2 * ns] = h; }
+  else if (k < 3 * ns + nt) { xt[k - 3 * ns] = h; xtl[k - 3 * ns] = l; }
+  else { zt[k - 3 * ns - nt] = h; ztl[k - 3 * ns - nt] = l; }
+}
+
+// ... and the two fp32 results leave as one float64 block out = u[nt] | w[nt].
+__global__ void __launch_bounds__(kBlock)
+cvt_packed_outputs(const float* u, const float* w, double* out, long long nt) {
+  const long long k = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= 2 * nt) return;
+  out[k] = k < nt ? (double)u[k] : (double)w[k - nt];
+}
+
 // Velocity induced at nt points by n_unit unit-strength vortices (the new TEV / LEV of a time step,
 // LUDVM.py:751, :926, :931), fp64: out[(k*2 + 0)*nt + p] = u, out[(k*2 + 1)*nt + p] = w.
 __global__ void __launch_bounds__(kBlock)
