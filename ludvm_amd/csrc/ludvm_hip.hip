@@ -1175,6 +1175,10 @@ int ludvm_march_setup(ludvm_ctx* c, int npan, int ncoef, const double* scalars, 
   c->march_vcore = scalars[5];
   m.kelvin0 = scalars[7] - scalars[6];          // sum(Gamma_free) - IC
   m.vc4 = (scalars[5] * scalars[5]) * (scalars[5] * scalars[5]);
+  m.method = scalars[8] != 0.0 ? 1 : 0;
+  m.maxerror = scalars[9]; m.maxiter = (int)scalars[10]; m.epsilon = scalars[11];
+  if (m.method == 1 && !(m.maxerror > 0.0 && m.maxiter >= 1 && m.epsilon > 0.0))
+    return fail(c, LUDVM_E_ARG, "march: 'Ramesh' needs maxerror > 0, maxiter >= 1, epsilon > 0");
   const double* t = static_cast<const double*>(c->march_tab.p);
   m.detadx = t; m.eta = t + P; m.xpan = t + 2 * P; m.cm1 = t + 3 * P; m.wq = t + 4 * P; m.opcs = t + 5 * P;
   m.hcsd = t + 6 * P; m.wx = t + 7 * P; m.cproj = t + 8 * P; m.ssin = t + 8 * P + (size_t)ncoef * P;

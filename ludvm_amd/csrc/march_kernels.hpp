@@ -49,6 +49,9 @@ struct MarchSetup {
   int npan, ncoef;
   double U, chord, rho, dt, piv, kelvin0;   // kelvin0 = sum(Gamma_free) - IC  (:758)
   double vc4;
+  int method;                               // 0: 'Faure' (closed forms), 1: 'Ramesh' (Newton iterations, :683-739, :807-914)
+  int maxiter;
+  double maxerror, epsilon;
   // packed tables (device): see ludvm_march_setup in include/ludvm_hip.h
   const double* detadx; const double* eta; const double* xpan; const double* cm1; const double* wq;
   const double* opcs; const double* hcsd; const double* wx; const double* cproj; const double* ssin;
@@ -98,6 +101,49 @@ __device__ __forceinline__ void unit_pair_f64(double xp, double zp, double xs, d
   const double s = kInv2PiD * rsqrt_f64(__builtin_fma(r2, r2, vc4));
   u = dz * s;
   w = -dx * s;
+}
+
+// 'Ramesh' residuals.  The downwash is linear in the circulations being solved for, W = T1 + gt T2 + gl T3, so the
+// reference's residual  U c pi (A0 + A1 / 2) + kelvin + (gt + gl)  with A0, A1 projected from W (:692-700, :820-835)
+// needs only the six projections p0[k] = cproj[0] . T_k / U, p1[k] = cproj[1] . T_k / U.
+struct RameshProj { double p0[3], p1[3], ucpi, kelvin; };
+__device__ __forceinline__ double ramesh_res(const RameshProj& r, double gt, double gl, double& A0) {
+  A0 = r.p0[0] + gt * r.p0[1] + gl * r.p0[2];
+  const double A1 = r.p1[0] + gt * r.p1[1] + gl * r.p1[2];
+  return r.ucpi * (A0 + A1 / 2) + r.kelvin + (gt + gl);
+}
+// Newton with a forward-difference slope, start -1, as the reference iterates it (:683-739)
+__device__ __forceinline__ double ramesh_tev(const RameshProj& r, double maxerror, int maxiter, double eps) {
+  double f = 1.0, g = -1.0, A0;
+  int niter = 1;
+  while (fabs(f) > maxerror && niter < maxiter) {
+    f = ramesh_res(r, g, 0.0, A0);
+    const double fd = ramesh_res(r, g + eps, 0.0, A0);
+    g = g - f / ((fd - f) / eps);
+    niter += 1;
+  }
+  return g;
+}
+// 2x2 Newton for (Gamma_LEV, Gamma_TEV) with the LESP condition as second equation (:807-914)
+__device__ __forceinline__ void ramesh_tev_lev(const RameshProj& r, double lesp_crit, double guess, double maxerror, int maxiter,
+                                               double eps, double& g_tev, double& g_lev) {
+  g_tev = guess; g_lev = guess;
+  double f1 = 0.1, f2 = 0.1;
+  int niter = 1;
+  while ((fabs(f1) > maxerror || fabs(f2) > maxerror) && niter < maxiter) {
+    double A0;
+    f1 = ramesh_res(r, g_tev, g_lev, A0);
+    f2 = lesp_crit - A0;
+    const double f1t = ramesh_res(r, g_tev + eps, g_lev, A0);
+    const double f2t = lesp_crit - A0;
+    const double f1l = ramesh_res(r, g_tev, g_lev + eps, A0);
+    const double f2l = lesp_crit - A0;
+    double dl, dt_;
+    solve2((f1l - f1) / eps, (f1t - f1) / eps, (f2l - f2) / eps, (f2t - f2) / eps, f1, f2, dl, dt_);
+    g_lev -= dl;
+    g_tev -= dt_;
+    niter += 1;
+  }
 }
 
 // Start of a march call: the caller supplied the placements of the first step; stage its targets.
@@ -187,7 +233,19 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
   const double I1 = block_sum(t1 * cm1, scratch);
   const double I2 = block_sum(t2 * cm1, scratch);
   const double kelvin = S->sum_tev + S->sum_lev + m.kelvin0;
-  double g_tev = -(I1 + kelvin) / (1 + I2);          // :758-760
+  const bool ramesh = m.method == 1;
+  RameshProj rp{};
+  double g_tev;
+  if (ramesh) {
+    const double c0 = on ? m.cproj[j] / m.U : 0.0, c1 = on ? m.cproj[npan + j] / m.U : 0.0;
+    rp.p0[0] = block_sum(t1 * c0, scratch); rp.p0[1] = block_sum(t2 * c0, scratch); rp.p0[2] = block_sum(t3 * c0, scratch);
+    rp.p1[0] = block_sum(t1 * c1, scratch); rp.p1[1] = block_sum(t2 * c1, scratch); rp.p1[2] = block_sum(t3 * c1, scratch);
+    rp.ucpi = m.U * m.chord * pi;
+    rp.kelvin = kelvin;
+    g_tev = ramesh_tev(rp, m.maxerror, m.maxiter, m.epsilon);
+  } else {
+    g_tev = -(I1 + kelvin) / (1 + I2);               // :758-760
+  }
   double g_lev = 0.0;
   if (on) Wn[j] = (t1 + g_tev * t2) / m.U;
   __syncthreads();
@@ -199,7 +257,8 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
     Ad[j] = (acc - S->prevA[j]) / m.dt;              // :772-773
   }
   __syncthreads();
-  double bound = I1 + g_tev * I2;
+  const double ucpi = m.U * m.chord * pi;
+  double bound = ramesh ? ucpi * (A[0] + A[1] / 2) : I1 + g_tev * I2;     // :761 / :738
   const double lesp_prev = A[0];
   double lesp_crit = S->lesp_crit;
   const bool shed = fabs(A[0]) >= fabs(lesp_crit);   // :781
@@ -210,16 +269,19 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
     const double J1 = -1 / pi * block_sum(t1 * wq, scratch);
     const double J2 = -1 / pi * block_sum(t2 * wq, scratch);
     const double J3 = -1 / pi * block_sum(t3 * wq, scratch);
-    solve2(1 + I2, 1 + I3, J2, J3, -(I1 + kelvin), lesp_crit - J1, g_tev, g_lev);   // :944-954
+    if (ramesh) ramesh_tev_lev(rp, lesp_crit, g_tev, m.maxerror, m.maxiter, m.epsilon, g_tev, g_lev);
+    else solve2(1 + I2, 1 + I3, J2, J3, -(I1 + kelvin), lesp_crit - J1, g_tev, g_lev);   // :944-954
     if (on) Wn[j] = (t1 + g_tev * t2 + g_lev * t3) / m.U;
     __syncthreads();
     if (j < ncoef) {
       double acc = 0.0;
       const double* cp = m.cproj + (long long)j * npan;
       for (int q = 0; q < npan; ++q) acc = __builtin_fma(cp[q], Wn[q], acc);
-      A[j] = j == 0 ? J1 + g_tev * J2 + g_lev * J3 : acc;          // :959; derivatives keep their values (:963-966)
+      // 'Faure' takes A0 from the LESP form (:959); derivatives keep their values in both methods (:963-966)
+      A[j] = (j == 0 && !ramesh) ? J1 + g_tev * J2 + g_lev * J3 : acc;
     }
-    bound = I1 + g_tev * I2 + g_lev * I3;
+    __syncthreads();
+    bound = ramesh ? ucpi * (A[0] + A[1] / 2) : I1 + g_tev * I2 + g_lev * I3;
     __syncthreads();
   }
 

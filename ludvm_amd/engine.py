@@ -257,11 +257,12 @@ class Engine:
 
     def march_setup(self, npan, ncoef, scalars, tables, kin):
         """Upload what a run keeps constant (ludvm_march_setup): scalars [Uinf, chord, rho, dt, piv, v_core, IC,
-        sum(Gamma_free)], the packed chord tables and the per-step kinematics rows [nt, 7 + 2 npan]."""
+        sum(Gamma_free), method (0 Faure / 1 Ramesh), maxerror, maxiter, epsilon], the packed chord tables and the
+        per-step kinematics rows [nt, 7 + 2 npan]."""
         sc, tb = _f64(scalars), _f64(tables)
         kin = np.ascontiguousarray(kin, dtype=np.float64)
-        if kin.ndim != 2 or kin.shape[1] != 7 + 2 * npan or len(sc) != 8:
-            raise ValueError("march_setup: kin must be [nt, 7 + 2 npan] and scalars 8 long")
+        if kin.ndim != 2 or kin.shape[1] != 7 + 2 * npan or len(sc) != 12:
+            raise ValueError("march_setup: kin must be [nt, 7 + 2 npan] and scalars 12 long")
         if len(tb) != 8 * npan + ncoef * npan + (ncoef - 1) * npan:
             raise ValueError("march_setup: wrong table length")
         self._check(self._lib.ludvm_march_setup(self._ctx, int(npan), int(ncoef), _pd(sc), _pd(tb), _pd(kin), kin.shape[0]))

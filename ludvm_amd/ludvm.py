@@ -85,7 +85,7 @@ class LUDVM:
       checkpoint_every, checkpoint_path   write an .npz checkpoint every so many steps (0 = never);
                  `LUDVM.resume(path)` continues such a run (the reference has no checkpointing)
       march      True (default): stretches of time steps whose history row is not recorded run as a
-                 device-resident march (Gamma solve on the GPU, no host round trip per step; 'Faure' method);
+                 device-resident march (Gamma solve on the GPU, no host round trip per step);
                  False: one device round trip per step throughout
     """
 
@@ -418,16 +418,17 @@ class LUDVM:
         have_next = False     # sb already holds step i's placement and chord sums (from the previous wake_step)
 
         # Device-resident march (ludvm_march_setup / ludvm_march_run): stretches of steps whose history row is
-        # not recorded run without a host round trip per step; the per-step path below serves recorded steps,
-        # the 'Ramesh' method and engines without the march.
-        can_march = (self.march and self.method == 'Faure' and hasattr(eng, 'march_run') and npan <= 256
+        # not recorded run without a host round trip per step; the per-step path below serves recorded steps
+        # and engines without the march.
+        can_march = (self.march and self.method in ('Faure', 'Ramesh') and hasattr(eng, 'march_run') and npan <= 256
                      and 4 <= self.Ncoeffs <= 64)
         if can_march:
             tables = np.concatenate([detadx, self.airfoil['eta_panel'], x_gamma, cm1, wq, one_plus_cos_over_sin,
                                      half_c_sin_dth, wx, cproj.ravel(), ssin.ravel()])
             kin = np.concatenate([self.alpha[:, None], self.alpha_dot[:, None], self.h_dot[:, None], foil[:, :, -1],
                                   foil[:, :, 0], gpts[:, 0, :], gpts[:, 1, :]], axis=1)
-            eng.march_setup(npan, self.Ncoeffs, [U, c, rho, dt, self.piv, vc, C['IC'], sum_free], tables, kin)
+            eng.march_setup(npan, self.Ncoeffs, [U, c, rho, dt, self.piv, vc, C['IC'], sum_free,
+                                                  float(self.method == 'Ramesh'), self.maxerror, self.maxiter, self.epsilon], tables, kin)
         march_chunk = int(getattr(self, '_march_chunk', 32768))   # steps per ludvm_march_run call (bounds the returned rows)
 
         i = first_step

@@ -454,8 +454,8 @@ def test_march_rejects_bad_calls(eng):
     st = np.zeros(16 + 30)
     eng.wake_clear()
     with pytest.raises(LudvmHipError):       # setup with too few Fourier coefficients
-        eng.march_setup(80, 3, np.ones(8), np.zeros(8 * 80 + 3 * 80 + 2 * 80), np.zeros([10, 7 + 160]))
-    eng.march_setup(80, 30, np.ones(8), np.zeros(8 * 80 + 30 * 80 + 29 * 80), np.zeros([10, 7 + 160]))
+        eng.march_setup(80, 3, np.ones(12), np.zeros(8 * 80 + 3 * 80 + 2 * 80), np.zeros([10, 7 + 160]))
+    eng.march_setup(80, 30, np.ones(12), np.zeros(8 * 80 + 30 * 80 + 29 * 80), np.zeros([10, 7 + 160]))
     with pytest.raises(LudvmHipError):       # steps outside the kinematics table
         eng.march_run(5, 6, "f32", st)
     st[0] = 3                                # not the current wake size
@@ -570,3 +570,27 @@ def test_march_overlapped_in_several_calls_and_resumed(tmp_path):
             assert (one.itev, one.ilev) == (other.itev, other.ilev)
     finally:
         e.close()
+
+
+def test_march_ramesh_method(eng):
+    """'Ramesh' (Newton iterations for Gamma_TEV and the TEV/LEV pair) marched: against the reference's golden run
+    (G5, 40 steps) and against the oracle over 160 steps with LEV shedding; the march and the per-step path agree."""
+    from ludvm_amd import LUDVM
+    g = load_golden("g5_ramesh.npz")
+    sim = LUDVM(**dict(CONFIG1, tf=2, method="Ramesh"), verbose=False, engine=eng, precision="f64", history="sparse")
+    assert np.array_equal(sim.LEV_shed, g["LEV_shed"]) and (g["LEV_shed"] != -1).any()
+    for name in ("Cl", "Cd", "Cm", "LESP"):
+        assert np.abs(getattr(sim, name) - g[name]).max() <= 1e-7, name
+
+    kw = dict(CONFIG1, tf=8, method="Ramesh")
+    ref = O.OracleLUDVM(**kw)
+    a = LUDVM(**kw, verbose=False, engine=eng, precision="f64", history="sparse", march=True)
+    b = LUDVM(**kw, verbose=False, engine=eng, precision="f64", history="sparse", march=False)
+    for sim in (a, b):
+        assert np.array_equal(sim.LEV_shed, ref.LEV_shed)
+        for name in ("Cl", "Cd", "Cm"):
+            assert np.abs(getattr(sim, name)[:100] - getattr(ref, name)[:100]).max() <= 1e-8, name
+        assert np.abs(sim.circulation["TEV"][:100] - ref.circulation["TEV"][:100]).max() <= 1e-8
+        assert np.abs(sim.circulation["bound"][:100] - ref.circulation["bound"][:100]).max() <= 1e-8
+        assert np.abs(sim.fourier[:100] - ref.fourier[:100]).max() <= 1e-6
+    assert np.abs(a.Cl[:100] - b.Cl[:100]).max() <= 1e-9
