@@ -76,8 +76,10 @@ class LUDVM:
     the whole simulation runs inside the constructor.  Keyword-only extras:
       engine     an existing ludvm_amd.engine.Engine to use (default: a new one on `device`)
       device     HIP device ordinal
-      precision  'f32' (default), 'f32x2' (hi+lo fp32 positions) or 'f64': arithmetic of the
-                 wake-on-wake pair sums; the Npanels-target sums always run in fp64
+      precision  arithmetic of the wake-on-wake pair sums: 'f32', 'f32x2' (hi+lo fp32 positions), 'f64', or 'auto'
+                 (default): 'f64' for runs short enough to keep the reference's dense history (nt <= 2001, wake
+                 <= 4000 vortices: fp64 costs nothing there and the reference's numbers are reproduced to ~1e-5
+                 over the whole run), 'f32' beyond.  The Npanels-target sums always run in fp64
       history    'full' (dense path arrays as in the reference), 'sparse' (rows only at
                  snapshot_steps + last step) or 'auto' (full up to nt = 2001)
       snapshot_steps  iterable of time-step indices to record when history is sparse
@@ -95,7 +97,7 @@ class LUDVM:
                  alpha_max=10, k=0.2 * np.pi, phi=90, h_max=1,
                  verbose=True, method='Faure',
                  circulation_freevort=None, xy_freevort=None, *,
-                 engine=None, device=0, precision='f32', history='auto', snapshot_steps=(), run=True,
+                 engine=None, device=0, precision='auto', history='auto', snapshot_steps=(), run=True,
                  checkpoint_every=0, checkpoint_path=None, march=True):
         self._ctor = dict(t0=t0, tf=tf, dt=dt, chord=chord, rho=rho, Uinf=Uinf, Npoints=Npoints, Ncoeffs=Ncoeffs,
                           LESPcrit=LESPcrit, Naca=Naca, foil_filename=foil_filename, G=G, T=T, alpha_m=alpha_m,
@@ -127,8 +129,12 @@ class LUDVM:
             self.circulation_freevort = np.array([0])
             self.xy_freevort = np.array([0, 0])[:, np.newaxis]
 
-        if precision not in ('f32', 'f32x2', 'f64'):
-            raise ValueError("precision must be 'f32', 'f32x2' or 'f64'")
+        if precision not in ('auto', 'f32', 'f32x2', 'f64'):
+            raise ValueError("precision must be 'auto', 'f32', 'f32x2' or 'f64'")
+        if precision == 'auto':
+            # an fp32 rounding difference grows ~10x per 12 steps once the wake rolls up: in fp32
+            # the README case ends 0.1 away from the reference on Cl, in fp64 4e-5 -- at the same speed for small wakes
+            precision = 'f64' if self.nt <= _FULL_HISTORY_MAX_NT else 'f32'
         if history not in ('auto', 'full', 'sparse'):
             raise ValueError("history must be 'auto', 'full' or 'sparse'")
         self.precision = precision
