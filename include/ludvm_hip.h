@@ -220,15 +220,20 @@ int ludvm_wake_step(ludvm_ctx* ctx, const double* new_x, const double* new_z, co
  *   [11] out: vortices shed by the last step (1 or 2)
  *   [12..15] out: x[size-2], x[size-1], z[size-2], z[size-1] after the last roll-up
  *   [16..16+ncoef) Fourier coefficients of the previous step.
- * rows (out): count rows of 10 + 2 ncoef + 2 npan doubles:
+ * rows (out): count rows of 12 + 2 ncoef + 2 npan doubles:
  *   g_tev, g_lev, shed(0/1), bound, LESP_prev, LESP, Fn, Fs, M, wake slot of the new TEV,
- *   A[ncoef], dA/dt[ncoef], gamma[npan], dGamma[npan].
+ *   velocity (u, w) at the origin on a step that sheds no LEV (the reference convects a zero-strength LEV slot
+ *   from there and stores where it lands, :1112-1118), A[ncoef], dA/dt[ncoef], gamma[npan], dGamma[npan].
+ * hist (out, may be NULL): the reference's dense trajectory history (:1108-1127) -- after each step's roll-up the
+ *   positions of all wake vortices, count rows of x[hist_nmax] | z[hist_nmax] in wake (shedding) order;
+ *   hist_nmax >= wake size + 2 count.
  * Synchronous: returns when the last step has finished.  `precision` selects the roll-up arithmetic as in
  * ludvm_wake_advect; the solve is float64.  From the symmetric-kernel threshold on, a step's chord sums and solve run on
  * a second stream beside the symmetric kernel (environment LUDVM_MARCH_OVERLAP=0 keeps every step serial). */
 int ludvm_march_setup(ludvm_ctx* ctx, int npan, int ncoef, const double* scalars, const double* tables, const double* kin,
                       size_t kin_rows);
-int ludvm_march_run(ludvm_ctx* ctx, long long first_step, long long count, int precision, double* state, double* rows);
+int ludvm_march_run(ludvm_ctx* ctx, long long first_step, long long count, int precision, double* state, double* rows,
+                    double* hist, size_t hist_nmax);
 
 /* ---- flow field: backs LUDVM.flowfield (LUDVM.py:1186-1298) -------------------------------- */
 

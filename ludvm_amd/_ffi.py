@@ -57,7 +57,7 @@ SIGNATURES = {
     "ludvm_wake_step": [c_void_p, _pd, _pd, _pd, c_size_t, c_double, _pd, _pd, _pd, c_size_t, c_double, c_int, _pd, _pd,
                         c_int, c_size_t, _pd, _pd, c_size_t, _pd, _pd, _pd, _pd, _pd, _pd, _pd, _pd],
     "ludvm_march_setup": [c_void_p, c_int, c_int, _pd, _pd, _pd, c_size_t],
-    "ludvm_march_run": [c_void_p, c_longlong, c_longlong, c_int, _pd, _pd],
+    "ludvm_march_run": [c_void_p, c_longlong, c_longlong, c_int, _pd, _pd, _pd, c_size_t],
     "ludvm_flowfield_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, _pd, _pd, _pd, c_size_t,
                             c_double, _pf, _pf],
     "ludvm_flowfield_dev_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, c_void_p, c_void_p,

@@ -56,7 +56,7 @@ struct ludvm_ctx {
   float *xh = nullptr, *xl = nullptr, *zh = nullptr, *zl = nullptr, *g32 = nullptr;
 
   // device-resident march (ludvm_march_setup / ludvm_march_run)
-  Buf march_tab, march_kin, march_rows, march_state;
+  Buf march_tab, march_kin, march_rows, march_state, march_hist;
   MarchSetup msetup{};
   size_t march_kin_rows = 0;
   double march_vcore = 0.0;
@@ -480,7 +480,7 @@ int ludvm_destroy(ludvm_ctx* c) {
   for (auto& t : c->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   for (auto& t : c->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   void* bufs[] = {c->part.p, c->acc.p, c->arena.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32,
-                  c->march_tab.p, c->march_kin.p, c->march_rows.p, c->march_state.p};
+                  c->march_tab.p, c->march_kin.p, c->march_rows.p, c->march_state.p, c->march_hist.p};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   for (auto& e : c->march_ev)
@@ -1203,12 +1203,12 @@ int ludvm_march_setup(ludvm_ctx* c, int npan, int ncoef, const double* scalars, 
 
 namespace {
 
-// fp64 partial sums of the wake at the npan + 2 targets staged in MarchState (chord points of the coming solve and
-// its two placements), then the finisher that leaves sums and unit influences in the device state.  Launches on
+// fp64 partial sums of the wake at the npan + 3 targets staged in MarchState (chord points of the coming solve, its
+// two placements, the origin), then the finisher that leaves sums and unit influences in the device state.  Launches on
 // c->stream (the caller points it at the second stream for overlapped steps).
 int march_chord_launch(ludvm_ctx* c, long long n_ub) {
   const MarchSetup& m = c->msetup;
-  const size_t P = (size_t)m.npan, NT = P + 2;
+  const size_t P = (size_t)m.npan, NT = P + 3;
   MarchState* S = static_cast<MarchState*>(c->march_state.p);
   PairArgs a{};
   a.xs = c->x64; a.zs = c->z64; a.gs = c->g64;
@@ -1238,13 +1238,14 @@ void march_workspace(const ludvm_ctx* c, long long n_ub, int precision, size_t n
     const size_t elt = precision == LUDVM_PREC_F64 ? 8 : 4;
     part_bytes = std::max(part_bytes, (size_t)p.nsplit * 2 * (size_t)p.nt_pad * elt);
   }
-  Plan q = make_plan(c, (long long)nfoil + 2, nt, LUDVM_PREC_F64);
+  Plan q = make_plan(c, (long long)nfoil + 3, nt, LUDVM_PREC_F64);
   part_bytes = std::max(part_bytes, (size_t)q.nsplit * 2 * (size_t)q.nt_pad * 8);
 }
 
 }  // namespace
 
-int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int precision, double* state, double* rows) {
+int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int precision, double* state, double* rows,
+                    double* hist, size_t hist_nmax) {
   if (!c) return LUDVM_E_ARG;
   if (!c->march_ready) return fail(c, LUDVM_E_STATE, "ludvm_march_setup has not been called");
   if (!valid_precision(precision)) return fail(c, LUDVM_E_ARG, "unknown precision");
@@ -1257,6 +1258,7 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   const long long n0 = (long long)c->wake_n;
   if ((long long)state[0] != n0) return fail(c, LUDVM_E_ARG, "march: state[0] must be the current wake size");
   if (n0 + 2 * count + (long long)nfoil >= (1LL << 32)) return fail(c, LUDVM_E_ARG, "march: wake too large");
+  if (hist && (long long)hist_nmax < n0 + 2 * count) return fail(c, LUDVM_E_ARG, "march: history rows shorter than the wake can get");
   HIPCHK(c, hipSetDevice(c->device));
   // everything that could reallocate happens before the first launch: the steps then run without a host sync
   CHK(wake_grow(c, (size_t)(n0 + 2 * count) + nfoil));
@@ -1267,6 +1269,7 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   CHK(ensure(c, c->part, part_bytes + (1 << 20)));
   if (acc_bytes) CHK(ensure(c, c->acc, acc_bytes + (1 << 20)));
   CHK(ensure(c, c->march_rows, (size_t)count * row_doubles * 8));
+  if (hist) CHK(ensure(c, c->march_hist, (size_t)count * 2 * hist_nmax * 8));
 
   MarchState hs{};
   hs.n = n0;
@@ -1328,7 +1331,11 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
     }
     const double* krow_s = kin + (size_t)s * krow;
     const double* krow_next = (size_t)(s + 1) < c->march_kin_rows ? kin + (size_t)(s + 1) * krow : nullptr;
-    const TailDuty td = make_tail_duty(S, s, krow_next, (int)P);
+    TailDuty td = make_tail_duty(S, s, krow_next, (int)P);
+    if (hist) {
+      td.hist_row = static_cast<double*>(c->march_hist.p) + (size_t)rel * 2 * hist_nmax;
+      td.hist_nmax = (long long)hist_nmax;
+    }
     double* row = drows + (size_t)rel * row_doubles;
     if (!fork) {
       // serial step: chord sums -> solve -> roll-up (direct, or symmetric with its memset) and Euler finisher
@@ -1379,6 +1386,7 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   }
   // results: per-step rows, final state, the two newest wake vortices
   HIPCHK(c, hipMemcpyAsync(rows, drows, (size_t)count * row_doubles * 8, hipMemcpyDeviceToHost, c->stream));
+  if (hist) HIPCHK(c, hipMemcpyAsync(hist, c->march_hist.p, (size_t)count * 2 * hist_nmax * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&hs, S, sizeof(MarchState), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (hs.n < n0 + count || hs.n > n0 + 2 * count) return fail(c, LUDVM_E_STATE, "march: inconsistent wake size on the device");

@@ -4,8 +4,9 @@
 // workgroup per step.
 //
 // Per time step i the device runs, in this order,
-//   pair_f64<128>       fp64 partial sums of the wake at Npanels + 2 targets: the chord points of step i
-//                       (:746, :921) and the two points where step i will shed its TEV and candidate LEV
+//   pair_f64<128>       fp64 partial sums of the wake at Npanels + 3 targets: the chord points of step i
+//                       (:746, :921), the two points where step i will shed its TEV and candidate LEV, and the
+//                       origin (where the reference keeps a zero-strength LEV slot that it convects, :1112-1118)
 //   march_chord_finish  sums the partials; unit influences of those two vortices at the chord points
 //                       (:751, :926-931)                                              -> MarchState
 //   march_solve         T1/T2/T3 downwash rows, Gamma_TEV (and Gamma_LEV when |A0| reaches LESPcrit), Fourier
@@ -36,12 +37,12 @@ struct MarchState {
   int tail;             // vortices appended by the step just solved (1 or 2; 0 before the first one)
   double lesp_crit, sum_tev, sum_lev;
   double place[4];      // coming step: tev_x, lev_x, tev_z, lev_z
-  double pvel[4];       // what the wake induces there: u_tev, u_lev, w_tev, w_lev
+  double pvel[6];       // what the wake induces there and at the origin: u_tev, u_lev, u_org, w_tev, w_lev, w_org
   double newv[6];       // vortices shed by the step just solved, before their roll-up: x0, x1, z0, z1, g0, g1
   double newvel[4];     // ... and their velocities u0, u1, w0, w1 (wake + each other + bound vortices)
   double prevA[kMarchMaxCoef];
   double chord[6 * kMarchMaxPan];          // coming step: u1 | w1 | u_tev | w_tev | u_lev | w_lev at the chord points
-  double tgt[2 * (kMarchMaxPan + 2)];      // targets of the chord launch: x[npan + 2] | z[npan + 2]
+  double tgt[2 * (kMarchMaxPan + 3)];      // targets of the chord launch: x[npan + 3] | z[npan + 3]
 };
 
 // Read-only description of a run, passed by value.
@@ -57,12 +58,13 @@ struct MarchSetup {
   const double* opcs; const double* hcsd; const double* wx; const double* cproj; const double* ssin;
 };
 
-constexpr int kMarchRowHead = 10;   // g_tev, g_lev, shed, bound, LESP_prev, LESP, Fn, Fs, M, slot
+constexpr int kMarchRowHead = 12;   // g_tev, g_lev, shed, bound, LESP_prev, LESP, Fn, Fs, M, slot, phantom u, w
 
 inline TailDuty make_tail_duty(MarchState* S, long long step, const double* kin_next, int npan) {
   TailDuty td;
   td.place = S->place; td.tgt = S->tgt; td.n_old = &S->n_old[(step + 1) & 1]; td.tail = &S->tail; td.shed = &S->shed;
   td.kin_next = kin_next; td.npan = npan;
+  td.hist_row = nullptr; td.hist_nmax = 0;
   return td;
 }
 
@@ -150,24 +152,25 @@ __device__ __forceinline__ void ramesh_tev_lev(const RameshProj& r, double lesp_
 __global__ void __launch_bounds__(kBlock)
 march_begin(MarchState* S, const double* kin, int npan, int slot) {
   const int t = threadIdx.x;
-  if (t < npan) { S->tgt[t] = kin[7 + t]; S->tgt[npan + 2 + t] = kin[7 + npan + t]; }
+  const int ntt = npan + 3;
+  if (t < npan) { S->tgt[t] = kin[7 + t]; S->tgt[ntt + t] = kin[7 + npan + t]; }
   if (t == 0) {
-    S->tgt[npan] = S->place[0]; S->tgt[npan + 1] = S->place[1];
-    S->tgt[npan + 2 + npan] = S->place[2]; S->tgt[npan + 2 + npan + 1] = S->place[3];
+    S->tgt[npan] = S->place[0]; S->tgt[npan + 1] = S->place[1]; S->tgt[npan + 2] = 0.0;
+    S->tgt[ntt + npan] = S->place[2]; S->tgt[ntt + npan + 1] = S->place[3]; S->tgt[ntt + npan + 2] = 0.0;
     S->n_old[slot] = S->n;
   }
 }
 
 // Sums the fp64 partial slabs of the chord launch (one WAVEFRONT per output column, fixed shuffle tree) and
 // evaluates the unit influences of the coming TEV / candidate LEV at the chord points.  Columns: component k
-// (0: u, 1: w) x target p; p < npan is a chord point, p = npan, npan + 1 the two placements.
+// (0: u, 1: w) x target p; p < npan is a chord point, p = npan, npan + 1 the two placements, npan + 2 the origin.
 __global__ void __launch_bounds__(kBlock)
 march_chord_finish(const double* part, long long nt_pad, int nsplit, const double* direct_u, int npan, MarchState* S,
                    double vc4) {
   const long long gtid = (long long)blockIdx.x * kBlock + threadIdx.x;
   const long long col = gtid >> 6;
   const int lane = threadIdx.x & 63;
-  const int ntt = npan + 2;
+  const int ntt = npan + 3;
   if (col >= 2 * ntt) return;   // whole wavefronts leave together
   const int k = (int)(col / ntt), p = (int)(col - (long long)k * ntt);
   double acc = 0.0;
@@ -181,7 +184,7 @@ march_chord_finish(const double* part, long long nt_pad, int nsplit, const doubl
   }
   if (lane != 0) return;
   if (p >= npan) {
-    S->pvel[k * 2 + (p - npan)] = acc;
+    S->pvel[k * 3 + (p - npan)] = acc;
     return;
   }
   double* out = S->chord;
@@ -308,7 +311,8 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
   const long long n0 = S->n;
   const int k = shed ? 2 : 1;
   const double tev_x = S->place[0], lev_x = S->place[1], tev_z = S->place[2], lev_z = S->place[3];
-  const double pu0 = S->pvel[0], pu1 = S->pvel[1], pw0 = S->pvel[2], pw1 = S->pvel[3];
+  const double pu0 = S->pvel[0], pu1 = S->pvel[1], pw0 = S->pvel[3], pw1 = S->pvel[4];
+  const double puo = S->pvel[2], pwo = S->pvel[5];
 
   // Velocity of the vortices shed now, for the roll-up that treats them apart (:1105-1124 restricted to them):
   // the wake's part came with the chord sums; the bound vortices' part is summed here; plus each other.
@@ -324,6 +328,15 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
   }
   const double su0 = block_sum(fu0, scratch), sw0 = block_sum(fw0, scratch);
   const double su1 = block_sum(fu1, scratch), sw1 = block_sum(fw1, scratch);
+  // The reference convects LEV slot `ilev` -- zero strength, at the origin -- on a step that sheds no LEV and stores
+  // where it lands in path['LEV'][i] (:1112-1118); its velocity: wake (chord launch), the new TEV, the bound vortices.
+  double fuo = 0, fwo = 0;
+  if (on && !shed) {
+    double uu, ww;
+    unit_pair_f64(0.0, 0.0, xg[j], zg[j], m.vc4, uu, ww);
+    fuo = dgamma * uu; fwo = dgamma * ww;
+  }
+  const double suo = block_sum(fuo, scratch), swo = block_sum(fwo, scratch);
   __syncthreads();                                   // all reads of S are done; it is rewritten below
 
   if (j == 0) {
@@ -338,6 +351,13 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
         + c * (7.0 / 16 * A0d + 3.0 / 16 * A1d + 1.0 / 16 * A2d - 1.0 / 64 * A3d)) - rho * m_sum;
     row[0] = g_tev; row[1] = g_lev; row[2] = shed ? 1.0 : 0.0; row[3] = bound; row[4] = lesp_prev; row[5] = A0;
     row[6] = Fn; row[7] = Fs; row[8] = M; row[9] = (double)n0;
+    row[10] = 0.0; row[11] = 0.0;
+    if (!shed) {
+      double uu, ww;
+      unit_pair_f64(0.0, 0.0, tev_x, tev_z, m.vc4, uu, ww);
+      row[10] = puo + suo + g_tev * uu;
+      row[11] = pwo + swo + g_tev * ww;
+    }
     // the shed vortices join the wake (:1095-1098)
     x64[n0] = tev_x; z64[n0] = tev_z; g64[n0] = g_tev;
     split_hilo(tev_x, xh[n0], xl[n0]); split_hilo(tev_z, zh[n0], zl[n0]); g32[n0] = (float)g_tev;

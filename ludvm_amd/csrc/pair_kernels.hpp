@@ -393,8 +393,8 @@ __device__ __forceinline__ void split_hilo(double v, float& hi, float& lo) {
 // Device-resident march: what the Euler finisher leaves for the coming time step (march_kernels.hpp), done by the
 // threads that have the data in their hands.  The thread that has just moved the newest TEV / LEV places the
 // next ones one third of the way from the shedding edge (LUDVM.py:680-681, :797-800); block 0 copies the coming
-// step's chord points next to them: tgt = x[npan + 2] | z[npan + 2] are the targets of the fp64 wake -> chord
-// launch (chord points, TEV placement, LEV placement).  kin_next = the coming step's kinematics row
+// step's chord points next to them: tgt = x[npan + 3] | z[npan + 3] are the targets of the fp64 wake -> chord
+// launch (chord points, TEV placement, LEV placement, the origin).  kin_next = the coming step's kinematics row
 // [alpha, alpha_dot, h_dot, te_x, te_z, le_x, le_z, xg[npan], zg[npan]]; null S = not a march.
 struct TailDuty {
   double* place;          // tev_x, lev_x, tev_z, lev_z of the coming step
@@ -404,24 +404,29 @@ struct TailDuty {
   const int* shed;        // ... and whether a LEV was among them
   const double* kin_next;
   int npan;
+  // dense history: every vortex's position after this roll-up goes to hist_row = x[hist_nmax] | z[hist_nmax]
+  // (the reference's path[...][i] rows, LUDVM.py:1108-1127); null = not recorded
+  double* hist_row;
+  long long hist_nmax;
 };
 
 __device__ __forceinline__ void tail_duty(const TailDuty& td, long long i, long long n, double xn, double zn) {
+  if (td.hist_row) { td.hist_row[i] = xn; td.hist_row[td.hist_nmax + i] = zn; }
   if (td.kin_next == nullptr) return;
-  const int np = td.npan;
+  const int np = td.npan, ntt = np + 3;
   const int tail = *td.tail;
   if (i == n - tail) {
     const double tex = td.kin_next[3], tez = td.kin_next[4];
     const double px = tex + (xn - tex) / 3, pz = tez + (zn - tez) / 3;
     td.place[0] = px; td.place[2] = pz;
-    td.tgt[np] = px; td.tgt[np + 2 + np] = pz;
+    td.tgt[np] = px; td.tgt[ntt + np] = pz;
   }
   if (i == n - 1) {
     const double lex = td.kin_next[5], lez = td.kin_next[6];
     double px = lex, pz = lez;
     if (*td.shed && tail == 2) { px = lex + (xn - lex) / 3; pz = lez + (zn - lez) / 3; }
     td.place[1] = px; td.place[3] = pz;
-    td.tgt[np + 1] = px; td.tgt[np + 2 + np + 1] = pz;
+    td.tgt[np + 1] = px; td.tgt[ntt + np + 1] = pz;
   }
 }
 
@@ -429,12 +434,12 @@ __device__ __forceinline__ void tail_duty(const TailDuty& td, long long i, long 
 // threads without a vortex leave (a young wake is smaller than the number of chord points).
 __device__ __forceinline__ void tail_duty_block0(const TailDuty& td, long long n) {
   if (td.kin_next == nullptr || blockIdx.x != 0) return;
-  const int np = td.npan;
+  const int np = td.npan, ntt = np + 3;
   for (int t = threadIdx.x; t < np; t += blockDim.x) {
     td.tgt[t] = td.kin_next[7 + t];
-    td.tgt[np + 2 + t] = td.kin_next[7 + np + t];
+    td.tgt[ntt + t] = td.kin_next[7 + np + t];
   }
-  if (threadIdx.x == 0) *td.n_old = n;
+  if (threadIdx.x == 0) { *td.n_old = n; td.tgt[np + 2] = 0.0; td.tgt[ntt + np + 2] = 0.0; }
 }
 
 // Resident-wake Euler step (LUDVM.py:1108-1127): float64 update of the master copy from the summed

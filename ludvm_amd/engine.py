@@ -252,7 +252,7 @@ class Engine:
         return (u, w) if return_velocity else None
 
     # -- device-resident time march ----------------------------------------------------------------
-    MARCH_ROW_HEAD = 10
+    MARCH_ROW_HEAD = 12
     MARCH_STATE_HEAD = 16
 
     def march_setup(self, npan, ncoef, scalars, tables, kin):
@@ -268,16 +268,19 @@ class Engine:
         self._check(self._lib.ludvm_march_setup(self._ctx, int(npan), int(ncoef), _pd(sc), _pd(tb), _pd(kin), kin.shape[0]))
         self._march_dims = (int(npan), int(ncoef))
 
-    def march_run(self, first_step, count, precision, state):
+    def march_run(self, first_step, count, precision, state, hist_nmax=0):
         """Advance the resident wake through time steps [first_step, first_step + count) without a host round
         trip per step (ludvm_march_run).  `state` (16 + ncoef float64) is updated in place; returns the
-        per-step rows [count, 10 + 2 ncoef + 2 npan]."""
+        per-step rows [count, 12 + 2 ncoef + 2 npan] -- and, with hist_nmax > 0, the positions of every wake
+        vortex after each step, [count, 2, hist_nmax] (the reference's dense history)."""
         npan, ncoef = self._march_dims
         if state.dtype != np.float64 or not state.flags.c_contiguous or len(state) != self.MARCH_STATE_HEAD + ncoef:
             raise ValueError("march_run: state must be contiguous float64 of length 16 + ncoef")
         rows = np.empty([int(count), self.MARCH_ROW_HEAD + 2 * ncoef + 2 * npan])
-        self._check(self._lib.ludvm_march_run(self._ctx, int(first_step), int(count), _prec(precision), _pd(state), _pd(rows)))
-        return rows
+        hist = np.empty([int(count), 2, int(hist_nmax)]) if hist_nmax else None
+        self._check(self._lib.ludvm_march_run(self._ctx, int(first_step), int(count), _prec(precision), _pd(state), _pd(rows),
+                                              _pd(hist), int(hist_nmax)))
+        return (rows, hist) if hist_nmax else rows
 
     # -- flow field ------------------------------------------------------------------------------
     def flowfield(self, xmin, zmin, dr, nx, nz, circulation, xw, zw, v_core):

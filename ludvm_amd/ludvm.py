@@ -435,13 +435,16 @@ class LUDVM:
                                   foil[:, :, 0], gpts[:, 0, :], gpts[:, 1, :]], axis=1)
             eng.march_setup(npan, self.Ncoeffs, [U, c, rho, dt, self.piv, vc, C['IC'], sum_free,
                                                   float(self.method == 'Ramesh'), self.maxerror, self.maxiter, self.epsilon], tables, kin)
-        march_chunk = int(getattr(self, '_march_chunk', 32768))   # steps per ludvm_march_run call (bounds the returned rows)
+        # with the dense history every step's row is recorded: the march then keeps a snapshot of the wake per step on
+        # the device (shorter calls, the snapshots are [steps, 2, wake size])
+        dense_march = can_march and full
+        march_chunk = int(getattr(self, '_march_chunk', 512 if dense_march else 32768))   # steps per ludvm_march_run call
 
         i = first_step
         while i < nt:
-            if can_march and not self._record_row(i):
+            if can_march and (dense_march or not self._record_row(i)):
                 j = i
-                while j < nt and not self._record_row(j) and j - i < march_chunk:
+                while j < nt and (dense_march or not self._record_row(j)) and j - i < march_chunk:
                     j += 1
                     if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
                         break
@@ -455,7 +458,7 @@ class LUDVM:
                         place = [tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]]
                     (itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev) = self._march_stretch(
                         i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed, tev_slot,
-                        lev_slot, prec_code)
+                        lev_slot, prec_code, record=dense_march)
                     have_next = False
                     if self.verbose == True:  # noqa: E712
                         for q in range(i, j):
@@ -641,17 +644,22 @@ class LUDVM:
         return None
 
     def _march_stretch(self, i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
-                       tev_slot, lev_slot, prec_code):
+                       tev_slot, lev_slot, prec_code, record=False):
         """Time steps [i, j) as one device-resident march (Engine.march_run) and everything the per-step path
-        would have stored for them (LUDVM.py:765-1090): circulations, Fourier rows, LESP, loads, slot maps.
+        would have stored for them (LUDVM.py:765-1090): circulations, Fourier rows, LESP, loads, slot maps -- and,
+        with `record` (dense history), the path[...] rows of every step (:1108-1127).
         `place` = [tev_x, lev_x, tev_z, lev_z] of step i.  LEV_shed, tev_slot, lev_slot and the result arrays
         are updated in place; returns the loop's scalars after step j - 1."""
         C, nc, npan, cnt = self.circulation, self.Ncoeffs, self.Npoints - 1, j - i
+        H = self.engine.MARCH_ROW_HEAD
         n_wake = nf + itev + ilev
         st = np.zeros(16 + nc)
         st[:11] = [n_wake, itev, ilev, float(LEV_shed[i - 1] != -1), lesp_crit, sum_tev, sum_lev] + list(place)
         st[16:] = self.fourier[i - 1, 0, :]
-        R = self.engine.march_run(i, cnt, prec_code, st)
+        if record:
+            R, hist = self.engine.march_run(i, cnt, prec_code, st, hist_nmax=n_wake + 2 * cnt)
+        else:
+            R = self.engine.march_run(i, cnt, prec_code, st)
         steps = np.arange(i, j)
         tix = itev + np.arange(cnt)
         shed_v = R[:, 2] != 0
@@ -668,15 +676,30 @@ class LUDVM:
         self.D[steps] = self.Fn[steps] * sa - self.Fs[steps] * ca
         self.T[steps] = -self.D[steps]
         tev_slot[tix] = slot
-        lix = ilev + np.cumsum(shed_v)[shed_v] - 1
+        levs_before = ilev + np.cumsum(shed_v) - shed_v          # LEVs shed before each step
+        lix = levs_before[shed_v]
         C['LEV'][lix] = R[shed_v, 1]
         lev_slot[lix] = slot[shed_v] + 1
         LEV_shed[steps[shed_v]] = lix
-        self.fourier[steps, 0, :] = R[:, 10:10 + nc]
-        self.fourier[steps, 1, :] = R[:, 10 + nc:10 + 2 * nc]
-        C['gamma_airfoil'][tix] = R[:, 10 + 2 * nc:10 + 2 * nc + npan]
-        C['airfoil'][tix] = R[:, 10 + 2 * nc + npan:]
+        self.fourier[steps, 0, :] = R[:, H:H + nc]
+        self.fourier[steps, 1, :] = R[:, H + nc:H + 2 * nc]
+        C['gamma_airfoil'][tix] = R[:, H + 2 * nc:H + 2 * nc + npan]
+        C['airfoil'][tix] = R[:, H + 2 * nc + npan:]
         C['Gamma_airfoil'][tix] = np.cumsum(C['airfoil'][tix], axis=1)
+        if record:
+            # rows of the dense history from the per-step snapshots (wake order -> TEV / LEV / FREE slots); on a step
+            # without LEV shedding the reference's zero-strength LEV slot lands at dt * (velocity at the origin)
+            P = self.path
+            for r in range(cnt):
+                q, it, il = i + r, itev + r, int(levs_before[r])
+                xs, zs = hist[r, 0], hist[r, 1]
+                ts = tev_slot[:it + 1]
+                P['TEV'][q, 0, :it + 1], P['TEV'][q, 1, :it + 1] = xs[ts], zs[ts]
+                ls = lev_slot[:il + 1] if shed_v[r] else lev_slot[:il]
+                P['LEV'][q, 0, :len(ls)], P['LEV'][q, 1, :len(ls)] = xs[ls], zs[ls]
+                if not shed_v[r]:
+                    P['LEV'][q, :, il] = self.dt * R[r, 10:12]
+                P['FREE'][q, 0, :], P['FREE'][q, 1, :] = xs[:nf], zs[:nf]
         last_shed = bool(shed_v[-1])
         # as the per-step path leaves them: the counters before the last step's increment
         self.itev, self.ilev, self.LEV_shed = itev + cnt - 1, ilev + n_shed - int(last_shed), LEV_shed
@@ -721,7 +744,7 @@ class LUDVM:
         os.replace(tmp, self.checkpoint_path)      # a reader never sees a half-written file
 
     @classmethod
-    def resume(cls, path, engine=None, device=0, verbose=True, checkpoint_every=0, checkpoint_path=None):
+    def resume(cls, path, engine=None, device=0, verbose=True, checkpoint_every=0, checkpoint_path=None, march=True):
         """Continue a run from a checkpoint written with `checkpoint_every` / `checkpoint_path`: rebuilds
         geometry and kinematics from the stored constructor arguments, uploads the wake and marches
         from the stored step to the end."""
@@ -733,7 +756,7 @@ class LUDVM:
                 or float(np.abs(R['xy_freevort']).sum()) != 0.0:
             free = dict(circulation_freevort=R['circulation_freevort'], xy_freevort=R['xy_freevort'])
         sim = cls(**kw, **free, verbose=verbose, engine=engine, device=device, run=False,
-                  checkpoint_every=checkpoint_every, checkpoint_path=checkpoint_path)
+                  checkpoint_every=checkpoint_every, checkpoint_path=checkpoint_path, march=march)
         sim.time_loop(_resume=R)
         sim.compute_coefficients()
         return sim

@@ -199,7 +199,8 @@ def g2():
     return load_golden("g2_config1.npz")
 
 
-def test_time_loop_config1_fp64_mode_tier_T3(eng, g2):
+@pytest.mark.parametrize("march", [True, False])
+def test_time_loop_config1_fp64_mode_tier_T3(eng, g2, march):
     """fp64 parity mode against the reference's README run: identical LEV shedding pattern over all 400
     steps, wake positions to 1e-9 through step 50, loads to 1e-9 over the first 100 steps and 1e-7 over
     the first 200.  Beyond that the comparison is limited by the flow, not the arithmetic: the rolled-up
@@ -207,7 +208,7 @@ def test_time_loop_config1_fp64_mode_tier_T3(eng, g2):
     by step 400 -- measured 9e-6 and 4e-5 on Cl for two equally exact fp64 formulations -- so the last 200
     steps are bounded at 1e-3 and compared on their mean."""
     from ludvm_amd import LUDVM
-    sim = LUDVM(**CONFIG1, verbose=False, engine=eng, precision="f64")
+    sim = LUDVM(**CONFIG1, verbose=False, engine=eng, precision="f64", march=march)   # dense history either way
     assert (sim.nt, sim.itev, sim.ilev) == (401, 399, 202)
     assert np.array_equal(sim.LEV_shed, g2["LEV_shed"])
     for name in ("Cl", "Cd", "Cm"):
@@ -216,7 +217,7 @@ def test_time_loop_config1_fp64_mode_tier_T3(eng, g2):
         assert abs(getattr(sim, name)[200:].mean() - g2[name][200:].mean()) <= 1e-4, name
     np.testing.assert_allclose(sim.circulation["TEV"][:200], g2["circ_TEV"][:200], rtol=0, atol=1e-7)
     np.testing.assert_allclose(sim.fourier[:200], g2["fourier"][:200], rtol=0, atol=1e-6)
-    for s in (1, 2, 10, 50):
+    for s in (1, 2, 10, 50):   # whole dense rows, the zero-strength LEV slot of non-shedding steps included
         for key in ("TEV", "LEV", "FREE"):
             np.testing.assert_allclose(sim.path[key][s], g2[f"{key}_{s}"], rtol=0, atol=1e-9, err_msg=f"{key}@{s}")
     c = sim.circulation
@@ -228,14 +229,15 @@ def test_time_loop_config1_fp64_mode_tier_T3(eng, g2):
     ("f32", {50: 1e-5, 75: 1e-3, 100: 1e-1}),
     ("f32x2", {50: 1e-6, 75: 1e-4, 100: 1e-2}),
 ])
-def test_time_loop_config1_fp32_tier_T2(eng, g2, precision, win):
+@pytest.mark.parametrize("march", [True, False])
+def test_time_loop_config1_fp32_tier_T2(eng, g2, precision, win, march):
     """fp32 wake roll-up (chord sums stay fp64): wake positions to 1e-5 through step 50, identical LEV
     shedding pattern over all 400 steps, loads inside windows that widen with time -- the wake is
     chaotic, a rounding-level difference grows ~10x every ~12 steps once it rolls up
     (measured on MI355X: fp32 3.6e-7 / 1.8e-4 / 2.6e-2 and hi+lo 5e-8 / 1.5e-5 / 1.8e-3 for steps
     < 50 / 75 / 100) -- and late times are compared on the period average only."""
     from ludvm_amd import LUDVM
-    sim = LUDVM(**CONFIG1, verbose=False, engine=eng, precision=precision)
+    sim = LUDVM(**CONFIG1, verbose=False, engine=eng, precision=precision, march=march)
     assert np.array_equal(sim.LEV_shed, g2["LEV_shed"])
     for s in (1, 2, 10, 50):
         np.testing.assert_allclose(sim.path["TEV"][s], g2[f"TEV_{s}"], rtol=0, atol=1e-5)
@@ -264,20 +266,22 @@ def test_flowfield_through_the_class(eng):
     ("g5_ramesh.npz", dict(tf=2, method="Ramesh"), 1e-7),
     ("g5_alpham.npz", dict(tf=5, alpha_m=5, alpha_max=15), 1e-7),
 ])
-def test_variants_fp64(eng, fixture, kwargs, tol):
+@pytest.mark.parametrize("march", [True, False])
+def test_variants_fp64(eng, fixture, kwargs, tol, march):
     from ludvm_amd import LUDVM
     g = load_golden(fixture)
-    sim = LUDVM(**dict(CONFIG1, **kwargs), verbose=False, engine=eng, precision="f64")
+    sim = LUDVM(**dict(CONFIG1, **kwargs), verbose=False, engine=eng, precision="f64", march=march)
     assert np.array_equal(sim.LEV_shed, g["LEV_shed"])
     for name in ("Cl", "Cd", "Cm", "LESP"):
         assert np.abs(getattr(sim, name) - g[name]).max() <= tol, name
 
 
-def test_free_vortices_fp64(eng):
+@pytest.mark.parametrize("march", [True, False])
+def test_free_vortices_fp64(eng, march):
     from ludvm_amd import LUDVM
     g = load_golden("g5_freevort.npz")
     sim = LUDVM(**dict(CONFIG1, tf=5, circulation_freevort=g["gamma_freevort"], xy_freevort=g["xy_freevort"]),
-                verbose=False, engine=eng, precision="f64")
+                verbose=False, engine=eng, precision="f64", march=march)
     assert np.array_equal(sim.LEV_shed, g["LEV_shed"])
     for name in ("Cl", "Cd", "Cm"):
         assert np.abs(getattr(sim, name) - g[name]).max() <= 1e-6, name
@@ -298,15 +302,24 @@ def test_public_induced_velocity_and_downwash(eng, g1_cases):
     np.testing.assert_allclose(u, c2["u"], rtol=1e-10, atol=1e-12)
 
 
-def test_checkpoint_resume_on_the_device(eng, tmp_path):
+@pytest.mark.parametrize("march", [True, False])
+def test_checkpoint_resume_on_the_device(eng, tmp_path, march):
     """A run resumed from a checkpoint (wake re-uploaded from its float64 master) continues bit for bit
     when the pair sums are deterministic (fp64 direct kernels)."""
     from ludvm_amd import LUDVM
     ck = str(tmp_path / "ck.npz")
     kw = dict(CONFIG1, tf=6)
-    a = LUDVM(**kw, verbose=False, engine=eng, precision="f64")
-    LUDVM(**kw, verbose=False, engine=eng, precision="f64", checkpoint_every=50, checkpoint_path=ck)
-    c = LUDVM.resume(ck, engine=eng, verbose=False)
+    a = LUDVM(**kw, verbose=False, engine=eng, precision="f64", march=march)
+    LUDVM(**kw, verbose=False, engine=eng, precision="f64", checkpoint_every=50, checkpoint_path=ck, march=march)
+    c = LUDVM.resume(ck, engine=eng, verbose=False, march=march)
+    if march:
+        # the marches of the resumed run start elsewhere, so the direct kernels split their sources differently:
+        # agreement to rounding (amplified by the flow towards the end), not bit for bit
+        assert np.array_equal(a.LEV_shed, c.LEV_shed)
+        for name in ("Cl", "Cd", "Cm", "LESP"):
+            assert np.abs(getattr(a, name) - getattr(c, name))[:100].max() <= 1e-10, name
+        assert np.abs(a.path["TEV"][50] - c.path["TEV"][50]).max() <= 1e-10
+        return
     for name in ("Cl", "Cd", "Cm", "LESP", "LEV_shed"):
         assert np.array_equal(getattr(a, name), getattr(c, name)), name
     assert np.array_equal(a.path["TEV"][-1], c.path["TEV"][-1])
