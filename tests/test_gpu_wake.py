@@ -607,3 +607,24 @@ def test_march_ramesh_method(eng):
         assert np.abs(sim.circulation["bound"][:100] - ref.circulation["bound"][:100]).max() <= 1e-8
         assert np.abs(sim.fourier[:100] - ref.fourier[:100]).max() <= 1e-6
     assert np.abs(a.Cl[:100] - b.Cl[:100]).max() <= 1e-9
+
+
+def test_march_dense_history_in_several_calls(eng, g2):
+    """Dense history marched in chunks of 37 steps (the default is 512): every recorded row, the zero-strength LEV slot
+    included, against the golden rows and against the per-step path."""
+    from ludvm_amd import LUDVM
+    cut = LUDVM(**CONFIG1, verbose=False, engine=eng, precision="f64", run=False)
+    assert cut.history == "full"
+    cut._march_chunk = 37
+    cut.time_loop()
+    cut.compute_coefficients()
+    ref = LUDVM(**CONFIG1, verbose=False, engine=eng, precision="f64", march=False)
+    assert np.array_equal(cut.LEV_shed, g2["LEV_shed"])
+    for s in (1, 2, 10, 50):
+        for key in ("TEV", "LEV", "FREE"):
+            np.testing.assert_allclose(cut.path[key][s], g2[f"{key}_{s}"], rtol=0, atol=1e-9, err_msg=f"{key}@{s}")
+    for s in (36, 37, 38, 73, 74, 75, 100):      # around the chunk boundaries, against the per-step path
+        for key in ("TEV", "LEV", "FREE"):
+            np.testing.assert_allclose(cut.path[key][s], ref.path[key][s], rtol=0, atol=1e-8, err_msg=f"{key}@{s}")
+        assert cut.path["TEV"][s][:, s + 1:].max() == 0.0 and cut.path["TEV"][s][:, :s].min() != 0.0
+    assert np.abs(cut.Cl[:100] - ref.Cl[:100]).max() <= 1e-10
