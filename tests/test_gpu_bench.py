@@ -92,3 +92,16 @@ def test_bench_stdout_is_one_line_with_the_rccl_backend_initialised():
     thing there.  One rank, real "nccl" backend (LUDVM_BENCH_FORCE_DIST=1)."""
     d = _launch(1, {"LUDVM_BENCH_FORCE_DIST": "1"}, "--vortices", "40000", "--steps", "2", "--warmup", "1", "--cpu-rows", "32")
     assert d["n_gpus"] == 1 and "config 3" in d["config"]["workload"] and d["cpu_baseline"]["gpu_vs_oracle_max_rel_err"] < 1e-5
+
+
+def test_engine_lifecycle_releases_device_memory():
+    """300 create / run / destroy cycles (all precisions, both histories, overlapped march steps every third cycle):
+    free device memory is the same after 300 cycles as after 20 (tools/soak_engine_lifecycle.py)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_engine_lifecycle.py")], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert d["cycles"] == 300 and abs(d["leaked_MB"]) < 64
