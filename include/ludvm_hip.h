@@ -194,11 +194,12 @@ int ludvm_wake_step(ludvm_ctx* ctx, const double* new_x, const double* new_z, co
 /* ---- device-resident time march: many steps of LUDVM.time_loop per call (LUDVM.py:597-1171) --------
  *
  * ludvm_wake_step still costs one host round trip per time step, because the Gamma solve between two
- * roll-ups (LUDVM.py:743-1090) runs on the host.  These two calls move that solve to the device ('Faure'
- * method: closed-form Gamma_TEV :758-760, the 2x2 TEV/LEV system :944-954; 'Ramesh': the Newton iterations of
- * :683-739 and :807-914 on the six projections of T1, T2, T3 -- the downwash is linear in the circulations; Fourier coefficients :765-773,
- * LESP criterion :781-805, bound vorticity :987-1010, loads :1035-1090), so `count` consecutive steps are
- * enqueued back to back; whether a LEV is shed -- and hence the wake size -- is decided on the device.
+ * roll-ups (LUDVM.py:743-1090) runs on the host.  These two calls move that solve to the device: 'Faure' method,
+ * closed-form Gamma_TEV :758-760 and the 2x2 TEV/LEV system :944-954; 'Ramesh', the Newton iterations of :683-739
+ * and :807-914 on the six projections of T1, T2, T3 (the downwash is linear in the circulations); for both, the
+ * Fourier coefficients :765-773, LESP criterion :781-805, bound vorticity :987-1010 and loads :1035-1090.  So `count`
+ * consecutive steps are enqueued back to back; whether a LEV is shed -- and hence the wake size -- is decided on the
+ * device.
  *
  * ludvm_march_setup uploads what does not change during a run:
  *   scalars[12] = Uinf, chord, rho, dt, piv, v_core, IC (:647), sum(Gamma_free), method (0 'Faure', 1 'Ramesh'),
