@@ -628,3 +628,28 @@ def test_march_dense_history_in_several_calls(eng, g2):
             np.testing.assert_allclose(cut.path[key][s], ref.path[key][s], rtol=0, atol=1e-8, err_msg=f"{key}@{s}")
         assert cut.path["TEV"][s][:, s + 1:].max() == 0.0 and cut.path["TEV"][s][:, :s].min() != 0.0
     assert np.abs(cut.Cl[:100] - ref.Cl[:100]).max() <= 1e-10
+
+
+def test_march_on_a_caller_provided_stream():
+    """The engine on a torch side stream (ludvm_set_stream): the march's own second stream forks from and joins that
+    stream; results as on the engine's own stream."""
+    import torch
+    from ludvm_amd import Engine, LUDVM
+    e = Engine(0)
+    try:
+        e.set_symmetric(8)
+        kw = dict(CONFIG1, tf=6)
+        own = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse")
+        side = torch.cuda.Stream()
+        e.set_stream(side.cuda_stream)
+        with torch.cuda.stream(side):
+            ext = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse")
+            dense = LUDVM(**kw, verbose=False, engine=e, precision="f64")
+        e.set_stream(None)
+        ref = LUDVM(**kw, verbose=False, engine=e, precision="f64")
+        assert np.array_equal(own.LEV_shed, ext.LEV_shed)
+        assert np.abs(own.Cl[:60] - ext.Cl[:60]).max() <= 2e-5
+        assert np.abs(dense.Cl[:100] - ref.Cl[:100]).max() <= 1e-10
+        assert np.abs(dense.path["TEV"][50] - ref.path["TEV"][50]).max() <= 1e-10
+    finally:
+        e.close()
