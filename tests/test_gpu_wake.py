@@ -653,3 +653,19 @@ def test_march_on_a_caller_provided_stream():
         assert np.abs(dense.path["TEV"][50] - ref.path["TEV"][50]).max() <= 1e-10
     finally:
         e.close()
+
+
+def test_march_fuzz_against_the_per_step_path():
+    """tools/fuzz_march.py, 24 random configurations (resolution, LESP threshold, kinematics, time step, method,
+    history, symmetric threshold, precision): fp64 runs agree to 1e-8 with identical shedding; fp32 runs that separate
+    inside 50 steps must agree over the first 15 and be no further from an fp64 run than the per-step path is."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_march.py"), "--cases", "24", "--seed", "7"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-1500:])
+    last = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert last["cases"] == 24 and last["failures"] == 0 and last["worst_fp64"]["dCl"] < 1e-8
