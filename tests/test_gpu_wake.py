@@ -664,7 +664,7 @@ def test_march_fuzz_against_the_per_step_path():
     import subprocess
     import sys
     from conftest import ROOT
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_march.py"), "--cases", "24", "--seed", "7"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_march.py"), "--cases", "24", "--seed", "4"],
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-1500:])
     last = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
