@@ -41,6 +41,9 @@ struct ludvm_ctx {
   int tune_split = 0;
   int sym_mode = 1;
   int tune_sym_t = 0, tune_sym_rsplit = 0;   // ludvm_set_sym_tuning (0 = heuristics)
+  long long small_tile_max = 14000;          // direct fp32 launches with at most this many sources use 256-source tiles
+  long long small_tile_max_f64 = 12000;      // fp64 launches with at most this many sources use 128-source tiles
+                                             // (roll-up step 52 -> 26 us at 2400 vortices, 87 -> 72 at 8192 [MI355X])
 
   Buf part;   // partial slabs of the split reduction
   Buf acc;    // raw (u, w) sums of the symmetric kernel: [2][nt_pad] floats
@@ -173,6 +176,11 @@ struct Plan {
 };
 
 constexpr int kTileF32 = 1024;
+// Small source sets (a young wake, a chord-sized launch): with 1024-source tiles a launch of a few hundred sources is
+// one tile walked by one wave per SIMD, which issues at ~40 % of the SIMD's rate; 256-source tiles give 4x more splits
+// (more workgroups, shorter walks): one self-advection step 21 -> 9-11 us up to 4096 vortices, 46 -> 37 us at
+// 12 288, no gain at 16 384 [MI355X].  LUDVM_SMALL_TILE_MAX (sources) overrides the switch-over, 0 disables.
+constexpr int kTileF32Small = 256;
 constexpr int kTileF64 = 512;
 constexpr int kTileF64Few = 128;         // fp64 launches with few targets (chord points): short tiles, more workgroups
 constexpr long long kFewTargets = 256;
@@ -182,7 +190,8 @@ constexpr int kMaxSplit = 2048;
 Plan make_plan(const ludvm_ctx* c, long long nt, long long ns, int precision) {
   Plan p{};
   const bool f64 = precision == LUDVM_PREC_F64;
-  p.tile = f64 ? (nt <= kFewTargets ? kTileF64Few : kTileF64) : kTileF32;
+  p.tile = f64 ? ((nt <= kFewTargets || ns <= c->small_tile_max_f64) ? kTileF64Few : kTileF64) : kTileF32;
+  if (!f64 && ns <= c->small_tile_max) p.tile = kTileF32Small;
   if (f64) {
     p.tpl = 1;
   } else if (c->tune_tpl == 1 || c->tune_tpl == 2 || c->tune_tpl == 4) {
@@ -190,6 +199,7 @@ Plan make_plan(const ludvm_ctx* c, long long nt, long long ns, int precision) {
   } else {
     p.tpl = nt >= 131072 ? 2 : 1;
   }
+  if (p.tile == kTileF32Small && (p.tpl != 1 || nt > 65536)) p.tile = kTileF32;   // the small tile exists for TPL = 1
   const long long ttiles = std::max<long long>(1, (nt + (long long)kBlock * p.tpl - 1) / ((long long)kBlock * p.tpl));
   const long long max_split = std::max<long long>(1, (ns + p.tile - 1) / p.tile);
   long long nsplit = c->tune_split > 0 ? c->tune_split : (kTargetBlocks + ttiles - 1) / ttiles;
@@ -266,6 +276,11 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
       hipLaunchKernelGGL((pair_f64<kTileF64Few>), grid, dim3(kBlock), 0, c->stream, a);
     else
       hipLaunchKernelGGL((pair_f64<kTileF64>), grid, dim3(kBlock), 0, c->stream, a);
+  } else if (p.tile == kTileF32Small && !(a.grid_nz > 0)) {
+    if (precision == LUDVM_PREC_F32X2)
+      hipLaunchKernelGGL((pair_f32<1, kTileF32Small, true>), grid, dim3(kBlock), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((pair_f32<1, kTileF32Small, false>), grid, dim3(kBlock), 0, c->stream, a);
   } else if (precision == LUDVM_PREC_F32X2) {
     switch (p.tpl) {
       case 1: hipLaunchKernelGGL((pair_f32<1, kTileF32, true>), grid, dim3(kBlock), 0, c->stream, a); break;
@@ -447,6 +462,7 @@ extern "C" {
 int ludvm_abi_version(void) { return LUDVM_ABI_VERSION; }
 
 int ludvm_create(int device_ordinal, ludvm_ctx** out) {
+  const char* small_env = std::getenv("LUDVM_SMALL_TILE_MAX");
   if (!out) return LUDVM_E_ARG;
   *out = nullptr;
   int ndev = 0;
@@ -469,6 +485,9 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
     return LUDVM_E_HIP;
   }
   c->stream = c->own_stream;
+  if (small_env) { c->small_tile_max = std::atoll(small_env); c->small_tile_max_f64 = std::min<long long>(c->small_tile_max, 12000); }
+  const char* small64_env = std::getenv("LUDVM_SMALL_TILE_MAX_F64");
+  if (small64_env) c->small_tile_max_f64 = std::atoll(small64_env);
   *out = c;
   return LUDVM_OK;
 }

@@ -9,7 +9,8 @@ dev = torch.device("cuda", 0)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 rng = np.random.default_rng(1)
 rows = []
-for n in (1024, 2048, 4096, 8192, 12288, 16384, 24576, 32768, 65536, 131072, 262144):
+sizes = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 8192, 12288, 16384, 24576, 32768, 65536, 131072, 262144]
+for n in sizes:
     x = torch.from_numpy(rng.uniform(-10, 0, n).astype(np.float32)).to(dev)
     z = torch.from_numpy(rng.uniform(-2, 2, n).astype(np.float32)).to(dev)
     g = torch.from_numpy((rng.standard_normal(n) / n).astype(np.float32)).to(dev)
