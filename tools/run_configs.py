@@ -67,7 +67,7 @@ def cfg2(args):
     eng = Engine(0)
     eng.kernel_timing(not args.no_timing)    # per-launch events (two per pair-kernel launch)
     t0 = time.perf_counter()
-    sim = LUDVM(t0=0, tf=args.tf, dt=1e-3, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2,
+    sim = LUDVM(t0=0, tf=args.tf, dt=args.dt, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2,
                 Naca="0012", verbose=args.verbose, engine=eng, precision=args.precision, history="sparse",
                 snapshot_steps=[], march=not args.no_march, run=False)
     t_setup = time.perf_counter() - t0          # geometry + kinematics of all steps (host)
@@ -79,7 +79,7 @@ def cfg2(args):
     # pairs of the roll-up launches: sum_i (n_i + 80) * n_i with n_i = wake size at step i
     sizes = 1 + np.arange(1, sim.nt) + np.cumsum(sim.LEV_shed[1:] != -1)
     pairs = float(np.sum((sizes + 80.0) * sizes))
-    print(json.dumps({"config": f"cfg2 time_loop dt=1e-3 tf={args.tf} precision={args.precision}", "steps": sim.nt - 1,
+    print(json.dumps({"config": f"cfg2 time_loop dt={args.dt:g} tf={args.tf} precision={args.precision}", "steps": sim.nt - 1,
                       "path": "per-step round trips" if args.no_march else "device-resident march",
                       "wall_s": el, "setup_s": t_setup, "time_loop_s": el - t_setup, "final_wake": int(sizes[-1]), "tev": int(ntev), "lev": int(nlev),
                       "rollup_pairs": pairs, "pairs_per_s_wall": pairs / el, "kernel_launches": nl,
@@ -95,6 +95,7 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--tpl", type=int, default=0)
     ap.add_argument("--tf", type=float, default=50.0)
+    ap.add_argument("--dt", type=float, default=1e-3, help="cfg2: time step (BASELINE config 2 uses 1e-3)")
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--no-march", action="store_true", help="cfg2: one device round trip per time step")
