@@ -7,10 +7,16 @@
 
 A "step" is one pass of the hot path over the synthetic wake held in HBM:
   * 1 GPU  (BASELINE config 3): one induced_velocity all-pairs call, N sources x N targets;
-  * G GPUs (BASELINE config 4): one self-advection step of the N = 8e6 wake -- every rank evaluates
-    all N sources on its own N/G targets, Euler-updates them, and one RCCL all-gather republishes
-    the positions (ludvm_amd/sharded.py).  Total work per step is fixed (N^2 pairs): strong scaling.
+  * G GPUs (BASELINE config 4): one self-advection step of the N = 8e6 wake, sharded over the ranks with ONE
+    collective per step (ludvm_amd/sharded.py): symmetric variant (default) -- every rank evaluates its I-tile block
+    of the unordered pairs, one RCCL all-reduce of the 64-bit fixed-point sums, replicated Euler update; direct
+    variant (--symmetric 0) -- all N sources on the rank's own N/G targets, Euler update, one RCCL all-gather of the
+    positions.  Total work per step is fixed (N^2 pairs): strong scaling.
 value = ordered pair interactions (self pairs count) of all ranks / wall time, max over ranks.
+
+Order of a run: CPU baseline (rank 0, N = 1 only) -> warmup -> the timed region of exactly --steps steps (barrier +
+synchronize on both sides) -> --repeats further regions of the same length, reported as `repeat_values` (box-to-box and
+run-to-run spread; they also keep the GPU busy long enough for a 5-second utilisation sampler to see the run).
 
 Prints ONE JSON line on rank 0's stdout (everything else that libraries print there, e.g. RCCL's version
 banner, is routed to stderr).  Synthetic inputs follow SURVEY.md section 8(d):
@@ -30,12 +36,18 @@ if ROOT not in sys.path:
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBPS = 8000.0
-FLOP_PER_PAIR = 13                # sub sub mul fma fma rsq mul fma fma (FMA = 2, rsq = 1), SURVEY 8(d)
-# HBM-side bytes per launch of the dominant kernel at config 3 (N = 1e6), from separate rocprofv3 --pmc
-# passes of this same command (profiles/r01_bench_cfg3_{direct,sym}_pmc_{fetch,write}.csv): FETCH_SIZE +
-# WRITE_SIZE in bytes.  Uncalibrated for these access widths (MI355X_MICROARCH.md, HBM section); the
-# symmetric kernel's write side is its float atomics (1.26e8 64-B requests).  Not measured in this run.
-PMC_TRAFFIC_BYTES_CFG3 = {"direct": 73.2e6 + 72.0e6, "symmetric": 1.50e9 + 8.08e9}
+FLOP_PER_PAIR = 13                # algorithmic: sub sub mul fma fma rsq mul fma fma (FMA = 2, rsq = 1), SURVEY 8(d)
+EXECUTED_FLOP_PER_PAIR = {"direct": 13, "symmetric": 9}   # the symmetric kernel shares dx, dz, r^2, q, rsq between (i,j), (j,i)
+# HBM-side bytes per launch of the dominant kernel at config 3 (N = 1e6): FETCH_SIZE + WRITE_SIZE of separate
+# rocprofv3 --pmc passes of this same command, committed under profiles/ (not collected in this run -- a PMC pass
+# cannot share a run with the timing).  Keyed by the exact kernel the figure was taken from; a run whose kernel
+# differs (another tile, another accumulation scheme) reports traffic = null rather than a stale constant.
+# Units as the guide's HBM section prescribes: FETCH_SIZE counts 64 B per 128-B streaming request (doubled here for
+# the direct kernel's coalesced reads); WRITE_SIZE is exact for the atomics (one 8-B integer per lane).
+PMC_TRAFFIC_CFG3 = {
+    "ludvm::pair_f32<2,1024> direct, partial slabs": {"bytes": 2 * 73.2e6 + 72.0e6,
+                                                      "source": "profiles/r01_bench_cfg3_direct_pmc_{fetch,write}.csv"},
+}
 V_CORE = 0.065
 DT = 5e-2
 
@@ -48,9 +60,10 @@ def synthetic_wake(n):
     return x.astype(np.float32), z.astype(np.float32), g.astype(np.float32)
 
 
-def cpu_baseline(x, z, g, u_gpu, w_gpu, rows, budget_s):
+def cpu_baseline(x, z, g, rows, budget_s):
     """The reference arithmetic as written (float64 NumPy broadcast, oracle/ludvm_oracle.py restating
-    LUDVM.py:549-570) on a bounded sample: the first `rows` targets against all sources, one core."""
+    LUDVM.py:549-570) on a bounded sample: the first `rows` targets against all sources, one core.  Returns the
+    record and the (u, w) it computed, which the GPU results are checked against afterwards."""
     from oracle import ludvm_oracle as O
     xs, zs, gs = x.astype(np.float64), z.astype(np.float64), g.astype(np.float64)
     per_chunk = max(1, int(2.0e7 // len(xs)))   # ~160 MB per [rows, N] float64 temporary
@@ -62,14 +75,10 @@ def cpu_baseline(x, z, g, u_gpu, w_gpu, rows, budget_s):
         u[done:b], w[done:b] = O.induced_velocity(gs, xs, zs, xs[done:b], zs[done:b], V_CORE)
         done = b
     el = time.perf_counter() - t0
-    err = None
-    if u_gpu is not None:
-        scale = max(np.abs(u[:done]).max(), np.abs(w[:done]).max())
-        err = float(max(np.abs(u_gpu[:done] - u[:done]).max(), np.abs(w_gpu[:done] - w[:done]).max()) / scale)
-    return {"value": done * len(xs) / el, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": f"first {done} targets x all {len(xs)} sources, float64 NumPy broadcast as the reference "
-                      f"writes it (LUDVM.py:549-570), {el:.1f} s; host has {os.cpu_count()} logical CPUs",
-            "gpu_vs_oracle_max_rel_err": err}
+    rec = {"value": done * len(xs) / el, "unit": "pairs/s", "cores": 1, "kind": "port",
+           "sample": f"first {done} targets x all {len(xs)} sources, float64 NumPy broadcast as the reference "
+                     f"writes it (LUDVM.py:549-570), {el:.1f} s; host has {os.cpu_count()} logical CPUs"}
+    return rec, u[:done], w[:done]
 
 
 def main():
@@ -85,6 +94,7 @@ def main():
                     help="1: self-interaction launches use the symmetric kernel (each unordered pair once); 0: direct")
     ap.add_argument("--cpu-rows", type=int, default=2048, help="targets in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work at most")
+    ap.add_argument("--repeats", type=int, default=3, help="further timed regions of --steps steps after the reported one")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON.  Libraries write there too (RCCL prints a version banner when a
@@ -134,6 +144,11 @@ def main():
     n = args.vortices or (1_000_000 if workload == "cfg3" else 8_000_000)
     x, z, g = synthetic_wake(n)
 
+    # CPU baseline first (rank 0, one GPU): ~20 s of host work, then the GPU phase runs uninterrupted to the end
+    cpu_rec = cpu_u = cpu_w = None
+    if world == 1 and rank == 0 and args.cpu_rows > 0:
+        cpu_rec, cpu_u, cpu_w = cpu_baseline(x, z, g, args.cpu_rows, args.cpu_budget)
+
     eng = Engine(dev_index)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_tuning(args.tpl, args.splits)
@@ -142,6 +157,7 @@ def main():
 
     # the symmetric kernel serves self-interaction launches (configs 3 and 4)
     symmetric = bool(args.symmetric) and n >= 16384
+    variant = "symmetric" if symmetric else "direct"
     if workload == "cfg3":
         dx, dz, dg = (torch.from_numpy(a).to(device) for a in (x, z, g))
         du, dw = torch.empty_like(dx), torch.empty_like(dx)
@@ -152,16 +168,19 @@ def main():
         pairs_per_step = float(n) * float(n)
         pairs_per_launch = pairs_per_step
         desc = f"config 3: synthetic wake N={n}, one induced_velocity all-pairs call per step (targets = sources)"
-        scaling = "strong"
+        collective = None
     else:
         wake = ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric)
         step = wake.step
         pairs_per_step = wake.pairs_per_step
-        pairs_per_launch = float(wake.n_loc) * float(wake.n_pad)
-        desc = (f"config 4: synthetic wake N={n}, targets sharded over {world} GPU(s), per step: all-pairs "
-                f"kernel on own N/G targets + Euler update + one RCCL all-gather of positions"
-                + (" (symmetric kernel: + one reduce-scatter of the raw sums)" if symmetric else ""))
-        scaling = "strong"
+        pairs_per_launch = float(wake.n_pad) * float(wake.n_pad) / world if symmetric else float(wake.n_loc) * float(wake.n_pad)
+        collective = ("one all_reduce(sum) of int64[2 N + 1] fixed-point sums per step" if symmetric
+                      else "one all_gather of fp32[2, N / G] positions per step")
+        desc = (f"config 4: synthetic wake N={n}, sharded over {world} GPU(s); per step: "
+                + ("symmetric kernel on the rank's I-tile block of the unordered pairs + ONE all-reduce of the 64-bit "
+                   "fixed-point sums + replicated Euler update" if symmetric else
+                   "all-pairs kernel on own N/G targets + Euler update + ONE all-gather of positions"))
+    scaling = "strong"
 
     def fence():
         if world > 1:
@@ -174,70 +193,94 @@ def main():
         probe = torch.zeros(world * 4, dtype=torch.float32, device=device)
         piece = torch.ones(4, dtype=torch.float32, device=device)
         dist.all_gather_into_tensor(probe, piece)
-        if backend == "nccl":
-            dist.reduce_scatter_tensor(piece, probe, op=dist.ReduceOp.SUM)
-        else:
-            dist.all_reduce(probe)
+        dist.all_reduce(torch.ones(4, dtype=torch.int64, device=device))     # the symmetric variant's collective
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
-    eng.kernel_timing(True)
-    eng.kernel_time_ms(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = eng.kernel_time_ms(reset=True)
-    eng.kernel_timing(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    def timed_region():
+        eng.kernel_timing(True)
+        eng.kernel_time_ms(reset=True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        kms, nl = eng.kernel_time_ms(reset=True)
+        eng.kernel_timing(False)
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), kms, nl
+
+    elapsed, kernel_ms, launches = timed_region()
+    u_first = w_first = None
+    if cpu_rec is not None and workload == "cfg3":
+        u_first = du[: len(cpu_u)].cpu().numpy().astype(np.float64)
+        w_first = dw[: len(cpu_u)].cpu().numpy().astype(np.float64)
+    repeats = [timed_region()[0] for _ in range(max(0, args.repeats))]
+
+    # per-rank kernel time (the pair kernel alone, HIP events on the launch stream)
+    kt = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+    per_rank_ms = [kernel_ms]
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        allk = torch.zeros([world], dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allk, kt)
+        per_rank_ms = [float(v) for v in allk.cpu()]
 
     if rank == 0:
         value = pairs_per_step * args.steps / elapsed
         kern_s = kernel_ms * 1e-3
-        achieved_tflops = FLOP_PER_PAIR * pairs_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
+        exe = EXECUTED_FLOP_PER_PAIR[variant]
+        alg_tflops = FLOP_PER_PAIR * pairs_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
+        exe_tflops = exe * pairs_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
         # algorithmic HBM bytes per launch: 12 B per source read, 8 B per target read, 8 B written
         ns_l = n if workload == "cfg3" else wake.n_pad
-        nt_l = n if workload == "cfg3" else wake.n_loc
+        nt_l = n if workload == "cfg3" else (wake.n_pad if symmetric else wake.n_loc)
         alg_bytes = 12.0 * ns_l + 16.0 * nt_l
+        kernel_name = ("ludvm::pair_sym_f32<8> fixed-point accumulation" if symmetric
+                       else "ludvm::pair_f32<2,1024> direct, partial slabs")
+        traffic = PMC_TRAFFIC_CFG3.get(kernel_name) if (workload == "cfg3" and n == 1_000_000 and not args.tpl and not args.splits) else None
         out = {
             "metric": "biot_savart_pair_interactions_per_s", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "collective_backend": backend if world > 1 else None, "n_vortices": n, "v_core": V_CORE, "device": info["name"],
-                       "cu_count": info["cu_count"], "kernel_variant": "symmetric" if symmetric else "direct", "targets_per_lane": args.tpl or "auto",
-                       "source_splits": args.splits or "auto"},
+            "repeat_values": [pairs_per_step * args.steps / r for r in repeats],
+            "config": {"workload": desc, "collective_backend": backend if world > 1 else None,
+                       "ranks": dist.get_world_size() if (world > 1 or force_dist) else 1, "collective": collective,
+                       "n_vortices": n, "v_core": V_CORE, "device": info["name"],
+                       "cu_count": info["cu_count"], "kernel_variant": variant, "targets_per_lane": args.tpl or "auto",
+                       "source_splits": args.splits or "auto", "pair_kernel_ms_per_rank": per_rank_ms},
             "roofline": {
+                # per the metric's definition: algorithmic FLOPs -- 13 per ordered pair -- over the
+                # dominant kernel's own time.  The symmetric kernel EXECUTES 9 per ordered pair (it shares dx, dz, r^2,
+                # q and the rsqrt between (i,j) and (j,i)): `executed` is the share of the vector ALU's peak that was
+                # actually issued, and the one to read as hardware utilisation
                 "bound": "valu",
-                "kernel": ("ludvm::pair_sym_f32<8> (each unordered pair once: 9 executed FLOP per ordered pair; "
-                           "packed fp32 vector ALU; no MFMA, not HBM-bound)") if symmetric else
-                          "ludvm::pair_f32 (direct, packed fp32 vector ALU; no MFMA, not HBM-bound)",
-                "executed_flop_per_pair": 9 if symmetric else 13,
-                "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
-                "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": pairs_per_launch,
+                "kernel": kernel_name + (" (each unordered pair once; packed fp32 vector ALU; no MFMA, not HBM-bound)"
+                                         if symmetric else " (packed fp32 vector ALU; no MFMA, not HBM-bound)"),
+                "achieved": alg_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": alg_tflops / FP32_VECTOR_PEAK_TFLOPS, "flop_per_pair": FLOP_PER_PAIR,
+                "executed": {"flop_per_pair": exe, "achieved": exe_tflops, "frac": exe_tflops / FP32_VECTOR_PEAK_TFLOPS},
+                "pairs_per_launch": pairs_per_launch,
                 "kernel_ms_avg": kernel_ms, "kernel_launches_timed": launches,
-                "pct_fp32_vector_peak": 100.0 * achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
                 "hbm_algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_achieved_gbps": alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0, "hbm_peak_gbps": HBM_PEAK_GBPS,
-                "traffic": PMC_TRAFFIC_BYTES_CFG3["symmetric" if symmetric else "direct"]
-                if (workload == "cfg3" and n == 1_000_000) else None,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed under "
-                                  "profiles/ (not collected in this run)",
+                "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": (traffic["source"] + " (separate rocprofv3 --pmc passes of this command; not collected "
+                                   "in this run)") if traffic else "no PMC pass on record for this kernel / size",
             },
         }
-        if workload == "cfg3" and world == 1 and args.cpu_rows > 0:
-            u_gpu = du[: args.cpu_rows].cpu().numpy().astype(np.float64)
-            w_gpu = dw[: args.cpu_rows].cpu().numpy().astype(np.float64)
-            out["cpu_baseline"] = cpu_baseline(x, z, g, u_gpu, w_gpu, args.cpu_rows, args.cpu_budget)
-        elif world == 1 and args.cpu_rows > 0:
-            out["cpu_baseline"] = cpu_baseline(x, z, g, None, None, args.cpu_rows, args.cpu_budget)
+        if cpu_rec is not None:
+            if u_first is not None:
+                scale = max(np.abs(cpu_u).max(), np.abs(cpu_w).max())
+                cpu_rec["gpu_vs_oracle_max_rel_err"] = float(max(np.abs(u_first - cpu_u).max(), np.abs(w_first - cpu_w).max()) / scale)
+            else:
+                cpu_rec["gpu_vs_oracle_max_rel_err"] = None
+            out["cpu_baseline"] = cpu_rec
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dist:

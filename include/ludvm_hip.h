@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LUDVM_ABI_VERSION 1
+#define LUDVM_ABI_VERSION 2
 
 enum {
   LUDVM_OK = 0,
@@ -46,7 +46,11 @@ enum {
 
 /* Arithmetic the pair sum is evaluated in. */
 enum {
-  LUDVM_PREC_F32 = 0,   /* fp32 positions and arithmetic (headline kernel) */
+  LUDVM_PREC_F32 = 0,   /* fp32 arithmetic (headline kernel).  Wherever the library lays the positions out itself (host
+                           float64 inputs, the resident wake) they are stored as fp32 offsets from the origin of their
+                           256-vortex block and the origin difference is added once per block pair ("local origins"):
+                           same speed as plain fp32, and a wake at |x| ~ 50 with vortices 1e-3 apart keeps ~1e-5 of
+                           max|u| instead of ~1e-3.  Device fp32 inputs are used as they are. */
   LUDVM_PREC_F32X2 = 1, /* positions as hi+lo fp32 pairs: dx = (xh_p - xh_w) + (xl_p - xl_w), rest fp32.
                            Removes the cancellation error of |x| ~ 50 vs spacing ~ 1e-3. */
   LUDVM_PREC_F64 = 2    /* fp64 throughout (parity / debug mode, and the small chord-target calls) */
@@ -74,14 +78,16 @@ int ludvm_synchronize(ludvm_ctx* ctx);
 int ludvm_set_tuning(ludvm_ctx* ctx, int targets_per_lane, int source_splits);
 
 /* Self-interaction launches (targets are exactly the sources: wake roll-up, all-pairs calls on one
- * array) may use the symmetric kernel, which evaluates each unordered pair once (K(i->j) = -K(j->i))
- * and accumulates with float atomics: ~1.5x faster, reproducible to rounding but not bitwise.
- * mode 0 = never (direct kernel, bitwise reproducible), 1 = automatic (default; fp32, N >= 16384),
+ * array) may use the symmetric kernel, which evaluates each unordered pair once (K(i->j) = -K(j->i)): ~1.5x
+ * faster.  It accumulates in 64-bit fixed point (integer atomics, scale from sum|Gamma| / v_core), so its results
+ * do not depend on the order of the atomics: a launch repeats bit for bit, like the direct kernel and like the
+ * reference.  Launches with v_core = 0 (no bound on the kernel) always take the direct kernel.
+ * mode 0 = never (direct kernel), 1 = automatic (default; fp32, N >= 16384),
  * mode >= 2 = automatic with that value as the smallest N that takes the symmetric kernel. */
 int ludvm_set_symmetric(ludvm_ctx* ctx, int mode);
 /* Tuning of the symmetric kernel (tools and tests; 0 = the library's heuristics): vortices per lane (4: 256-vortex
  * tiles, 8: 512-vortex tiles; plain fp32 positions only) and the number of wavefronts (1, 2, 4) that share the 64
- * rotation steps of one tile pair.  Results change only in the order of the float atomics. */
+ * rotation steps of one tile pair.  Results change only through the partition into fp32 partial sums. */
 int ludvm_set_sym_tuning(ludvm_ctx* ctx, int vortices_per_lane, int rotation_split);
 
 /* ---- stateless pair sum: backs LUDVM.induced_velocity (LUDVM.py:549-570) ------------------ */
@@ -110,19 +116,27 @@ int ludvm_advect_dev_f32(ludvm_ctx* ctx, const float* d_xs, const float* d_zs, c
 
 /* Multi-GPU building blocks of the symmetric roll-up (ludvm_amd/sharded.py).  Vortices are cut into
  * tiles of LUDVM_SYM_TILE; the caller owns tiles [tile_first, tile_first + tile_count) of the
- * ceil(n / LUDVM_SYM_TILE) tiles.  ludvm_sym_accumulate_dev_f32 evaluates this owner's share of the
- * unordered pairs (its tiles against the cyclic half of the tile ring) and ADDS the raw sums of both
- * partners into d_acc_u / d_acc_w (n floats each, zeroed by the caller): summed over all owners,
- * u = acc_u / (2 pi), w = -acc_w / (2 pi).  ludvm_advect_from_sums_dev_f32 turns the summed values of
- * targets [t_first, t_first + nt) (d_sum_*[i] belongs to target t_first + i) into the Euler step
- * x_out[i] = x[t_first + i] + dt * u, z_out likewise (LUDVM.py:1108-1109). */
+ * ceil(n / LUDVM_SYM_TILE) tiles.
+ *   ludvm_sym_scale_dev_f32 derives the fixed-point scale of the raw sums from sum|Gamma| / v_core (summed in a
+ *     fixed order: every GPU holding the same circulations gets the same record) into d_scale, a caller-owned
+ *     device record of LUDVM_SYM_SCALE_BYTES; v_core must be > 0.
+ *   ludvm_sym_accumulate_dev_f32 evaluates this owner's share of the unordered pairs (its tiles against the cyclic
+ *     half of the tile ring) and ADDS the raw sums of both partners, as 64-bit fixed-point integers, into
+ *     d_acc_u / d_acc_w (n each, zeroed by the caller); *d_bad (zeroed by the caller) is incremented when a partial
+ *     sum was not finite.  Integer sums are order-independent: summed over all owners (a sum all-reduce of the
+ *     three buffers) they are bit for bit what one GPU owning all tiles produces.
+ *   ludvm_advect_from_sums_dev_f32 turns the summed values of targets [t_first, t_first + nt) (d_sum_*[i] belongs to
+ *     target t_first + i) into the Euler step x_out[i] = x[t_first + i] + dt * u, z_out likewise
+ *     (LUDVM.py:1108-1109); NaN when *d_bad != 0, as the reference's sum over a NaN source would be. */
 #define LUDVM_SYM_TILE 512
+#define LUDVM_SYM_SCALE_BYTES 32
+int ludvm_sym_scale_dev_f32(ludvm_ctx* ctx, const float* d_g, size_t n, float vcore, void* d_scale);
 int ludvm_sym_accumulate_dev_f32(ludvm_ctx* ctx, const float* d_x, const float* d_z, const float* d_g, size_t n,
-                                 size_t tile_first, size_t tile_count, float vcore, float* d_acc_u,
-                                 float* d_acc_w);
-int ludvm_advect_from_sums_dev_f32(ludvm_ctx* ctx, const float* d_sum_u, const float* d_sum_w, const float* d_x,
-                                   const float* d_z, size_t t_first, size_t nt, float dt, float* d_x_out,
-                                   float* d_z_out);
+                                 size_t tile_first, size_t tile_count, float vcore, const void* d_scale,
+                                 long long* d_acc_u, long long* d_acc_w, long long* d_bad);
+int ludvm_advect_from_sums_dev_f32(ludvm_ctx* ctx, const long long* d_sum_u, const long long* d_sum_w,
+                                   const void* d_scale, const long long* d_bad, const float* d_x, const float* d_z,
+                                   size_t t_first, size_t nt, float dt, float* d_x_out, float* d_z_out);
 
 /* ---- resident wake: backs LUDVM.time_loop (LUDVM.py:597-1171) ----------------------------- */
 /* The wake (TEV, LEV and FREE vortices, in an order the host chooses) lives on the device across
@@ -230,7 +244,9 @@ int ludvm_wake_step(ludvm_ctx* ctx, const double* new_x, const double* new_z, co
  *   hist_nmax >= wake size + 2 count.
  * Synchronous: returns when the last step has finished.  `precision` selects the roll-up arithmetic as in
  * ludvm_wake_advect; the solve is float64.  From the symmetric-kernel threshold on, a step's chord sums and solve run on
- * a second stream beside the symmetric kernel (environment LUDVM_MARCH_OVERLAP=0 keeps every step serial). */
+ * a second stream beside the symmetric kernel (environment LUDVM_MARCH_OVERLAP=0 keeps every step serial).  The launch
+ * geometry of every step is a function of the arguments and of the simulation itself (never of host timing), and every
+ * sum is order-independent or done in a fixed order: two runs of the same call return the same bits. */
 int ludvm_march_setup(ludvm_ctx* ctx, int npan, int ncoef, const double* scalars, const double* tables, const double* kin,
                       size_t kin_rows);
 int ludvm_march_run(ludvm_ctx* ctx, long long first_step, long long count, int precision, double* state, double* rows,
@@ -241,12 +257,18 @@ int ludvm_march_run(ludvm_ctx* ctx, long long first_step, long long count, int p
 /* Grid targets generated on the device, x-major ravel like np.meshgrid(indexing='ij')
  * (LUDVM.py:1193-1195): point (i,j) = (xmin + i*dr, zmin + j*dr), i < nx, j < nz, index i*nz + j.
  * Sources are host float64 arrays (wake ++ foil as the caller gathered them, LUDVM.py:1202-1217).
- * Outputs u, w are host float32 arrays of nx*nz (fp32 arithmetic).  d_u/d_w variants keep the result
- * on the device for the vorticity stencil. */
+ * Outputs u, w are host float32 arrays of nx*nz (fp32 arithmetic on local-origin positions: the sources as offsets
+ * from the origin of their 256-source blocks, the grid points generated in float64 and referred to those origins).
+ * d_u/d_w variants keep the result on the device for the vorticity stencil. */
 int ludvm_flowfield_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz,
                         const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
                         float* u, float* w);
-/* Same, device-resident fp32 sources and outputs (asynchronous). */
+/* Velocity field and its vorticity (LUDVM.py:1224-1292) in one call: the stencil runs on the device on the
+ * fields where they are, and u, w, ome (host float32, nx*nz each; ome may be NULL) come back together. */
+int ludvm_flowfield_vorticity_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz,
+                                  const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
+                                  float* u, float* w, float* ome);
+/* Same as ludvm_flowfield_f32, device-resident fp32 sources and outputs (asynchronous). */
 int ludvm_flowfield_dev_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz,
                             const float* d_xs, const float* d_zs, const float* d_gs, size_t ns, float vcore,
                             float* d_u, float* d_w);

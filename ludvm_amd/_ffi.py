@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libludvm_hip.so")
 OK, E_ARG, E_HIP, E_NOMEM, E_NODEVICE, E_STATE = range(6)
 PREC_F32, PREC_F32X2, PREC_F64 = 0, 1, 2
 SYM_TILE = 512
-ABI_VERSION = 1
+ABI_VERSION = 2
+SYM_SCALE_BYTES = 32
 
 _pd, _pf = POINTER(c_double), POINTER(c_float)
 
@@ -38,10 +39,11 @@ SIGNATURES = {
                              c_float, c_void_p, c_void_p],
     "ludvm_advect_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float,
                              c_float, c_void_p, c_void_p],
+    "ludvm_sym_scale_dev_f32": [c_void_p, c_void_p, c_size_t, c_float, c_void_p],
     "ludvm_sym_accumulate_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float,
-                                     c_void_p, c_void_p],
-    "ludvm_advect_from_sums_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float,
-                                       c_void_p, c_void_p],
+                                     c_void_p, c_void_p, c_void_p, c_void_p],
+    "ludvm_advect_from_sums_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                       c_size_t, c_float, c_void_p, c_void_p],
     "ludvm_wake_reserve": [c_void_p, c_size_t],
     "ludvm_wake_clear": [c_void_p],
     "ludvm_wake_size": [c_void_p, POINTER(c_size_t)],
@@ -60,6 +62,8 @@ SIGNATURES = {
     "ludvm_march_run": [c_void_p, c_longlong, c_longlong, c_int, _pd, _pd, _pd, c_size_t],
     "ludvm_flowfield_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, _pd, _pd, _pd, c_size_t,
                             c_double, _pf, _pf],
+    "ludvm_flowfield_vorticity_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, _pd, _pd, _pd, c_size_t,
+                                      c_double, _pf, _pf, _pf],
     "ludvm_flowfield_dev_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_float, c_void_p, c_void_p],
     "ludvm_vorticity_f32": [c_void_p, _pf, _pf, c_size_t, c_size_t, c_double, _pf],

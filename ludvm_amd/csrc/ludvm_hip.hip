@@ -46,7 +46,8 @@ struct ludvm_ctx {
                                              // (roll-up step 52 -> 26 us at 2400 vortices, 87 -> 72 at 8192 [MI355X])
 
   Buf part;   // partial slabs of the split reduction
-  Buf acc;    // raw (u, w) sums of the symmetric kernel: [2][nt_pad] floats
+  Buf acc;    // raw (u, w) sums of the symmetric kernel: [2][nt_pad] 64-bit fixed-point integers
+  Buf symsc;  // SymScale of the current symmetric launch, followed by its NaN counter (long long)
   Buf arena;  // staging for the host-pointer entry points
   char* pin = nullptr;  // pinned host ring for small uploads from entry points that do not synchronize
   size_t pin_off = 0;
@@ -57,6 +58,8 @@ struct ludvm_ctx {
   size_t wake_cap = 0, wake_n = 0;
   double *x64 = nullptr, *z64 = nullptr, *g64 = nullptr;
   float *xh = nullptr, *xl = nullptr, *zh = nullptr, *zl = nullptr, *g32 = nullptr;
+  float *xr = nullptr, *zr = nullptr, *cx = nullptr, *cz = nullptr;   // local-origin offsets and block origins
+  Mirrors mir() const { return Mirrors{xh, xl, zh, zl, xr, zr, cx, cz}; }
 
   // device-resident march (ludvm_march_setup / ludvm_march_run)
   Buf march_tab, march_kin, march_rows, march_state, march_hist;
@@ -64,7 +67,7 @@ struct ludvm_ctx {
   size_t march_kin_rows = 0;
   double march_vcore = 0.0;
   bool march_ready = false;
-  unsigned long long* progress = nullptr;      // host-mapped: (step << 32 | wake size) after each solve
+  unsigned long long* progress = nullptr;      // host-mapped ring: slot s % kProgressRing = (s << 32 | wake size after step s)
   unsigned long long* progress_dev = nullptr;
   hipEvent_t march_ev[2] = {nullptr, nullptr};
   hipStream_t stream_b = nullptr;              // the solve chain beside the roll-up (overlapped march steps)
@@ -106,6 +109,7 @@ int ensure(ludvm_ctx* c, Buf& b, size_t bytes) {
   if (bytes <= b.cap) return LUDVM_OK;
   // the old contents are never needed across a grow; wait for in-flight users, then replace
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->stream_b) HIPCHK(c, hipStreamSynchronize(c->stream_b));
   if (b.p) HIPCHK(c, hipFree(b.p));
   b.p = nullptr;
   b.cap = 0;
@@ -187,11 +191,12 @@ constexpr long long kFewTargets = 256;
 constexpr long long kTargetBlocks = 16384;  // total workgroups aimed for (2048 resident at 8/CU)
 constexpr int kMaxSplit = 2048;
 
-Plan make_plan(const ludvm_ctx* c, long long nt, long long ns, int precision) {
+// small_ok = false: the launch has no 256-source-tile kernel (generic flow-field grids), keep the chunk a multiple of 1024
+Plan make_plan(const ludvm_ctx* c, long long nt, long long ns, int precision, bool small_ok = true) {
   Plan p{};
   const bool f64 = precision == LUDVM_PREC_F64;
   p.tile = f64 ? ((nt <= kFewTargets || ns <= c->small_tile_max_f64) ? kTileF64Few : kTileF64) : kTileF32;
-  if (!f64 && ns <= c->small_tile_max) p.tile = kTileF32Small;
+  if (!f64 && small_ok && ns <= c->small_tile_max) p.tile = kTileF32Small;
   if (f64) {
     p.tpl = 1;
   } else if (c->tune_tpl == 1 || c->tune_tpl == 2 || c->tune_tpl == 4) {
@@ -199,7 +204,8 @@ Plan make_plan(const ludvm_ctx* c, long long nt, long long ns, int precision) {
   } else {
     p.tpl = nt >= 131072 ? 2 : 1;
   }
-  if (p.tile == kTileF32Small && (p.tpl != 1 || nt > 65536)) p.tile = kTileF32;   // the small tile exists for TPL = 1
+  // the small tile exists for TPL = 1 (and for the 4-points-per-lane grid kernel, whose TPL the launch fixes itself)
+  if (p.tile == kTileF32Small && (p.tpl != 1 || nt > 65536)) p.tile = kTileF32;
   const long long ttiles = std::max<long long>(1, (nt + (long long)kBlock * p.tpl - 1) / ((long long)kBlock * p.tpl));
   const long long max_split = std::max<long long>(1, (ns + p.tile - 1) / p.tile);
   long long nsplit = c->tune_split > 0 ? c->tune_split : (kTargetBlocks + ttiles - 1) / ttiles;
@@ -276,6 +282,24 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
       hipLaunchKernelGGL((pair_f64<kTileF64Few>), grid, dim3(kBlock), 0, c->stream, a);
     else
       hipLaunchKernelGGL((pair_f64<kTileF64>), grid, dim3(kBlock), 0, c->stream, a);
+  } else if (a.scx != nullptr) {
+    // local-origin fp32 (LUDVM_PREC_F32 wherever the library lays the positions out itself)
+    if (a.grid_nz > 0 && a.grid_nz % 4 == 0 && c->tune_tpl == 0) {
+      const long long ttiles = (a.nt + (long long)kBlock * 4 - 1) / ((long long)kBlock * 4);
+      grid = dim3((unsigned)ttiles, grid.y, 1);
+      if (p.tile == kTileF32Small)
+        hipLaunchKernelGGL((pair_f32<4, kTileF32Small, false, true, true>), grid, dim3(kBlock), 0, c->stream, a);
+      else
+        hipLaunchKernelGGL((pair_f32<4, kTileF32, false, true, true>), grid, dim3(kBlock), 0, c->stream, a);
+    } else if (p.tile == kTileF32Small) {
+      hipLaunchKernelGGL((pair_f32<1, kTileF32Small, false, false, true>), grid, dim3(kBlock), 0, c->stream, a);
+    } else {
+      switch (p.tpl) {
+        case 1: hipLaunchKernelGGL((pair_f32<1, kTileF32, false, false, true>), grid, dim3(kBlock), 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL((pair_f32<2, kTileF32, false, false, true>), grid, dim3(kBlock), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL((pair_f32<4, kTileF32, false, false, true>), grid, dim3(kBlock), 0, c->stream, a); break;
+      }
+    }
   } else if (p.tile == kTileF32Small && !(a.grid_nz > 0)) {
     if (precision == LUDVM_PREC_F32X2)
       hipLaunchKernelGGL((pair_f32<1, kTileF32Small, true>), grid, dim3(kBlock), 0, c->stream, a);
@@ -292,7 +316,10 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
     // as TPL = 4, so the plan's grid is recomputed for it
     const long long ttiles = (a.nt + (long long)kBlock * 4 - 1) / ((long long)kBlock * 4);
     grid = dim3((unsigned)ttiles, grid.y, 1);
-    hipLaunchKernelGGL((pair_f32<4, kTileF32, false, true>), grid, dim3(kBlock), 0, c->stream, a);
+    if (p.tile == kTileF32Small)
+      hipLaunchKernelGGL((pair_f32<4, kTileF32Small, false, true>), grid, dim3(kBlock), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((pair_f32<4, kTileF32, false, true>), grid, dim3(kBlock), 0, c->stream, a);
   } else {
     switch (p.tpl) {
       case 1: hipLaunchKernelGGL((pair_f32<1, kTileF32, false>), grid, dim3(kBlock), 0, c->stream, a); break;
@@ -314,7 +341,8 @@ int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, i
     HIPCHK(c, hipMemsetAsync(w, 0, (size_t)nt * elt, c->stream));
     return LUDVM_OK;
   }
-  Plan p = make_plan(c, nt, ns, precision);
+  const bool grid_generic = a.grid_nz > 0 && !(a.grid_nz % 4 == 0 && c->tune_tpl == 0);
+  Plan p = make_plan(c, nt, ns, precision, !grid_generic);
   CHK(launch_pair(c, a, p, precision, u, w));
   if (p.nsplit > 1) {
     if (precision == LUDVM_PREC_F64)
@@ -337,48 +365,64 @@ constexpr long long kSymMinN = 16384;   // below this the direct kernel's launch
 // positions (8 would not fit the register file).
 constexpr long long kSymT8MinN = 40960;
 static_assert(64 * 8 == LUDVM_SYM_TILE, "the multi-GPU entry points always use the 512-vortex tile");
-constexpr long long kSymTargetWaves = 65536;
-constexpr long long kSymMaxSplit = 64;
-constexpr long long kSymMaxRsplit = 4;
-constexpr long long kSymMinItems = 9000;    // measured (profiles/r01_sym_kernel_rotation_split.txt)
 
-bool use_symmetric(const ludvm_ctx* c, long long n) {
-  if (c->sym_mode == 0) return false;
+// The symmetric kernel accumulates in fixed point, which needs the bound sum|Gamma| / (sqrt(2) v_core) on the raw
+// sums: point vortices (v_core = 0, or so small that v_core^4 vanishes in fp32) take the direct kernel.
+bool use_symmetric(const ludvm_ctx* c, long long n, double vc4) {
+  if (c->sym_mode == 0 || !((float)vc4 > 0.0f)) return false;
   return n >= (c->sym_mode == 1 ? kSymMinN : (long long)c->sym_mode);
 }
 
-// Symmetric kernel over I tiles [i_first, i_first + i_count) of the tile ring of (x, z, g)[0, n); raw sums
-// are ADDED into acc_u / acc_w (n floats each, zeroed by the caller).
-int launch_sym_tiles(ludvm_ctx* c, int T, const float* x, const float* z, const float* g, long long n, long long i_first,
-                     long long i_count, double vc4, float* acc_u, float* acc_w, const float* xl = nullptr,
-                     const float* zl = nullptr, const long long* n_dev = nullptr) {
+int sym_tile_t(const ludvm_ctx* c, long long n, bool hilo, bool local = false) {
+  (void)local;                        // local origins fit both tiles (a 512-vortex tile keeps its targets twice)
+  if (hilo) return 4;                 // hi+lo positions: register file
+  if (c->tune_sym_t == 4 || c->tune_sym_t == 8) return c->tune_sym_t;
+  return n >= kSymT8MinN ? 8 : 4;
+}
+
+struct SymOperands {
+  const float* x; const float* z; const float* g;
+  const float* xl = nullptr; const float* zl = nullptr;     // hi+lo positions (T = 4)
+  const float* cx = nullptr; const float* cz = nullptr;     // local origins: x, z are offsets from them
+  long long* acc_u; long long* acc_w;
+  const SymScale* scale; long long* bad;
+};
+
+// Symmetric kernel over I tiles [i_first, i_first + i_count) of the tile ring of (x, z, g)[0, n); raw fixed-point
+// sums are ADDED into acc_u / acc_w (n each, zeroed by the caller).  The partition of the work into partial sums
+// is a function of n and T alone (sym_geometry).  n_dev (march): the vortex count is read on the device; it lies in
+// [n_lo, n], and the grid is sized for the largest wave count any such n needs.
+int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, long long i_first, long long i_count, double vc4,
+                     const long long* n_dev = nullptr, long long n_lo = 0) {
   SymArgs a{};
-  a.x = x; a.z = z; a.g = g; a.n = n;
-  a.n_dev = n_dev;     // march: n is an upper bound for the launch geometry, the kernel reads the real one
-  a.xl = xl; a.zl = zl;
-  const bool hilo = xl && zl;
+  a.x = o.x; a.z = o.z; a.g = o.g; a.n = n;
+  a.n_dev = n_dev;
+  a.xl = o.xl; a.zl = o.zl;
+  a.cx = o.cx; a.cz = o.cz;
+  const bool hilo = o.xl && o.zl;
   if (hilo) T = 4;
-  const long long W = 64LL * T;
-  a.ntiles = (n + W - 1) / W;
-  a.dmax = (a.ntiles - 1) / 2;
+  a.tune_split = c->tune_split;
+  a.tune_rsplit = c->tune_sym_rsplit;
+  const SymGeom gm = sym_geometry(n, T, a.tune_split, a.tune_rsplit);
+  a.ntiles = gm.ntiles;
+  a.dmax = gm.dmax;
   a.i_first = i_first;
   a.i_count = i_count;
-  const long long dtot = a.dmax + ((a.ntiles % 2 == 0 && a.ntiles > 1) ? 1 : 0);
-  long long ys = c->tune_split > 0 ? c->tune_split : (kSymTargetWaves + i_count - 1) / i_count;
-  ys = std::max<long long>(1, std::min<long long>(std::min<long long>(ys, kSymMaxSplit), std::max<long long>(dtot, 1)));
-  a.ysplit = (int)ys;
-  // too few (I, d-chunk) items to keep every SIMD busy to the end: share each tile pair's rotation steps
-  long long rs = 1;
-  if (c->tune_sym_rsplit == 1 || c->tune_sym_rsplit == 2 || c->tune_sym_rsplit == 4) {
-    rs = c->tune_sym_rsplit;
-  } else {
-    while (rs < kSymMaxRsplit && i_count * ys * rs < kSymMinItems) rs *= 2;
-  }
-  a.rsplit = (int)rs;
-  a.acc_u = acc_u;
-  a.acc_w = acc_w;
+  a.ysplit = gm.ysplit;
+  a.rsplit = gm.rsplit;
+  a.acc_u = o.acc_u;
+  a.acc_w = o.acc_w;
+  a.scale = o.scale;
+  a.bad = o.bad;
   a.vc4 = (float)vc4;
-  const long long waves = i_count * ys * rs;
+  long long waves = i_count * gm.ysplit * gm.rsplit;
+  if (n_dev) {
+    const long long W = 64LL * T;
+    for (long long nt = std::max<long long>(1, (std::max<long long>(n_lo, 1) + W - 1) / W); nt <= gm.ntiles; ++nt) {
+      const SymGeom q = sym_geometry(nt * W, T, a.tune_split, a.tune_rsplit);
+      waves = std::max(waves, q.ntiles * q.ysplit * q.rsplit);
+    }
+  }
   TimedLaunch t{};
   bool active = false;
   CHK(timed_begin(c, t, active));
@@ -394,18 +438,30 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const float* x, const float* z, const 
   return LUDVM_OK;
 }
 
-// Symmetric self-interaction of all of (x, z, g)[0, n): zero the context's accumulators, run the kernel.
-// The raw sums are left in c->acc as [acc_u | acc_w], each nt_pad floats.
-int launch_sym(ludvm_ctx* c, const float* x, const float* z, const float* g, long long n, double vc4, long long* nt_pad_out,
-               const float* xl = nullptr, const float* zl = nullptr, const long long* n_dev = nullptr) {
+SymScale* ctx_scale(ludvm_ctx* c) { return static_cast<SymScale*>(c->symsc.p); }
+long long* ctx_bad(ludvm_ctx* c) { return reinterpret_cast<long long*>(static_cast<char*>(c->symsc.p) + 64); }
+
+// Symmetric self-interaction of all of (x, z, g)[0, n) with the context's accumulators: zero them, derive the
+// fixed-point scale from sum|Gamma| (unless the caller -- the march -- maintains it: scale / bad given), run the
+// kernel.  The raw sums are left in c->acc as [acc_u | acc_w], each nt_pad 64-bit integers.
+int launch_sym(ludvm_ctx* c, SymOperands o, long long n, double vc4, long long* nt_pad_out, const long long* n_dev = nullptr,
+               long long n_lo = 0) {
   const long long nt_pad = (n + 63) / 64 * 64;
-  CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(float)));
-  HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(float), c->stream));
-  float* acc = static_cast<float*>(c->acc.p);
-  int T = (n >= kSymT8MinN && !(xl && zl)) ? 8 : 4;
-  if ((c->tune_sym_t == 4 || c->tune_sym_t == 8) && !(xl && zl)) T = c->tune_sym_t;
+  CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(long long)));
+  CHK(ensure(c, c->symsc, 128));
+  HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(long long), c->stream));
+  long long* acc = static_cast<long long*>(c->acc.p);
+  o.acc_u = acc;
+  o.acc_w = acc + nt_pad;
+  if (!o.scale) {
+    hipLaunchKernelGGL(sym_prepare, dim3(1), dim3(kPrepBlock), 0, c->stream, o.g, n, vc4, ctx_scale(c), ctx_bad(c));
+    HIPCHK(c, hipGetLastError());
+    o.scale = ctx_scale(c);
+    o.bad = ctx_bad(c);
+  }
+  const int T = sym_tile_t(c, n, o.xl && o.zl, o.cx != nullptr);
   const long long ntiles = (n + 64LL * T - 1) / (64LL * T);
-  CHK(launch_sym_tiles(c, T, x, z, g, n, 0, ntiles, vc4, acc, acc + nt_pad, xl, zl, n_dev));
+  CHK(launch_sym_tiles(c, T, o, n, 0, ntiles, vc4, n_dev, n_lo));
   *nt_pad_out = nt_pad;
   return LUDVM_OK;
 }
@@ -415,42 +471,44 @@ bool valid_precision(int p) { return p == LUDVM_PREC_F32 || p == LUDVM_PREC_F32X
 int wake_grow(ludvm_ctx* c, size_t capacity) {
   if (capacity <= c->wake_cap) return LUDVM_OK;
   size_t cap = std::max(capacity, std::max<size_t>(4096, c->wake_cap * 2));
+  cap = (cap + kOriginBlock - 1) / kOriginBlock * kOriginBlock;      // whole origin blocks
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  double *x64, *z64, *g64;
-  float *xh, *xl, *zh, *zl, *g32;
-  HIPCHK(c, hipMalloc(&x64, cap * sizeof(double)));
-  HIPCHK(c, hipMalloc(&z64, cap * sizeof(double)));
-  HIPCHK(c, hipMalloc(&g64, cap * sizeof(double)));
-  HIPCHK(c, hipMalloc(&xh, cap * sizeof(float)));
-  HIPCHK(c, hipMalloc(&xl, cap * sizeof(float)));
-  HIPCHK(c, hipMalloc(&zh, cap * sizeof(float)));
-  HIPCHK(c, hipMalloc(&zl, cap * sizeof(float)));
-  HIPCHK(c, hipMalloc(&g32, cap * sizeof(float)));
+  if (c->stream_b) HIPCHK(c, hipStreamSynchronize(c->stream_b));
+  const size_t nblk = cap / kOriginBlock + 1;
+  double* d64[3] = {nullptr, nullptr, nullptr};
+  float* f32[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (auto& q : d64) HIPCHK(c, hipMalloc(&q, cap * sizeof(double)));
+  for (int k = 0; k < 7; ++k) HIPCHK(c, hipMalloc(&f32[k], cap * sizeof(float)));
+  for (int k = 7; k < 9; ++k) HIPCHK(c, hipMalloc(&f32[k], nblk * sizeof(float)));
   const size_t n = c->wake_n;
+  double* o64[3] = {c->x64, c->z64, c->g64};
+  float* o32[9] = {c->xh, c->xl, c->zh, c->zl, c->g32, c->xr, c->zr, c->cx, c->cz};
   if (n) {
-    HIPCHK(c, hipMemcpyAsync(x64, c->x64, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(z64, c->z64, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(g64, c->g64, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(xh, c->xh, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(xl, c->xl, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(zh, c->zh, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(zl, c->zl, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(g32, c->g32, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    for (int k = 0; k < 3; ++k) HIPCHK(c, hipMemcpyAsync(d64[k], o64[k], n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    for (int k = 0; k < 7; ++k) HIPCHK(c, hipMemcpyAsync(f32[k], o32[k], n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    const size_t ob = (n + kOriginBlock - 1) / kOriginBlock;
+    for (int k = 7; k < 9; ++k) HIPCHK(c, hipMemcpyAsync(f32[k], o32[k], ob * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  void* old[] = {c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32};
-  for (void* p : old)
-    if (p) HIPCHK(c, hipFree(p));
-  c->x64 = x64; c->z64 = z64; c->g64 = g64;
-  c->xh = xh; c->xl = xl; c->zh = zh; c->zl = zl; c->g32 = g32;
+  for (double* q : o64)
+    if (q) HIPCHK(c, hipFree(q));
+  for (float* q : o32)
+    if (q) HIPCHK(c, hipFree(q));
+  c->x64 = d64[0]; c->z64 = d64[1]; c->g64 = d64[2];
+  c->xh = f32[0]; c->xl = f32[1]; c->zh = f32[2]; c->zl = f32[3]; c->g32 = f32[4];
+  c->xr = f32[5]; c->zr = f32[6]; c->cx = f32[7]; c->cz = f32[8];
   c->wake_cap = cap;
   return LUDVM_OK;
 }
 
+// Rebuild the fp32 mirrors of [first, first + count) -- and of the rest of the origin blocks they touch -- from the
+// float64 masters.
 int wake_refresh(ludvm_ctx* c, size_t first, size_t count) {
   if (!count) return LUDVM_OK;
-  hipLaunchKernelGGL(refresh_mirrors, dim3(blocks_for((long long)count)), dim3(kBlock), 0, c->stream, (long long)first,
-                     (long long)count, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32);
+  const long long lo = (long long)(first / kOriginBlock * kOriginBlock);
+  const long long hi = std::min<long long>((long long)c->wake_cap, (long long)((first + count + kOriginBlock - 1) / kOriginBlock * kOriginBlock));
+  hipLaunchKernelGGL(refresh_mirrors, dim3(blocks_for(hi - lo)), dim3(kBlock), 0, c->stream, (long long)first, (long long)count,
+                     (long long)std::max(c->wake_n, first + count), (long long)c->wake_cap, c->x64, c->z64, c->g64, c->mir(), c->g32);
   HIPCHK(c, hipGetLastError());
   return LUDVM_OK;
 }
@@ -496,10 +554,11 @@ int ludvm_destroy(ludvm_ctx* c) {
   if (!c) return LUDVM_E_ARG;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
   for (auto& t : c->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   for (auto& t : c->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
-  void* bufs[] = {c->part.p, c->acc.p, c->arena.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32,
-                  c->march_tab.p, c->march_kin.p, c->march_rows.p, c->march_state.p, c->march_hist.p};
+  void* bufs[] = {c->part.p, c->acc.p, c->symsc.p, c->arena.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32,
+                  c->xr, c->zr, c->cx, c->cz, c->march_tab.p, c->march_kin.p, c->march_rows.p, c->march_state.p, c->march_hist.p};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   for (auto& e : c->march_ev)
@@ -588,88 +647,54 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
     std::memset(w, 0, nt * sizeof(double));
     return LUDVM_OK;
   }
-  const bool f64 = precision == LUDVM_PREC_F64;
-  const size_t in_doubles = 3 * ns + 2 * nt, out_doubles = 2 * nt;
-  if (in_doubles * 8 <= kPinBytes / 4 && out_doubles * 8 <= kPinOutBytes && !(xt == xs && zt == zs && nt == ns)) {
-    // Small call (every call of a README-size run): one packed pinned upload, one conversion launch, the pair
-    // launch, one back-conversion, one pinned download -- instead of 5 + 2 pageable copies and 7 conversions.
-    size_t bytes = Arena::need(in_doubles, 8) + Arena::need(out_doubles, 8);
-    if (!f64) bytes += 5 * Arena::need(ns, 4) + 6 * Arena::need(nt, 4);
-    CHK(ensure(c, c->arena, bytes));
-    Arena ar(c->arena.p);
-    double* din = ar.take<double>(in_doubles);
-    double* dout = ar.take<double>(out_doubles);
+  const bool f64 = precision == LUDVM_PREC_F64, hilo = precision == LUDVM_PREC_F32X2;
+  // the caller passed the same arrays as sources and targets: self-interaction (the targets are not uploaded twice,
+  // and from kSymMinN vortices the symmetric kernel takes it)
+  const bool self = xt == xs && zt == zs && nt == ns;
+  const size_t ntu = self ? 0 : nt;                       // targets uploaded
+  const size_t in_doubles = 3 * ns + 2 * ntu, out_doubles = 2 * nt;
+  // One packed block in = xs | zs | gs | xt | zt.  Small calls (every call of a README-size run) go through the pinned
+  // ring: one upload, one conversion launch, the pair launch, one back-conversion, one pinned download.
+  const bool small = in_doubles * 8 <= kPinBytes / 4 && out_doubles * 8 <= kPinOutBytes;
+  const size_t nsb = ns / kOriginBlock + 1, ntb = nt / kOriginBlock + 1;
+  size_t bytes = Arena::need(in_doubles, 8) + Arena::need(out_doubles, 8);
+  if (!f64) bytes += 5 * Arena::need(ns, 4) + 6 * Arena::need(nt, 4) + 2 * Arena::need(nsb, 4) + 2 * Arena::need(ntb, 4);
+  CHK(ensure(c, c->arena, bytes));
+  Arena ar(c->arena.p);
+  double* din = ar.take<double>(in_doubles);
+  double* dout = ar.take<double>(out_doubles);
+  if (small) {
     std::vector<double>& pk = c->pack;
     pk.resize(in_doubles);
     std::memcpy(pk.data(), xs, ns * 8);
     std::memcpy(pk.data() + ns, zs, ns * 8);
     std::memcpy(pk.data() + 2 * ns, gs, ns * 8);
-    std::memcpy(pk.data() + 3 * ns, xt, nt * 8);
-    std::memcpy(pk.data() + 3 * ns + nt, zt, nt * 8);
-    CHK(h2d(c, din, pk.data(), in_doubles * 8));
-    PairArgs a{};
-    a.ns = (long long)ns;
-    a.nt = (long long)nt;
-    const double v2 = vcore * vcore;
-    a.vc4 = v2 * v2;
-    if (f64) {
-      a.xs = din; a.zs = din + ns; a.gs = din + 2 * ns; a.xt = din + 3 * ns; a.zt = din + 3 * ns + nt;
-      CHK(induce_device(c, a, (long long)nt, (long long)ns, precision, dout, dout + nt));
-    } else {
-      float* fxs = ar.take<float>(ns);
-      float* fxsl = ar.take<float>(ns);
-      float* fzs = ar.take<float>(ns);
-      float* fzsl = ar.take<float>(ns);
-      float* fgs = ar.take<float>(ns);
-      float* fxt = ar.take<float>(nt);
-      float* fxtl = ar.take<float>(nt);
-      float* fzt = ar.take<float>(nt);
-      float* fztl = ar.take<float>(nt);
-      float* fu = ar.take<float>(nt);
-      float* fw = ar.take<float>(nt);
-      hipLaunchKernelGGL(cvt_packed_inputs, dim3(blocks_for((long long)in_doubles)), dim3(kBlock), 0, c->stream, din,
-                         (long long)ns, (long long)nt, fxs, fxsl, fzs, fzsl, fgs, fxt, fxtl, fzt, fztl);
-      HIPCHK(c, hipGetLastError());
-      a.xs = fxs; a.zs = fzs; a.gs = fgs; a.xsl = fxsl; a.zsl = fzsl;
-      a.xt = fxt; a.zt = fzt; a.xtl = fxtl; a.ztl = fztl;
-      CHK(induce_device(c, a, (long long)nt, (long long)ns, precision, fu, fw));
-      hipLaunchKernelGGL(cvt_packed_outputs, dim3(blocks_for((long long)out_doubles)), dim3(kBlock), 0, c->stream, fu, fw, dout,
-                         (long long)nt);
-      HIPCHK(c, hipGetLastError());
+    if (ntu) {
+      std::memcpy(pk.data() + 3 * ns, xt, nt * 8);
+      std::memcpy(pk.data() + 3 * ns + nt, zt, nt * 8);
     }
-    void* hv = nullptr;
-    CHK(d2h_small_sync(c, dout, out_doubles * 8, &hv));
-    std::memcpy(u, hv, nt * 8);
-    std::memcpy(w, static_cast<const double*>(hv) + nt, nt * 8);
-    return LUDVM_OK;
+    CHK(h2d(c, din, pk.data(), in_doubles * 8));
+  } else {
+    HIPCHK(c, hipMemcpyAsync(din, xs, ns * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(din + ns, zs, ns * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(din + 2 * ns, gs, ns * 8, hipMemcpyHostToDevice, c->stream));
+    if (ntu) {
+      HIPCHK(c, hipMemcpyAsync(din + 3 * ns, xt, nt * 8, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(din + 3 * ns + nt, zt, nt * 8, hipMemcpyHostToDevice, c->stream));
+    }
   }
-  size_t bytes = 3 * Arena::need(ns, 8) + 4 * Arena::need(nt, 8);
-  if (!f64) bytes += 5 * Arena::need(ns, 4) + 6 * Arena::need(nt, 4);
-  CHK(ensure(c, c->arena, bytes));
-  Arena ar(c->arena.p);
-  double* dxs = ar.take<double>(ns);
-  double* dzs = ar.take<double>(ns);
-  double* dgs = ar.take<double>(ns);
-  double* dxt = ar.take<double>(nt);
-  double* dzt = ar.take<double>(nt);
-  double* du = ar.take<double>(nt);
-  double* dw = ar.take<double>(nt);
-  HIPCHK(c, hipMemcpyAsync(dxs, xs, ns * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dzs, zs, ns * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dgs, gs, ns * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dxt, xt, nt * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dzt, zt, nt * 8, hipMemcpyHostToDevice, c->stream));
   PairArgs a{};
   a.ns = (long long)ns;
   a.nt = (long long)nt;
   const double v2 = vcore * vcore;
   a.vc4 = v2 * v2;
   if (f64) {
-    a.xs = dxs; a.zs = dzs; a.gs = dgs; a.xt = dxt; a.zt = dzt;
-    CHK(induce_device(c, a, (long long)nt, (long long)ns, precision, du, dw));
+    a.xs = din; a.zs = din + ns; a.gs = din + 2 * ns;
+    a.xt = self ? din : din + 3 * ns; a.zt = self ? din + ns : din + 3 * ns + nt;
+    CHK(induce_device(c, a, (long long)nt, (long long)ns, precision, dout, dout + nt));
   } else {
     float* fxs = ar.take<float>(ns);
-    float* fxsl = ar.take<float>(ns);
+    float* fxsl = ar.take<float>(ns);     // lo parts (f32x2)
     float* fzs = ar.take<float>(ns);
     float* fzsl = ar.take<float>(ns);
     float* fgs = ar.take<float>(ns);
@@ -679,34 +704,53 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
     float* fztl = ar.take<float>(nt);
     float* fu = ar.take<float>(nt);
     float* fw = ar.take<float>(nt);
-    const dim3 bs(kBlock);
-    hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)ns)), bs, 0, c->stream, dxs, fxs, fxsl, (long long)ns);
-    hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)ns)), bs, 0, c->stream, dzs, fzs, fzsl, (long long)ns);
-    hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)ns)), bs, 0, c->stream, dgs, fgs, (float*)nullptr,
-                       (long long)ns);
-    hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)nt)), bs, 0, c->stream, dxt, fxt, fxtl, (long long)nt);
-    hipLaunchKernelGGL(cvt_f64_to_f32, dim3(blocks_for((long long)nt)), bs, 0, c->stream, dzt, fzt, fztl, (long long)nt);
+    float* sox = ar.take<float>(nsb);     // block origins (f32: local-origin positions)
+    float* soz = ar.take<float>(nsb);
+    float* tox = ar.take<float>(ntb);
+    float* toz = ar.take<float>(ntb);
+    if (hilo)
+      hipLaunchKernelGGL(cvt_packed_inputs, dim3(blocks_for((long long)in_doubles)), dim3(kBlock), 0, c->stream, din,
+                         (long long)ns, (long long)ntu, fxs, fxsl, fzs, fzsl, fgs, fxt, fxtl, fzt, fztl);
+    else
+      hipLaunchKernelGGL(cvt_packed_inputs_local, dim3(blocks_for((long long)in_doubles)), dim3(kBlock), 0, c->stream, din,
+                         (long long)ns, (long long)ntu, fxs, fzs, fgs, sox, soz, fxt, fzt, tox, toz);
     HIPCHK(c, hipGetLastError());
-    if (xt == xs && zt == zs && nt == ns && use_symmetric(c, (long long)ns)) {
-      // the caller passed the same arrays as sources and targets (self-interaction): symmetric kernel
+    if (self && use_symmetric(c, (long long)ns, a.vc4)) {
       long long nt_pad = 0;
-      const bool hilo = precision == LUDVM_PREC_F32X2;
-      CHK(launch_sym(c, fxs, fzs, fgs, (long long)ns, a.vc4, &nt_pad, hilo ? fxsl : nullptr, hilo ? fzsl : nullptr));
-      const float* acc = static_cast<const float*>(c->acc.p);
-      hipLaunchKernelGGL(finish_sym, dim3(blocks_for((long long)nt)), bs, 0, c->stream, acc, acc + nt_pad, (long long)nt, fu,
-                         fw);
+      SymOperands o{};
+      o.x = fxs; o.z = fzs; o.g = fgs;
+      if (hilo) { o.xl = fxsl; o.zl = fzsl; } else { o.cx = sox; o.cz = soz; }
+      CHK(launch_sym(c, o, (long long)ns, a.vc4, &nt_pad));
+      const long long* acc = static_cast<const long long*>(c->acc.p);
+      hipLaunchKernelGGL(finish_sym, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, ctx_scale(c),
+                         ctx_bad(c), (long long)nt, fu, fw);
       HIPCHK(c, hipGetLastError());
     } else {
-      a.xs = fxs; a.zs = fzs; a.gs = fgs; a.xsl = fxsl; a.zsl = fzsl;
-      a.xt = fxt; a.zt = fzt; a.xtl = fxtl; a.ztl = fztl;
+      a.xs = fxs; a.zs = fzs; a.gs = fgs;
+      a.xt = self ? fxs : fxt; a.zt = self ? fzs : fzt;
+      if (hilo) {
+        a.xsl = fxsl; a.zsl = fzsl;
+        a.xtl = self ? fxsl : fxtl; a.ztl = self ? fzsl : fztl;
+      } else {
+        a.scx = sox; a.scz = soz;
+        a.tcx = self ? sox : tox; a.tcz = self ? soz : toz;
+        a.t_index0 = 0;
+      }
       CHK(induce_device(c, a, (long long)nt, (long long)ns, precision, fu, fw));
     }
-    hipLaunchKernelGGL(cvt_f32_to_f64, dim3(blocks_for((long long)nt)), bs, 0, c->stream, fu, du, (long long)nt);
-    hipLaunchKernelGGL(cvt_f32_to_f64, dim3(blocks_for((long long)nt)), bs, 0, c->stream, fw, dw, (long long)nt);
+    hipLaunchKernelGGL(cvt_packed_outputs, dim3(blocks_for((long long)out_doubles)), dim3(kBlock), 0, c->stream, fu, fw, dout,
+                       (long long)nt);
     HIPCHK(c, hipGetLastError());
   }
-  HIPCHK(c, hipMemcpyAsync(u, du, nt * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(w, dw, nt * 8, hipMemcpyDeviceToHost, c->stream));
+  if (small) {
+    void* hv = nullptr;
+    CHK(d2h_small_sync(c, dout, out_doubles * 8, &hv));
+    std::memcpy(u, hv, nt * 8);
+    std::memcpy(w, static_cast<const double*>(hv) + nt, nt * 8);
+    return LUDVM_OK;
+  }
+  HIPCHK(c, hipMemcpyAsync(u, dout, nt * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(w, dout + nt, nt * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LUDVM_OK;
 }
@@ -750,12 +794,14 @@ int ludvm_induce_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, con
     return fail(c, LUDVM_E_ARG, "null array");
   HIPCHK(c, hipSetDevice(c->device));
   const double v2 = (double)vcore * (double)vcore;
-  if (d_xt == d_xs && d_zt == d_zs && nt == ns && use_symmetric(c, (long long)ns)) {
+  if (d_xt == d_xs && d_zt == d_zs && nt == ns && use_symmetric(c, (long long)ns, v2 * v2)) {
     long long nt_pad = 0;
-    CHK(launch_sym(c, d_xs, d_zs, d_gs, (long long)ns, v2 * v2, &nt_pad));
-    const float* acc = static_cast<const float*>(c->acc.p);
-    hipLaunchKernelGGL(finish_sym, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad,
-                       (long long)nt, d_u, d_w);
+    SymOperands o{};
+    o.x = d_xs; o.z = d_zs; o.g = d_gs;
+    CHK(launch_sym(c, o, (long long)ns, v2 * v2, &nt_pad));
+    const long long* acc = static_cast<const long long*>(c->acc.p);
+    hipLaunchKernelGGL(finish_sym, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, ctx_scale(c),
+                       ctx_bad(c), (long long)nt, d_u, d_w);
     HIPCHK(c, hipGetLastError());
     return LUDVM_OK;
   }
@@ -774,12 +820,14 @@ int ludvm_advect_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, con
   if (nt == 0) return LUDVM_OK;
   HIPCHK(c, hipSetDevice(c->device));
   const double v2 = (double)vcore * (double)vcore;
-  if (t_first == 0 && nt == ns && use_symmetric(c, (long long)ns)) {
+  if (t_first == 0 && nt == ns && use_symmetric(c, (long long)ns, v2 * v2)) {
     long long nt_pad = 0;
-    CHK(launch_sym(c, d_xs, d_zs, d_gs, (long long)ns, v2 * v2, &nt_pad));
-    const float* acc = static_cast<const float*>(c->acc.p);
+    SymOperands o{};
+    o.x = d_xs; o.z = d_zs; o.g = d_gs;
+    CHK(launch_sym(c, o, (long long)ns, v2 * v2, &nt_pad));
+    const long long* acc = static_cast<const long long*>(c->acc.p);
     hipLaunchKernelGGL(finish_sym_advect, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad,
-                       d_xs, d_zs, 0LL, (long long)nt, dt, d_x_out, d_z_out);  // t_first = 0: sums index = target index
+                       ctx_scale(c), ctx_bad(c), d_xs, d_zs, 0LL, (long long)nt, dt, d_x_out, d_z_out);
     HIPCHK(c, hipGetLastError());
     return LUDVM_OK;
   }
@@ -796,27 +844,47 @@ int ludvm_advect_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, con
   return LUDVM_OK;
 }
 
-int ludvm_sym_accumulate_dev_f32(ludvm_ctx* c, const float* d_x, const float* d_z, const float* d_g, size_t n,
-                                 size_t tile_first, size_t tile_count, float vcore, float* d_acc_u, float* d_acc_w) {
+int ludvm_sym_scale_dev_f32(ludvm_ctx* c, const float* d_g, size_t n, float vcore, void* d_scale) {
   if (!c) return LUDVM_E_ARG;
-  if (!d_x || !d_z || !d_g || !d_acc_u || !d_acc_w) return fail(c, LUDVM_E_ARG, "null array");
+  if (!d_g || !d_scale) return fail(c, LUDVM_E_ARG, "null array");
+  const double v2 = (double)vcore * (double)vcore;
+  if (!((float)(v2 * v2) > 0.0f)) return fail(c, LUDVM_E_ARG, "the symmetric kernel needs v_core > 0 (fixed-point bound)");
+  HIPCHK(c, hipSetDevice(c->device));
+  char* rec = static_cast<char*>(d_scale);
+  hipLaunchKernelGGL(sym_prepare, dim3(1), dim3(kPrepBlock), 0, c->stream, d_g, (long long)n, v2 * v2,
+                     reinterpret_cast<SymScale*>(rec), reinterpret_cast<long long*>(rec + 16));
+  HIPCHK(c, hipGetLastError());
+  return LUDVM_OK;
+}
+
+int ludvm_sym_accumulate_dev_f32(ludvm_ctx* c, const float* d_x, const float* d_z, const float* d_g, size_t n,
+                                 size_t tile_first, size_t tile_count, float vcore, const void* d_scale, long long* d_acc_u,
+                                 long long* d_acc_w, long long* d_bad) {
+  if (!c) return LUDVM_E_ARG;
+  if (!d_x || !d_z || !d_g || !d_scale || !d_acc_u || !d_acc_w || !d_bad) return fail(c, LUDVM_E_ARG, "null array");
   const size_t ntiles = (n + LUDVM_SYM_TILE - 1) / LUDVM_SYM_TILE;
   if (tile_first + tile_count > ntiles) return fail(c, LUDVM_E_ARG, "tile range outside the tile ring");
   if (tile_count == 0) return LUDVM_OK;
   HIPCHK(c, hipSetDevice(c->device));
   const double v2 = (double)vcore * (double)vcore;
-  return launch_sym_tiles(c, 8, d_x, d_z, d_g, (long long)n, (long long)tile_first, (long long)tile_count, v2 * v2,
-                          d_acc_u, d_acc_w);
+  SymOperands o{};
+  o.x = d_x; o.z = d_z; o.g = d_g;
+  o.acc_u = d_acc_u; o.acc_w = d_acc_w;
+  o.scale = static_cast<const SymScale*>(d_scale);
+  o.bad = d_bad;
+  return launch_sym_tiles(c, 8, o, (long long)n, (long long)tile_first, (long long)tile_count, v2 * v2);
 }
 
-int ludvm_advect_from_sums_dev_f32(ludvm_ctx* c, const float* d_sum_u, const float* d_sum_w, const float* d_x,
-                                   const float* d_z, size_t t_first, size_t nt, float dt, float* d_x_out, float* d_z_out) {
+int ludvm_advect_from_sums_dev_f32(ludvm_ctx* c, const long long* d_sum_u, const long long* d_sum_w, const void* d_scale,
+                                   const long long* d_bad, const float* d_x, const float* d_z, size_t t_first, size_t nt,
+                                   float dt, float* d_x_out, float* d_z_out) {
   if (!c) return LUDVM_E_ARG;
-  if (!d_sum_u || !d_sum_w || !d_x || !d_z || !d_x_out || !d_z_out) return fail(c, LUDVM_E_ARG, "null array");
+  if (!d_sum_u || !d_sum_w || !d_scale || !d_bad || !d_x || !d_z || !d_x_out || !d_z_out) return fail(c, LUDVM_E_ARG, "null array");
   if (nt == 0) return LUDVM_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  hipLaunchKernelGGL(finish_sym_advect, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, d_sum_u, d_sum_w, d_x,
-                     d_z, (long long)t_first, (long long)nt, dt, d_x_out, d_z_out);
+  hipLaunchKernelGGL(finish_sym_advect, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, d_sum_u, d_sum_w,
+                     static_cast<const SymScale*>(d_scale), d_bad, d_x, d_z, (long long)t_first, (long long)nt, dt, d_x_out,
+                     d_z_out);
   HIPCHK(c, hipGetLastError());
   return LUDVM_OK;
 }
@@ -1004,23 +1072,29 @@ int ludvm_wake_advect_tail(ludvm_ctx* c, double dt, const double* foil_x, const 
 // at [n, n + nfoil) (masters and mirrors): pair kernel(s) + Euler finisher.  du/dw: optional device
 // arrays receiving the induced velocities.  n_dev (march): the wake size is read on the device and `n` is
 // only an upper bound that sizes the launch.
+static inline unsigned fin_blocks(long long n) { return (unsigned)((n + kFinBlock - 1) / kFinBlock); }
+
+// (march) where a symmetric launch sized from an upper bound finds its scale and how small the wake may be
+struct MarchSym { const SymScale* scale = nullptr; long long* bad = nullptr; long long n_lo = 0; };
+
 static int advect_launch(ludvm_ctx* c, size_t n, const long long* n_dev, double dt, size_t nfoil, double vcore,
-                         int precision, double* du, double* dw, TailDuty td = TailDuty{}) {
+                         int precision, double* du, double* dw, TailDuty td = TailDuty{}, MarchSym ms = MarchSym{}) {
   const long long ns = (long long)(n + nfoil), nt = (long long)n;
   const double v2 = vcore * vcore;
-  if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt)) {
-    // wake x wake: each unordered pair once; bound vortices -> wake: direct kernel into slab row 0
-    const bool hilo = precision == LUDVM_PREC_F32X2;
+  const bool hilo = precision == LUDVM_PREC_F32X2;
+  if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt, v2 * v2)) {
+    // wake x wake: each unordered pair once; the bound vortices' part is summed in the Euler finisher
     long long nt_pad = 0;
-    CHK(launch_sym(c, c->xh, c->zh, c->g32, nt, v2 * v2, &nt_pad, hilo ? c->xl : nullptr, hilo ? c->zl : nullptr, n_dev));
-    if (nfoil > (size_t)kBlock) return fail(c, LUDVM_E_ARG, "too many bound vortices for the fused roll-up");
-    const float* acc = static_cast<const float*>(c->acc.p);
-    if (hilo)
-      hipLaunchKernelGGL(finish_wake_advect_sym<true>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, nt,
-                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw, n_dev, td);
-    else
-      hipLaunchKernelGGL(finish_wake_advect_sym<false>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, nt,
-                         (int)nfoil, (float)(v2 * v2), dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32, du, dw, n_dev, td);
+    SymOperands o{};
+    o.g = c->g32;
+    if (hilo) { o.x = c->xh; o.z = c->zh; o.xl = c->xl; o.zl = c->zl; }
+    else { o.x = c->xr; o.z = c->zr; o.cx = c->cx; o.cz = c->cz; }
+    o.scale = ms.scale; o.bad = ms.bad;
+    CHK(launch_sym(c, o, nt, v2 * v2, &nt_pad, n_dev, ms.n_lo));
+    const long long* acc = static_cast<const long long*>(c->acc.p);
+    hipLaunchKernelGGL(finish_wake_advect_sym, dim3(fin_blocks(nt)), dim3(kFinBlock), 0, c->stream, acc, acc + nt_pad,
+                       ms.scale ? ms.scale : ctx_scale(c), ms.bad ? ms.bad : ctx_bad(c), nt, (int)nfoil, (float)(v2 * v2), dt,
+                       c->x64, c->z64, c->mir(), c->g32, du, dw, n_dev, td);
     HIPCHK(c, hipGetLastError());
     return LUDVM_OK;
   }
@@ -1035,20 +1109,24 @@ static int advect_launch(ludvm_ctx* c, size_t n, const long long* n_dev, double 
   a.vc4 = v2 * v2;
   if (precision == LUDVM_PREC_F64) {
     a.xs = c->x64; a.zs = c->z64; a.gs = c->g64; a.xt = c->x64; a.zt = c->z64;
-  } else {
+  } else if (hilo) {
     a.xs = c->xh; a.zs = c->zh; a.gs = c->g32; a.xsl = c->xl; a.zsl = c->zl;
     a.xt = c->xh; a.zt = c->zh; a.xtl = c->xl; a.ztl = c->zl;
+  } else {
+    // fp32 with local origins: offsets from the origin of each 256-vortex block of the wake array
+    a.xs = c->xr; a.zs = c->zr; a.gs = c->g32; a.scx = c->cx; a.scz = c->cz;
+    a.xt = c->xr; a.zt = c->zr; a.tcx = c->cx; a.tcz = c->cz; a.t_index0 = 0;
   }
   Plan p = make_plan(c, nt, ns, precision);
   CHK(launch_pair(c, a, p, precision, nullptr, nullptr));  // results stay in the slab
   if (precision == LUDVM_PREC_F64)
-    hipLaunchKernelGGL(finish_wake_advect<double>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
-                       static_cast<const double*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->xh, c->xl,
-                       c->zh, c->zl, du, dw, n_dev, td);
+    hipLaunchKernelGGL(finish_wake_advect<double>, dim3(fin_blocks(nt)), dim3(kFinBlock), 0, c->stream,
+                       static_cast<const double*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->mir(), du, dw,
+                       n_dev, td);
   else
-    hipLaunchKernelGGL(finish_wake_advect<float>, dim3(blocks_for(nt)), dim3(kBlock), 0, c->stream,
-                       static_cast<const float*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->xh, c->xl,
-                       c->zh, c->zl, du, dw, n_dev, td);
+    hipLaunchKernelGGL(finish_wake_advect<float>, dim3(fin_blocks(nt)), dim3(kFinBlock), 0, c->stream,
+                       static_cast<const float*>(c->part.p), nt, p.nt_pad, p.nsplit, dt, c->x64, c->z64, c->mir(), du, dw,
+                       n_dev, td);
   HIPCHK(c, hipGetLastError());
   return LUDVM_OK;
 }
@@ -1123,7 +1201,7 @@ int ludvm_wake_step(ludvm_ctx* c, const double* new_x, const double* new_z, cons
   CHK(h2d(c, din, pk.data(), in_doubles * 8));
   if (n_new + nfoil) {
     hipLaunchKernelGGL(stage_step_inputs, dim3(blocks_for((long long)(n_new + nfoil))), dim3(kBlock), 0, c->stream, din,
-                       (long long)n0, (int)n_new, (int)nfoil, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32);
+                       (long long)n0, (int)n_new, (int)nfoil, c->x64, c->z64, c->g64, c->mir(), c->g32);
     HIPCHK(c, hipGetLastError());
   }
   c->wake_n = n;
@@ -1203,7 +1281,7 @@ int ludvm_march_setup(ludvm_ctx* c, int npan, int ncoef, const double* scalars, 
   m.hcsd = t + 6 * P; m.wx = t + 7 * P; m.cproj = t + 8 * P; m.ssin = t + 8 * P + (size_t)ncoef * P;
   c->march_kin_rows = kin_rows;
   if (!c->progress) {
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->progress), 64, hipHostMallocMapped));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->progress), kProgressRing * sizeof(unsigned long long), hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->progress_dev), c->progress, 0));
   }
   for (auto& e : c->march_ev)
@@ -1250,8 +1328,8 @@ int march_chord_launch(ludvm_ctx* c, long long n_ub) {
 // workspace a march step may need when the wake holds at most n_ub vortices
 void march_workspace(const ludvm_ctx* c, long long n_ub, int precision, size_t nfoil, size_t& part_bytes, size_t& acc_bytes) {
   const long long nt = std::max<long long>(n_ub, 1);
-  if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt)) {
-    acc_bytes = std::max(acc_bytes, (size_t)2 * (size_t)((nt + 63) / 64 * 64) * sizeof(float));
+  if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt, c->msetup.vc4)) {
+    acc_bytes = std::max(acc_bytes, (size_t)2 * (size_t)((nt + 63) / 64 * 64) * sizeof(long long));
   } else {
     Plan p = make_plan(c, nt, nt + (long long)nfoil, precision);
     const size_t elt = precision == LUDVM_PREC_F64 ? 8 : 4;
@@ -1287,6 +1365,7 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   march_workspace(c, n0 + 2 * count, precision, nfoil, part_bytes, acc_bytes);
   CHK(ensure(c, c->part, part_bytes + (1 << 20)));
   if (acc_bytes) CHK(ensure(c, c->acc, acc_bytes + (1 << 20)));
+  CHK(ensure(c, c->symsc, 128));
   CHK(ensure(c, c->march_rows, (size_t)count * row_doubles * 8));
   if (hist) CHK(ensure(c, c->march_hist, (size_t)count * 2 * hist_nmax * 8));
 
@@ -1302,18 +1381,26 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   MarchState* S = static_cast<MarchState*>(c->march_state.p);
   HIPCHK(c, hipMemcpyAsync(S, &hs, sizeof(MarchState), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // hs lives on this stack frame
-  *c->progress = ((unsigned long long)(first_step - 1) << 32) | (unsigned long long)n0;
+  for (int k = 0; k < kProgressRing; ++k) c->progress[k] = 0;
 
   double* drows = static_cast<double*>(c->march_rows.p);
   const double* kin = static_cast<const double*>(c->march_kin.p);
   const size_t krow = 7 + 2 * P;
   hipLaunchKernelGGL(march_begin, dim3(1), dim3(kBlock), 0, c->stream, S, kin + (size_t)first_step * krow, (int)P,
-                     (int)(first_step & 1));
+                     (int)(first_step & 1), c->g64, m.vc4);
   HIPCHK(c, hipGetLastError());
 
+  // The wake size is decided on the device (LEV shedding); the host needs an upper bound of it to size each step's
+  // launches, and -- for the direct kernels -- that bound also fixes how the sources are split, i.e. the summation
+  // order.  Every kSyncEvery steps the host waits for the event it recorded 2 * kSyncEvery steps earlier and reads,
+  // from the progress ring, the wake size after the last step enqueued BEFORE that event: a step that is certainly
+  // finished, and always the same one.  All bounds are therefore functions of the call's arguments and of the
+  // simulation itself, never of how far the host happens to run ahead: two runs repeat bit for bit, direct or
+  // symmetric kernel (whose fixed-point sums do not depend on the order of their atomics).
   bool ev_used[2] = {false, false};
+  long long ev_step[2] = {0, 0};          // the last step enqueued before the slot's event was recorded
   constexpr long long kSyncEvery = 64;
-  long long p_step = first_step - 1, p_n = n0;
+  long long p_step = first_step - 1, p_n = n0;   // a finished step and the wake size after it
   long long n_before = n0;          // upper bound of the wake size before the current step's solve
   bool overlapped = false;          // the accumulators have been zeroed for the overlapped steps
   // LUDVM_MARCH_OVERLAP=0 keeps every step serial (A/B measurements; results agree to fp32 rounding)
@@ -1321,33 +1408,32 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   const bool overlap_ok = !(ov_env && ov_env[0] == '0');
   hipStream_t const main_stream = c->stream;
   const double vc4 = m.vc4;
+  const long long thr = c->sym_mode == 1 ? kSymMinN : (long long)c->sym_mode;
   for (long long s = first_step; s < first_step + count; ++s) {
     const long long rel = s - first_step;
     if (rel % kSyncEvery == 0) {
-      // stay at most 2 * kSyncEvery steps ahead of the device, so that the upper bound on the wake size that
-      // sizes the launches stays within a few hundred vortices of the real one
       const int slot = (int)((rel / kSyncEvery) & 1);
-      if (ev_used[slot]) HIPCHK(c, hipEventSynchronize(c->march_ev[slot]));
-      const unsigned long long w = __atomic_load_n(c->progress, __ATOMIC_RELAXED);
-      p_step = (long long)(w >> 32);
-      p_n = (long long)(w & 0xffffffffULL);
+      if (ev_used[slot]) {
+        HIPCHK(c, hipEventSynchronize(c->march_ev[slot]));
+        const long long q = ev_step[slot];
+        if (q >= first_step) {
+          const unsigned long long w = __atomic_load_n(c->progress + (q % kProgressRing), __ATOMIC_RELAXED);
+          if ((long long)(w >> 32) != q) return fail(c, LUDVM_E_STATE, "march: progress ring out of step");
+          p_step = q;
+          p_n = (long long)(w & 0xffffffffULL);
+        }
+      }
       HIPCHK(c, hipEventRecord(c->march_ev[slot], c->stream));
       ev_used[slot] = true;
+      ev_step[slot] = s - 1;
     }
-    // Upper bound of the wake size after this step's solve; it sizes the launches and, for the direct kernels,
-    // fixes how the sources are split -- i.e. the summation order.  n_det depends on the call's arguments only,
-    // so runs repeat bit for bit wherever the direct kernels do; the tighter bound from the progress word
-    // depends on how far the host runs ahead and is used only once the symmetric kernel (float atomics, not
-    // bitwise anyway) has taken over.
-    const long long n_det = n0 + 2 * (rel + 1);
-    const bool symreg = precision != LUDVM_PREC_F64 && use_symmetric(c, n_det);
-    const bool fork = symreg && overlap_ok;
-    long long n_ub = n_det;
-    if (symreg) {
-      const long long thr = c->sym_mode == 1 ? kSymMinN : (long long)c->sym_mode;
-      n_ub = std::max<long long>(std::min<long long>(p_n + 2 * (s - p_step), n_det), thr);
-      n_before = std::min(n_before, n_ub);
-    }
+    // wake size after this step's solve: at most two vortices per step since the last known size
+    const long long n_ub = p_n + 2 * (s - p_step);
+    const long long n_lo = p_n + (s - 1 - p_step);      // ... and before it: at least one per step
+    n_before = std::min<long long>(n_before, n_ub);
+    const bool symreg = precision != LUDVM_PREC_F64 && use_symmetric(c, n_ub, vc4);
+    // overlapped steps need an old wake that already fills the symmetric kernel
+    const bool fork = symreg && overlap_ok && n_lo >= thr;
     const double* krow_s = kin + (size_t)s * krow;
     const double* krow_next = (size_t)(s + 1) < c->march_kin_rows ? kin + (size_t)(s + 1) * krow : nullptr;
     TailDuty td = make_tail_duty(S, s, krow_next, (int)P);
@@ -1360,15 +1446,18 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
       // serial step: chord sums -> solve -> roll-up (direct, or symmetric with its memset) and Euler finisher
       CHK(march_chord_launch(c, n_before));
       hipLaunchKernelGGL(march_solve, dim3(1), dim3(kBlock), 0, c->stream, m, S, krow_s, row, s, c->x64, c->z64, c->g64,
-                         c->xh, c->xl, c->zh, c->zl, c->g32, c->progress_dev);
+                         c->mir(), c->g32, c->progress_dev);
       HIPCHK(c, hipGetLastError());
-      CHK(advect_launch(c, (size_t)n_ub, &S->n, m.dt, nfoil, c->march_vcore, precision, nullptr, nullptr, td));
+      MarchSym ms;
+      ms.scale = &S->sc[(s + 1) & 1]; ms.bad = &S->sym_bad; ms.n_lo = n_lo + 1;
+      CHK(advect_launch(c, (size_t)n_ub, &S->n, m.dt, nfoil, c->march_vcore, precision, nullptr, nullptr, td, ms));
+      overlapped = false;    // the serial symmetric step leaves its sums in the accumulators
     } else {
       // overlapped step: the symmetric kernel on the wake as the last roll-up left it runs on the main stream
       // while chord sums and solve run on the second one; they meet at the Euler finisher
       const bool hilo = precision == LUDVM_PREC_F32X2;
       const long long nt_pad = (n_ub + 63) / 64 * 64;
-      float* acc = static_cast<float*>(c->acc.p);
+      long long* acc = static_cast<long long*>(c->acc.p);
       if (!overlapped) {
         HIPCHK(c, hipMemsetAsync(c->acc.p, 0, c->acc.cap, c->stream));   // march_finish_sym re-zeroes what it reads
         overlapped = true;
@@ -1379,26 +1468,25 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
       int rc = march_chord_launch(c, n_before);
       if (rc == LUDVM_OK) {
         hipLaunchKernelGGL(march_solve, dim3(1), dim3(kBlock), 0, c->stream, m, S, krow_s, row, s, c->x64, c->z64, c->g64,
-                           c->xh, c->xl, c->zh, c->zl, c->g32, c->progress_dev);
+                           c->mir(), c->g32, c->progress_dev);
         if (hipGetLastError() != hipSuccess) rc = fail(c, LUDVM_E_HIP, "march_solve launch failed");
       }
       c->stream = main_stream;
       CHK(rc);
       HIPCHK(c, hipEventRecord(c->ev_join, c->stream_b));
       const long long nb = std::max<long long>(n_before, 1);
-      const int T = (nb >= kSymT8MinN && !hilo) ? 8 : 4;
+      const int T = sym_tile_t(c, nb, hilo, !hilo);
       const long long ntiles = (nb + 64LL * T - 1) / (64LL * T);
-      CHK(launch_sym_tiles(c, T, c->xh, c->zh, c->g32, nb, 0, ntiles, vc4, acc, acc + nt_pad, hilo ? c->xl : nullptr,
-                           hilo ? c->zl : nullptr, &S->n_old[s & 1]));
+      SymOperands o{};
+      o.g = c->g32;
+      if (hilo) { o.x = c->xh; o.z = c->zh; o.xl = c->xl; o.zl = c->zl; }
+      else { o.x = c->xr; o.z = c->zr; o.cx = c->cx; o.cz = c->cz; }
+      o.acc_u = acc; o.acc_w = acc + nt_pad;
+      o.scale = &S->sc[s & 1]; o.bad = &S->sym_bad;
+      CHK(launch_sym_tiles(c, T, o, nb, 0, ntiles, vc4, &S->n_old[s & 1], n_lo));
       HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
-      if (hilo)
-        hipLaunchKernelGGL(march_finish_sym<true>, dim3(blocks_for(n_ub)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, S,
-                           &S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32,
-                           td);
-      else
-        hipLaunchKernelGGL(march_finish_sym<false>, dim3(blocks_for(n_ub)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, S,
-                           &S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->xh, c->xl, c->zh, c->zl, c->g32,
-                           td);
+      hipLaunchKernelGGL(march_finish_sym, dim3(fin_blocks(n_ub)), dim3(kFinBlock), 0, c->stream, acc, acc + nt_pad,
+                         &S->sc[s & 1], S, &S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->mir(), c->g32, td);
       HIPCHK(c, hipGetLastError());
     }
     n_before = n_ub;
@@ -1444,46 +1532,73 @@ int ludvm_flowfield_dev_f32(ludvm_ctx* c, double xmin, double zmin, double dr, s
   return induce_device(c, a, a.nt, a.ns, LUDVM_PREC_F32, d_u, d_w);
 }
 
-int ludvm_flowfield_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, const double* xs,
-                        const double* zs, const double* gs, size_t ns, double vcore, float* u, float* w) {
-  if (!c) return LUDVM_E_ARG;
-  const size_t nt = nx * nz;
-  if (nt == 0) return LUDVM_OK;
-  if ((ns && (!xs || !zs || !gs)) || !u || !w) return fail(c, LUDVM_E_ARG, "null array");
-  if (ns == 0) {
-    std::memset(u, 0, nt * sizeof(float));
-    std::memset(w, 0, nt * sizeof(float));
-    return LUDVM_OK;
-  }
-  HIPCHK(c, hipSetDevice(c->device));
-  CHK(ensure(c, c->arena, 3 * Arena::need(ns, 8) + 3 * Arena::need(ns, 4) + 2 * Arena::need(nt, 4)));
-  Arena ar(c->arena.p);
+// Sources of a flow field from host float64 arrays: uploaded and converted to local-origin fp32 (offsets from the
+// origin of each 256-source block; the wake arrives in shedding order, so a block is compact).  The grid targets are
+// generated in float64 and referred to each source block's origin, so a flow field over a wake at |x| ~ 50 with
+// vortices 1e-3 apart keeps the precision it has near the origin (LUDVM.py:1206, :1216-1217 evaluate in float64).
+static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, const double* zs, const double* gs, size_t ns,
+                                  PairArgs& a) {
+  const size_t nsb = ns / kOriginBlock + 1;
   double* dxs = ar.take<double>(ns);
   double* dzs = ar.take<double>(ns);
   double* dgs = ar.take<double>(ns);
   float* fxs = ar.take<float>(ns);
   float* fzs = ar.take<float>(ns);
   float* fgs = ar.take<float>(ns);
-  float* du = ar.take<float>(nt);
-  float* dw = ar.take<float>(nt);
+  float* sox = ar.take<float>(nsb);
+  float* soz = ar.take<float>(nsb);
   HIPCHK(c, hipMemcpyAsync(dxs, xs, ns * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dzs, zs, ns * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dgs, gs, ns * 8, hipMemcpyHostToDevice, c->stream));
   const dim3 bs(kBlock), gs_(blocks_for((long long)ns));
-  hipLaunchKernelGGL(cvt_f64_to_f32, gs_, bs, 0, c->stream, dxs, fxs, (float*)nullptr, (long long)ns);
-  hipLaunchKernelGGL(cvt_f64_to_f32, gs_, bs, 0, c->stream, dzs, fzs, (float*)nullptr, (long long)ns);
+  hipLaunchKernelGGL(cvt_f64_to_local, gs_, bs, 0, c->stream, dxs, fxs, sox, (long long)ns);
+  hipLaunchKernelGGL(cvt_f64_to_local, gs_, bs, 0, c->stream, dzs, fzs, soz, (long long)ns);
   hipLaunchKernelGGL(cvt_f64_to_f32, gs_, bs, 0, c->stream, dgs, fgs, (float*)nullptr, (long long)ns);
   HIPCHK(c, hipGetLastError());
-  PairArgs a{};
   a.xs = fxs; a.zs = fzs; a.gs = fgs; a.ns = (long long)ns;
-  a.nt = (long long)nt;
-  a.grid_nz = (long long)nz;
-  a.xmin = xmin; a.zmin = zmin; a.dr = dr;
-  const double v2 = vcore * vcore;
-  a.vc4 = v2 * v2;
-  CHK(induce_device(c, a, a.nt, a.ns, LUDVM_PREC_F32, du, dw));
+  a.scx = sox; a.scz = soz;
+  return LUDVM_OK;
+}
+static size_t flowfield_upload_bytes(size_t ns) {
+  return 3 * Arena::need(ns, 8) + 3 * Arena::need(ns, 4) + 2 * Arena::need(ns / kOriginBlock + 1, 4);
+}
+
+int ludvm_flowfield_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, const double* xs,
+                        const double* zs, const double* gs, size_t ns, double vcore, float* u, float* w) {
+  return ludvm_flowfield_vorticity_f32(c, xmin, zmin, dr, nx, nz, xs, zs, gs, ns, vcore, u, w, nullptr);
+}
+
+int ludvm_flowfield_vorticity_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, const double* xs,
+                                  const double* zs, const double* gs, size_t ns, double vcore, float* u, float* w, float* ome) {
+  if (!c) return LUDVM_E_ARG;
+  const size_t nt = nx * nz;
+  if (nt == 0) return LUDVM_OK;
+  if ((ns && (!xs || !zs || !gs)) || !u || !w) return fail(c, LUDVM_E_ARG, "null array");
+  if (ome && (nx < 2 || nz < 2)) return fail(c, LUDVM_E_ARG, "vorticity needs nx, nz >= 2");
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(ensure(c, c->arena, flowfield_upload_bytes(ns) + 3 * Arena::need(nt, 4)));
+  Arena ar(c->arena.p);
+  float* du = ar.take<float>(nt);
+  float* dw = ar.take<float>(nt);
+  float* dome = ar.take<float>(nt);
+  if (ns == 0) {
+    HIPCHK(c, hipMemsetAsync(du, 0, nt * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(dw, 0, nt * 4, c->stream));
+  } else {
+    PairArgs a{};
+    CHK(flowfield_upload_local(c, ar, xs, zs, gs, ns, a));
+    a.nt = (long long)nt;
+    a.grid_nz = (long long)nz;
+    a.xmin = xmin; a.zmin = zmin; a.dr = dr;
+    const double v2 = vcore * vcore;
+    a.vc4 = v2 * v2;
+    CHK(induce_device(c, a, a.nt, a.ns, LUDVM_PREC_F32, du, dw));
+  }
+  // velocity and vorticity leave the device together: the stencil (LUDVM.py:1224-1292) runs on the fields where they are
+  if (ome) CHK(ludvm_vorticity_dev_f32(c, du, dw, nx, nz, (float)dr, dome));
   HIPCHK(c, hipMemcpyAsync(u, du, nt * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(w, dw, nt * 4, hipMemcpyDeviceToHost, c->stream));
+  if (ome) HIPCHK(c, hipMemcpyAsync(ome, dome, nt * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LUDVM_OK;
 }

@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pair_kernels.hpp"
+#include "pair_sym_kernels.hpp"
 
 namespace ludvm {
 
@@ -40,6 +41,11 @@ struct MarchState {
   double pvel[6];       // what the wake induces there and at the origin: u_tev, u_lev, u_org, w_tev, w_lev, w_org
   double newv[6];       // vortices shed by the step just solved, before their roll-up: x0, x1, z0, z1, g0, g1
   double newvel[4];     // ... and their velocities u0, u1, w0, w1 (wake + each other + bound vortices)
+  double sum_abs_g;     // sum |Gamma| over the wake: bounds the symmetric kernel's raw sums (SymScale)
+  SymScale sc[2];       // fixed-point scale by step parity: march_solve of step s leaves sc[(s + 1) & 1] for the wake
+                        // as it stands after that step's shedding; an overlapped step s (old wake x old wake beside
+                        // its own solve) reads sc[s & 1], a serial symmetric step s reads sc[(s + 1) & 1]
+  long long sym_bad;    // a symmetric launch met a non-finite partial sum (sticky: NaN from there on)
   double prevA[kMarchMaxCoef];
   double chord[6 * kMarchMaxPan];          // coming step: u1 | w1 | u_tev | w_tev | u_lev | w_lev at the chord points
   double tgt[2 * (kMarchMaxPan + 3)];      // targets of the chord launch: x[npan + 3] | z[npan + 3]
@@ -58,6 +64,11 @@ struct MarchSetup {
   const double* opcs; const double* hcsd; const double* wx; const double* cproj; const double* ssin;
 };
 
+// Host-mapped progress ring: march_solve of step s stores (s << 32 | wake size after s) in slot s % kProgressRing.
+// The host reads the slot of a step it KNOWS to be finished (an event recorded behind it has completed), so the bound
+// it derives for the launches it enqueues next depends on the call's arguments only, not on how far the host happens
+// to run ahead: the launch geometry -- and with it every bit of the results -- repeats from run to run.
+constexpr int kProgressRing = 1024;
 constexpr int kMarchRowHead = 12;   // g_tev, g_lev, shed, bound, LESP_prev, LESP, Fn, Fs, M, slot, phantom u, w
 
 inline TailDuty make_tail_duty(MarchState* S, long long step, const double* kin_next, int npan) {
@@ -148,16 +159,30 @@ __device__ __forceinline__ void ramesh_tev_lev(const RameshProj& r, double lesp_
   }
 }
 
-// Start of a march call: the caller supplied the placements of the first step; stage its targets.
+// Start of a march call: the caller supplied the placements of the first step; stage its targets, and sum |Gamma|
+// over the wake as it stands (fixed order) for the symmetric kernel's fixed-point scale.
 __global__ void __launch_bounds__(kBlock)
-march_begin(MarchState* S, const double* kin, int npan, int slot) {
+march_begin(MarchState* S, const double* kin, int npan, int slot, const double* g64, double vc4) {
+  __shared__ double part[kBlock / 64];
   const int t = threadIdx.x;
   const int ntt = npan + 3;
+  const long long n = S->n;
+  double a = 0.0;
+  for (long long i = t; i < n; i += kBlock) a += fabs(g64[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+  if ((t & 63) == 0) part[t >> 6] = a;
+  __syncthreads();
   if (t < npan) { S->tgt[t] = kin[7 + t]; S->tgt[ntt + t] = kin[7 + npan + t]; }
   if (t == 0) {
     S->tgt[npan] = S->place[0]; S->tgt[npan + 1] = S->place[1]; S->tgt[npan + 2] = 0.0;
     S->tgt[ntt + npan] = S->place[2]; S->tgt[ntt + npan + 1] = S->place[3]; S->tgt[ntt + npan + 2] = 0.0;
-    S->n_old[slot] = S->n;
+    S->n_old[slot] = n;
+    const double tot = (part[0] + part[1]) + (part[2] + part[3]);
+    S->sum_abs_g = tot;
+    S->sym_bad = 0;
+    sym_scale_from_sum(tot, vc4, &S->sc[slot], &S->sym_bad);
+    S->sc[slot ^ 1] = S->sc[slot];
   }
 }
 
@@ -202,7 +227,7 @@ march_chord_finish(const double* part, long long nt_pad, int nsplit, const doubl
 // steps it enqueues next without synchronizing.
 __global__ void __launch_bounds__(kBlock)
 march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long long step, double* x64, double* z64,
-            double* g64, float* xh, float* xl, float* zh, float* zl, float* g32, unsigned long long* progress) {
+            double* g64, Mirrors mir, float* g32, unsigned long long* progress) {
   __shared__ double Wn[kMarchMaxPan];
   __shared__ double A[kMarchMaxCoef], Ad[kMarchMaxCoef];
   __shared__ double scratch[kBlock / 64];
@@ -339,6 +364,23 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
   const double suo = block_sum(fuo, scratch), swo = block_sum(fwo, scratch);
   __syncthreads();                                   // all reads of S are done; it is rewritten below
 
+  // Local-origin mirrors of the entries written now -- wake index n0 (TEV), n0 + 1 (LEV when shed), then the npan
+  // bound vortices: an origin block that starts among them takes its origin from the entry written there, the
+  // others keep the origin the last Euler finisher gave them.
+  auto origin_of = [&](long long i, float& ox, float& oz) {
+    const long long b = i >> kOriginShift, bs = b << kOriginShift;
+    if (bs >= n0) {
+      double bx, bz;
+      if (bs == n0) { bx = tev_x; bz = tev_z; }
+      else if (shed && bs == n0 + 1) { bx = lev_x; bz = lev_z; }
+      else { bx = xg[bs - n0 - k]; bz = zg[bs - n0 - k]; }
+      ox = (float)bx; oz = (float)bz;
+      if (i == bs) { mir.cx[b] = ox; mir.cz[b] = oz; }
+    } else {
+      ox = mir.cx[b]; oz = mir.cz[b];
+    }
+  };
+
   if (j == 0) {
     const double c = m.chord, U = m.U, rho = m.rho;
     const double A0 = A[0], A1 = A[1], A2 = A[2];
@@ -359,13 +401,16 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
       row[11] = pwo + swo + g_tev * ww;
     }
     // the shed vortices join the wake (:1095-1098)
+    float ox, oz;
+    origin_of(n0, ox, oz);
     x64[n0] = tev_x; z64[n0] = tev_z; g64[n0] = g_tev;
-    split_hilo(tev_x, xh[n0], xl[n0]); split_hilo(tev_z, zh[n0], zl[n0]); g32[n0] = (float)g_tev;
+    store_mirrors(mir, n0, tev_x, tev_z, ox, oz); g32[n0] = (float)g_tev;
     double m01u = 0, m01w = 0, m10u = 0, m10w = 0;   // TEV <- LEV, LEV <- TEV
     if (shed) {
       const long long n1 = n0 + 1;
+      origin_of(n1, ox, oz);
       x64[n1] = lev_x; z64[n1] = lev_z; g64[n1] = g_lev;
-      split_hilo(lev_x, xh[n1], xl[n1]); split_hilo(lev_z, zh[n1], zl[n1]); g32[n1] = (float)g_lev;
+      store_mirrors(mir, n1, lev_x, lev_z, ox, oz); g32[n1] = (float)g_lev;
       double uu, ww;
       unit_pair_f64(tev_x, tev_z, lev_x, lev_z, m.vc4, uu, ww);
       m01u = g_lev * uu; m01w = g_lev * ww;
@@ -384,8 +429,12 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
     S->lesp_crit = lesp_crit;
     S->sum_tev += g_tev;
     S->sum_lev += g_lev;
+    const double sabs = S->sum_abs_g + fabs(g_tev) + fabs(g_lev);
+    S->sum_abs_g = sabs;
+    sym_scale_from_sum(sabs, m.vc4, &S->sc[(step + 1) & 1], &S->sym_bad);
     if (progress) {
-      __atomic_store_n(progress, ((unsigned long long)step << 32) | (unsigned long long)(n0 + k), __ATOMIC_RELAXED);
+      __atomic_store_n(progress + (step % kProgressRing), ((unsigned long long)step << 32) | (unsigned long long)(n0 + k),
+                       __ATOMIC_RELAXED);
     }
   }
   if (j < ncoef) {
@@ -399,73 +448,53 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
     // bound vortices ride behind the wake as sources of the roll-up (:1106, :1115, :1124)
     const long long i = n0 + k + j;
     const double x = xg[j], z = zg[j];
+    float ox, oz;
+    origin_of(i, ox, oz);
     x64[i] = x; z64[i] = z; g64[i] = dgamma;
-    split_hilo(x, xh[i], xl[i]); split_hilo(z, zh[i], zl[i]); g32[i] = (float)dgamma;
+    store_mirrors(mir, i, x, z, ox, oz); g32[i] = (float)dgamma;
   }
 }
 
 // Euler finisher of the overlapped roll-up.  The symmetric kernel ran on the wake as it was BEFORE this step's
-// solve ([0, n_old), raw sums in acc_u / acc_w); here every old vortex also feels the vortices shed this step
-// (S->newv) and the bound vortices (staged at [n, n + nfoil)), and the shed vortices move with the velocities
-// march_solve left in S->newvel.  The raw sums are zeroed after use, so the accumulators need no memset between
-// steps.  HILO as in the pair kernels.
-template <bool HILO>
-__global__ void __launch_bounds__(kBlock)
-march_finish_sym(float* acc_u, float* acc_w, const MarchState* S, const long long* n_old_p, int nfoil, float vc4, double dt,
-                 double* x64, double* z64, float* xh, float* xl, float* zh, float* zl, const float* g32, TailDuty td) {
-  __shared__ float fx[kBlock + 2], fz[kBlock + 2], fg[kBlock + 2], fxl[HILO ? kBlock + 2 : 1], fzl[HILO ? kBlock + 2 : 1];
-  const int tid = threadIdx.x;
+// solve ([0, n_old), raw fixed-point sums in acc_u / acc_w, scale sc); here every old vortex also feels the vortices
+// shed this step (S->newv) and the bound vortices (staged at [n, n + nfoil)), and the shed vortices move with the
+// velocities march_solve left in S->newvel.  The raw sums are zeroed after use, so the accumulators need no memset
+// between steps.  One workgroup = one origin block (see finish_wake_advect).
+__global__ void __launch_bounds__(kFinBlock)
+march_finish_sym(long long* acc_u, long long* acc_w, const SymScale* sc, const MarchState* S, const long long* n_old_p,
+                 int nfoil, float vc4, double dt, double* x64, double* z64, Mirrors m, const float* g32, TailDuty td) {
+  __shared__ float org[2];
   const long long n = S->n, n_old = *n_old_p;
   const int k = (int)(n - n_old);
-  if (tid < nfoil) {
-    fx[tid] = xh[n + tid]; fz[tid] = zh[n + tid]; fg[tid] = g32[n + tid];
-    if (HILO) { fxl[tid] = xl[n + tid]; fzl[tid] = zl[n + tid]; }
-  }
-  if (tid < k) {
-    // the shed vortices as sources, from the copy the solve kept (their wake entries are moved by this kernel)
-    float h, l;
-    split_hilo(S->newv[tid], h, l);
-    fx[nfoil + tid] = h;
-    if (HILO) fxl[nfoil + tid] = l;
-    split_hilo(S->newv[2 + tid], h, l);
-    fz[nfoil + tid] = h;
-    if (HILO) fzl[nfoil + tid] = l;
-    fg[nfoil + tid] = (float)S->newv[4 + tid];
+  tail_duty_block0(td, n);
+  const long long i = (long long)blockIdx.x * kFinBlock + threadIdx.x;
+  const bool on = i < n, old = i < n_old;
+  const double xo = on ? x64[i] : 0.0, zo = on ? z64[i] : 0.0;
+  float fu, fw;
+  staged_sources_on(old, xo, zo, x64, z64, g32, n, nfoil, vc4, fu, fw, k, S->newv);
+  double xn = 0.0, zn = 0.0;
+  if (on) {
+    double su, sw;
+    if (old) {
+      const float s = (float)kInv2PiD;
+      su = (double)((fx_read(acc_u, i, sc, &S->sym_bad) + fu) * s);
+      sw = (double)(-(fx_read(acc_w, i, sc, &S->sym_bad) + fw) * s);
+      acc_u[i] = 0;
+      acc_w[i] = 0;
+    } else {
+      const int q = (int)(i - n_old);
+      su = S->newvel[q];
+      sw = S->newvel[2 + q];
+    }
+    xn = xo + dt * su;
+    zn = zo + dt * sw;
+    if (i == origin_index(blockIdx.x, n)) { org[0] = (float)xn; org[1] = (float)zn; m.cx[blockIdx.x] = org[0]; m.cz[blockIdx.x] = org[1]; }
   }
   __syncthreads();
-  tail_duty_block0(td, n);
-  const long long i = (long long)blockIdx.x * kBlock + tid;
-  if (i >= n) return;
-  double su, sw;
-  if (i < n_old) {
-    const float s = (float)kInv2PiD;
-    float fu = 0.0f, fw = 0.0f;
-    const float xi = xh[i], zi = zh[i];
-    const float xil = HILO ? xl[i] : 0.0f, zil = HILO ? zl[i] : 0.0f;
-    const int nsrc = nfoil + k;
-    for (int j = 0; j < nsrc; ++j) {
-      float dx = xi - fx[j], dz = zi - fz[j];
-      if (HILO) { dx += xil - fxl[j]; dz += zil - fzl[j]; }
-      const float r2 = __builtin_fmaf(dz, dz, dx * dx);
-      const float kk = fg[j] * __builtin_amdgcn_rsqf(__builtin_fmaf(r2, r2, vc4));
-      fu = __builtin_fmaf(dz, kk, fu);
-      fw = __builtin_fmaf(dx, kk, fw);
-    }
-    su = (double)((acc_u[i] + fu) * s);
-    sw = (double)(-(acc_w[i] + fw) * s);
-    acc_u[i] = 0.0f;
-    acc_w[i] = 0.0f;
-  } else {
-    const int q = (int)(i - n_old);
-    su = S->newvel[q];
-    sw = S->newvel[2 + q];
-  }
-  const double xn = x64[i] + dt * su;
-  const double zn = z64[i] + dt * sw;
+  if (!on) return;
   x64[i] = xn;
   z64[i] = zn;
-  split_hilo(xn, xh[i], xl[i]);
-  split_hilo(zn, zh[i], zl[i]);
+  store_mirrors(m, i, xn, zn, org[0], org[1]);
   tail_duty(td, i, n, xn, zn);
 }
 

@@ -28,6 +28,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts, one per SIMD
+// Local origins: fp32 positions are stored as offsets from the origin of their 256-vortex block
+// (block b = indices [256 b, 256 b + 256), origin = the fp32-rounded position of one of its vortices); a pair
+// difference is then (offset_p + (origin_p - origin_w)) - offset_w, with the origin difference added to the
+// targets once per block pair.  The wake is stored in shedding order, so a block is spatially compact: pairs
+// in nearby blocks keep (almost) full relative precision at any distance from the coordinate origin, far blocks
+// do not need it.  Costs nothing in the pair loop (unlike hi+lo positions: +4 packed ops per two pairs).
+// Measured [MI355X] on a wake at |x| ~ 50 with vortices 1e-3 apart (v_core = 1.3e-3): 1.4e-3 of max|u| with plain
+// fp32 coordinates, 1.7e-5 with 512-vortex blocks whose origin is their first vortex, < 1e-5 with 256-vortex
+// blocks whose origin is their middle vortex (what is built here), 1e-6 with hi+lo positions.
+constexpr int kOriginShift = 8;
+constexpr int kOriginBlock = 1 << kOriginShift;   // = the 256-vortex tile of pair_sym_f32<4>
+constexpr int kFinBlock = kOriginBlock;           // Euler finishers: one workgroup per origin block
 constexpr double kInv2PiD = 0.15915494309189533576888;
 // Padding for source slots past the end of the range: far enough that r^4 overflows to +inf, so
 // rsq() returns exactly 0 and the (zero-circulation) slot contributes exactly 0 even when vc = 0
@@ -58,6 +70,13 @@ struct PairArgs {
   // from the host's upper bound; surplus blocks find nothing to do.
   const long long* n_dev;
   int ns_dev, nt_dev;
+  // LOCAL kernels: xs / zs are offsets from the origin of their 256-source block, scx / scz the origins (block
+  // index = source index >> kOriginShift, the source arrays start on a block boundary).  Array targets are offsets too,
+  // their origins are tcx / tcz[(t_index0 + p) >> kOriginShift]; grid targets are generated in float64 and referred to
+  // the source block's origin directly.
+  const float* scx; const float* scz;
+  const float* tcx; const float* tcz;
+  long long t_index0;
 };
 
 struct PairSizes { long long ns, nt; };
@@ -88,11 +107,15 @@ __device__ __forceinline__ void grid_point(const PairArgs& a, long long p, doubl
 // GRIDROW = true (flow-field grids with nz % TPL == 0): a lane owns TPL CONSECUTIVE grid points of one
 //               row (same x, z stepping by dr), so dx and dx^2 are computed once per source pair and
 //               shared by the lane's targets: 6 instead of 8 packed ops per two pairs and target.
-template <int TPL, int TILE, bool HILO, bool GRIDROW = false>
+// LOCAL = true: positions are offsets from block origins (see kOriginShift); the targets are re-referred to the
+//               origin of each 256-source segment of the LDS tile (TPL adds per 256 sources).
+template <int TPL, int TILE, bool HILO, bool GRIDROW = false, bool LOCAL = false>
 __global__ void __launch_bounds__(kBlock)
 pair_f32(PairArgs a) {
   static_assert(TILE % kBlock == 0, "tile must be a multiple of the block size");
   static_assert(!(GRIDROW && HILO), "the grid variant is plain fp32");
+  static_assert(!(LOCAL && HILO), "local origins replace hi+lo positions");
+  static_assert(!LOCAL || TILE <= kOriginBlock || TILE % kOriginBlock == 0, "tile must be whole origin blocks");
   __shared__ __attribute__((aligned(16))) float lx[TILE];
   __shared__ __attribute__((aligned(16))) float lz[TILE];
   __shared__ __attribute__((aligned(16))) float lg[TILE];
@@ -116,10 +139,14 @@ pair_f32(PairArgs a) {
   if (s_end > sz.ns) s_end = sz.ns;
 
   f32x2 xp[TPL], zp[TPL], xpl[TPL], zpl[TPL], au[TPL], aw[TPL];
+  // LOCAL: what the targets are re-referred from -- exact grid coordinates, or offsets + origins
+  double gxd[LOCAL ? TPL : 1], gzd[LOCAL ? TPL : 1];
+  float tox[LOCAL ? TPL : 1], toz[LOCAL ? TPL : 1], tlx[LOCAL ? TPL : 1], tlz[LOCAL ? TPL : 1];
 #pragma unroll
   for (int t = 0; t < TPL; ++t) {
     const long long ti = t0 + (long long)t * kTStride;
     float x = 0.0f, z = 0.0f, xl = 0.0f, zl = 0.0f;
+    if (LOCAL) { gxd[t] = 0.0; gzd[t] = 0.0; tox[t] = 0.0f; toz[t] = 0.0f; tlx[t] = 0.0f; tlz[t] = 0.0f; }
     if (ti < sz.nt) {
       if (a.grid_nz > 0) {
         double xd, zd;
@@ -127,6 +154,13 @@ pair_f32(PairArgs a) {
         x = (float)xd;
         z = (float)zd;
         if (HILO) { xl = (float)(xd - (double)x); zl = (float)(zd - (double)z); }
+        if (LOCAL) { gxd[t] = xd; gzd[t] = zd; }
+      } else if (LOCAL) {
+        const long long tb = (a.t_index0 + ti) >> kOriginShift;
+        tlx[t] = static_cast<const float*>(a.xt)[ti];
+        tlz[t] = static_cast<const float*>(a.zt)[ti];
+        tox[t] = a.tcx[tb];
+        toz[t] = a.tcz[tb];
       } else {
         x = static_cast<const float*>(a.xt)[ti];
         z = static_cast<const float*>(a.zt)[ti];
@@ -167,8 +201,29 @@ pair_f32(PairArgs a) {
 #pragma unroll
     for (int t = 0; t < TPL; ++t) { tu[t] = (f32x2){0.0f, 0.0f}; tw[t] = (f32x2){0.0f, 0.0f}; }
 
+    constexpr int kSeg = LOCAL ? (TILE < kOriginBlock ? TILE : kOriginBlock) : TILE;
+    for (int seg = 0; seg < TILE; seg += kSeg) {
+    if (LOCAL) {
+      // the segment's sources share one origin: refer this lane's targets to it
+      const long long sidx = base + seg;
+      if (sidx >= s_end) break;
+      const float ox = a.scx[sidx >> kOriginShift], oz = a.scz[sidx >> kOriginShift];
+#pragma unroll
+      for (int t = 0; t < TPL; ++t) {
+        float x, z;
+        if (a.grid_nz > 0) {
+          x = (float)(gxd[t] - (double)ox);
+          z = (float)(gzd[t] - (double)oz);
+        } else {
+          x = tlx[t] + (tox[t] - ox);
+          z = tlz[t] + (toz[t] - oz);
+        }
+        xp[t] = (f32x2){x, x};
+        zp[t] = (f32x2){z, z};
+      }
+    }
 #pragma unroll 2
-    for (int j = 0; j < TILE; j += 4) {
+    for (int j = seg; j < seg + kSeg; j += 4) {
       const f32x4 X = *reinterpret_cast<const f32x4*>(&lx[j]);
       const f32x4 Z = *reinterpret_cast<const f32x4*>(&lz[j]);
       const f32x4 G = *reinterpret_cast<const f32x4*>(&lg[j]);
@@ -219,6 +274,7 @@ pair_f32(PairArgs a) {
           tw[t] = __builtin_elementwise_fma(dx, s, tw[t]);
         }
       }
+    }
     }
 #pragma unroll
     for (int t = 0; t < TPL; ++t) { au[t] = au[t] + tu[t]; aw[t] = aw[t] + tw[t]; }
@@ -390,6 +446,30 @@ __device__ __forceinline__ void split_hilo(double v, float& hi, float& lo) {
   lo = (float)(v - (double)hi);
 }
 
+// The fp32 mirrors of the resident wake's float64 master positions: (xh, xl) / (zh, zl) hi+lo pairs for the
+// f32x2 kernels, (xr, zr) offsets from the block origins (cx, cz)[index >> 9] for the local-origin fp32 kernels.
+// Invariant: xr[i] = (float)(x64[i] - cx[i >> kOriginShift]) for every stored vortex; cx[b] is the fp32 position a
+// vortex of block b had when the block's offsets were last rewritten (the middle one, or the last one of a block
+// that is not yet half full).
+struct Mirrors {
+  float* xh; float* xl; float* zh; float* zl;
+  float* xr; float* zr; float* cx; float* cz;
+};
+
+// Which vortex of origin block `b` lends the block its origin when n vortices are stored: the middle one, or the
+// newest while the block is less than half full.
+__device__ __forceinline__ long long origin_index(long long b, long long n) {
+  const long long mid = (b << kOriginShift) + kOriginBlock / 2;
+  return mid < n ? mid : n - 1;
+}
+
+__device__ __forceinline__ void store_mirrors(const Mirrors& m, long long i, double x, double z, float ox, float oz) {
+  split_hilo(x, m.xh[i], m.xl[i]);
+  split_hilo(z, m.zh[i], m.zl[i]);
+  m.xr[i] = (float)(x - (double)ox);
+  m.zr[i] = (float)(z - (double)oz);
+}
+
 // Device-resident march: what the Euler finisher leaves for the coming time step (march_kernels.hpp), done by the
 // threads that have the data in their hands.  The thread that has just moved the newest TEV / LEV places the
 // next ones one third of the way from the shedding edge (LUDVM.py:680-681, :797-800); block 0 copies the coming
@@ -444,36 +524,51 @@ __device__ __forceinline__ void tail_duty_block0(const TailDuty& td, long long n
 
 // Resident-wake Euler step (LUDVM.py:1108-1127): float64 update of the master copy from the summed
 // partials (T = float for the fp32 kernels, double for the fp64 one), refresh of the fp32 mirrors.
+// One workgroup of kFinBlock threads = one origin block: its middle vortex's new position becomes the block's
+// origin, so the local offsets stay small however far the wake drifts.
 template <typename T>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kFinBlock)
 finish_wake_advect(const T* part, long long nt, long long nt_pad, int nsplit, double dt, double* x64, double* z64,
-                   float* xh, float* xl, float* zh, float* zl, double* u_out, double* w_out,
-                   const long long* n_dev = nullptr, TailDuty td = TailDuty{}) {
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+                   Mirrors m, double* u_out, double* w_out, const long long* n_dev = nullptr, TailDuty td = TailDuty{}) {
+  __shared__ float org[2];
+  const long long i = (long long)blockIdx.x * kFinBlock + threadIdx.x;
   if (n_dev) nt = *n_dev;          // device-resident march: the wake size lives on the device
   tail_duty_block0(td, nt);
-  if (i >= nt) return;
-  T su, sw;
-  sum_splits(part, i, nt_pad, nsplit, su, sw);
-  if (u_out) { u_out[i] = (double)su; w_out[i] = (double)sw; }
-  const double xn = x64[i] + dt * (double)su;
-  const double zn = z64[i] + dt * (double)sw;
+  const bool on = i < nt;
+  double xn = 0.0, zn = 0.0;
+  if (on) {
+    T su, sw;
+    sum_splits(part, i, nt_pad, nsplit, su, sw);
+    if (u_out) { u_out[i] = (double)su; w_out[i] = (double)sw; }
+    xn = x64[i] + dt * (double)su;
+    zn = z64[i] + dt * (double)sw;
+    if (i == origin_index(blockIdx.x, nt)) { org[0] = (float)xn; org[1] = (float)zn; m.cx[blockIdx.x] = org[0]; m.cz[blockIdx.x] = org[1]; }
+  }
+  __syncthreads();
+  if (!on) return;
   x64[i] = xn;
   z64[i] = zn;
-  split_hilo(xn, xh[i], xl[i]);
-  split_hilo(zn, zh[i], zl[i]);
+  store_mirrors(m, i, xn, zn, org[0], org[1]);
   tail_duty(td, i, nt, xn, zn);
 }
 
-// Refresh the fp32 mirrors of [first, first+count) after a host write of the float64 master.
+// Rebuild the fp32 mirrors of every origin block that intersects [first, first + count) from the float64
+// masters (after a host write): the block's origin is re-taken (origin_index over the `stored` entries), so the
+// whole block is refreshed.  Entries of a touched block that lie beyond the stored range are computed from whatever
+// the master arrays hold there and are never read.  `limit` = allocated capacity.
 __global__ void __launch_bounds__(kBlock)
-refresh_mirrors(long long first, long long count, const double* x64, const double* z64, const double* g64,
-                float* xh, float* xl, float* zh, float* zl, float* g32) {
-  const long long k = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= count) return;
-  const long long i = first + k;
-  split_hilo(x64[i], xh[i], xl[i]);
-  split_hilo(z64[i], zh[i], zl[i]);
+refresh_mirrors(long long first, long long count, long long stored, long long limit, const double* x64, const double* z64,
+                const double* g64, Mirrors m, float* g32) {
+  const long long lo = (first >> kOriginShift) << kOriginShift;
+  const long long i = lo + (long long)blockIdx.x * kBlock + threadIdx.x;
+  long long hi = ((first + count + kOriginBlock - 1) >> kOriginShift) << kOriginShift;
+  if (hi > limit) hi = limit;
+  if (i >= hi) return;
+  const long long b = i >> kOriginShift;
+  const long long oi = origin_index(b, stored);
+  const float ox = (float)x64[oi], oz = (float)z64[oi];
+  if ((i & (kOriginBlock - 1)) == 0) { m.cx[b] = ox; m.cz[b] = oz; }
+  store_mirrors(m, i, x64[i], z64[i], ox, oz);
   g32[i] = (float)g64[i];
 }
 
@@ -494,6 +589,18 @@ cvt_f32_to_f64(const float* in, double* out, long long n) {
   if (i < n) out[i] = (double)in[i];
 }
 
+// float64 -> local-origin fp32 for the stateless host API: off[i] = (float)(in[i] - org[i >> kOriginShift]) with
+// org[b] = (float)in[origin_index(b, n)].
+__global__ void __launch_bounds__(kBlock)
+cvt_f64_to_local(const double* in, float* off, float* org, long long n) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const long long b = i >> kOriginShift;
+  const float o = (float)in[origin_index(b, n)];
+  if ((i & (kOriginBlock - 1)) == 0) org[b] = o;
+  off[i] = (float)(in[i] - (double)o);
+}
+
 // Small stateless calls: the five float64 input arrays arrive in one packed upload, in = xs[ns] | zs[ns] | gs[ns] |
 // xt[nt] | zt[nt]; one launch splits them into the fp32 (hi, lo) arrays the kernels read.
 __global__ void __launch_bounds__(kBlock)
@@ -509,6 +616,27 @@ cvt_packed_inputs(const double* in, long long ns, long long nt, float* xs, float
   else if (k < 3 * ns) { gs[k - 2 * ns] = h; }
   else if (k < 3 * ns + nt) { xt[k - 3 * ns] = h; xtl[k - 3 * ns] = l; }
   else { zt[k - 3 * ns - nt] = h; ztl[k - 3 * ns - nt] = l; }
+}
+
+// The same packed block as local-origin fp32: offsets from the origin of each array's own 256-element blocks
+// (origin = fp32 value of the block's middle element).  nt = 0 when the targets are the sources themselves.
+__global__ void __launch_bounds__(kBlock)
+cvt_packed_inputs_local(const double* in, long long ns, long long nt, float* xs, float* zs, float* gs, float* sox, float* soz,
+                        float* xt, float* zt, float* tox, float* toz) {
+  const long long k = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= 3 * ns + 2 * nt) return;
+  const double v = in[k];
+  auto local = [&](long long base, long long i, long long len, float* off, float* org) {
+    const long long b = i >> kOriginShift;
+    const float o = (float)in[base + origin_index(b, len)];
+    if ((i & (kOriginBlock - 1)) == 0) org[b] = o;
+    off[i] = (float)(v - (double)o);
+  };
+  if (k < ns) local(0, k, ns, xs, sox);
+  else if (k < 2 * ns) local(ns, k - ns, ns, zs, soz);
+  else if (k < 3 * ns) gs[k - 2 * ns] = (float)v;
+  else if (k < 3 * ns + nt) local(3 * ns, k - 3 * ns, nt, xt, tox);
+  else local(3 * ns + nt, k - 3 * ns - nt, nt, zt, toz);
 }
 
 // ... and the two fp32 results leave as one float64 block out = u[nt] | w[nt].
@@ -538,19 +666,33 @@ unit_influence_f64(const double* xt, const double* zt, long long nt, const doubl
 // One kernel stages everything a time step uploads: `n_new` shed vortices appended at wake index n0 and
 // `n_foil` bound vortices behind them (sources of the roll-up only), from one packed host->device copy
 // pack = [new_x | new_z | new_g | foil_x | foil_z | foil_g]; float64 masters and fp32 mirrors are written.
+// An origin block that starts inside the staged range takes its origin from the vortex staged there.
 __global__ void __launch_bounds__(kBlock)
-stage_step_inputs(const double* pack, long long n0, int n_new, int n_foil, double* x64, double* z64, double* g64, float* xh,
-                  float* xl, float* zh, float* zl, float* g32) {
+stage_step_inputs(const double* pack, long long n0, int n_new, int n_foil, double* x64, double* z64, double* g64, Mirrors m,
+                  float* g32) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= n_new + n_foil) return;
-  const double* base = k < n_new ? pack : pack + 3 * n_new;
-  const int cnt = k < n_new ? n_new : n_foil;
-  const int j = k < n_new ? k : k - n_new;
-  const double x = base[j], z = base[cnt + j], g = base[2 * cnt + j];
+  auto staged = [&](int q, double& x, double& z, double& g) {
+    const double* base = q < n_new ? pack : pack + 3 * n_new;
+    const int cnt = q < n_new ? n_new : n_foil;
+    const int j = q < n_new ? q : q - n_new;
+    x = base[j]; z = base[cnt + j]; g = base[2 * cnt + j];
+  };
+  double x, z, g;
+  staged(k, x, z, g);
   const long long i = n0 + k;
+  const long long b = i >> kOriginShift, bs = b << kOriginShift;
+  float ox, oz;
+  if (bs >= n0) {
+    double bx, bz, bg;
+    staged((int)(bs - n0), bx, bz, bg);
+    ox = (float)bx; oz = (float)bz;
+    if (i == bs) { m.cx[b] = ox; m.cz[b] = oz; }
+  } else {
+    ox = m.cx[b]; oz = m.cz[b];
+  }
   x64[i] = x; z64[i] = z; g64[i] = g;
-  split_hilo(x, xh[i], xl[i]);
-  split_hilo(z, zh[i], zl[i]);
+  store_mirrors(m, i, x, z, ox, oz);
   g32[i] = (float)g;
 }
 

@@ -18,18 +18,32 @@
 //     which holds the self pairs) is evaluated with the ordered formula.  Because the work of a tile I
 //     depends on I alone, a GPU that owns a contiguous block of I tiles does exactly 1/G of the job
 //     (multi-GPU: the raw sums are then reduce-scattered, see ludvm_amd/sharded.py);
-//   * results are accumulated with float atomics into acc_u / acc_w (zeroed by the caller) and turned
-//     into velocities (or an Euler step) by a finisher.  The summation order of the atomics is not
-//     fixed: results are reproducible to rounding, not bitwise (the direct kernel is bitwise).
+//   * results are accumulated into acc_u / acc_w (zeroed by the caller) as 64-BIT FIXED-POINT INTEGERS: each
+//     wave's partial sum -- an fp32 number computed in a fixed order -- is scaled by a per-launch power of two,
+//     truncated to an integer and added with global_atomic_add_x2.  Integer addition is associative, so the
+//     result does not depend on the order in which the atomics land: a launch repeats BIT FOR BIT, and so do
+//     the sums of several GPUs that split the tiles between them (the reference is deterministic too).  The
+//     scale comes from the bound |sum| <= sum|Gamma| / (sqrt(2) v_core) of the Vatistas kernel (SymScale); a
+//     finisher turns the integers into velocities (or an Euler step).  v_core = 0 has no such bound: inviscid
+//     self-interaction launches use the direct kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pair_kernels.hpp"
 
 namespace ludvm {
 
+// Fixed-point scale of a launch's raw sums (device memory; written by sym_prepare or by march_solve).
+struct SymScale {
+  float scale;   // a power of two: a partial sum p is accumulated as (long long)(p * scale)
+  float pad;
+  double inv;    // 1 / scale
+};
+
 struct SymArgs {
   const float* x; const float* z; const float* g;  // N vortices (device)
   const float* xl; const float* zl;                // lo parts of the positions (HILO kernels only)
+  const float* cx; const float* cz;                // non-null: x, z are offsets from the origins cx, cz[i >> 8] of their
+                                                   //   256-vortex blocks (local origins, pair_kernels.hpp)
   long long n;
   long long ntiles;      // ceil(n / (64*T))
   long long dmax;        // floor((ntiles-1)/2): symmetric offsets 1..dmax (+ ntiles/2 when even)
@@ -37,12 +51,49 @@ struct SymArgs {
   long long i_count;     //   global tile ring (multi-GPU), or all tiles
   int ysplit;            // number of d-chunks (gridDim.x = ceil(i_count*ysplit*rsplit / 4))
   int rsplit;            // 1, 2 or 4: the 64 rotation steps of a tile pair are shared by this many waves
-  float* acc_u; float* acc_w;  // raw sums: u = acc_u/(2 pi), w = -acc_w/(2 pi)
+  int tune_split, tune_rsplit;   // ludvm_set_tuning / ludvm_set_sym_tuning overrides (0 = heuristics), for n_dev launches
+  long long* acc_u; long long* acc_w;   // raw fixed-point sums: u = acc_u / (scale 2 pi), w = -acc_w / (scale 2 pi)
+  const SymScale* scale;
+  long long* bad;        // incremented when a partial sum is not finite (NaN / inf inputs): the finisher then
+                         //   returns NaN, as the reference's sum over all sources would
   float vc4;
-  // Device-resident march (single GPU, all tiles): n is read from memory and ntiles / dmax / i_count follow
-  // from it; the grid and ysplit come from the host's upper bound, surplus waves leave at once.
+  // Device-resident march (single GPU, all tiles): n is read from memory and ntiles / dmax / i_count / ysplit /
+  // rsplit follow from it by the same rule the host uses (sym_geometry); the grid is sized from the host's upper
+  // bound and surplus waves leave at once.
   const long long* n_dev;
 };
+
+// Launch geometry as a function of the vortex count alone (not of the owner's share, not of a host-side bound):
+// the partition of the work into partial sums -- and with it every bit of the result -- is then the same for a
+// march step sized from an upper bound, for one GPU and for G GPUs that own I-tile blocks of the same ring.
+constexpr long long kSymTargetWaves = 8 * 65536;   // (I, d-chunk) work items aimed for over the whole ring
+constexpr long long kSymMaxSplit = 64;
+constexpr long long kSymMaxRsplit = 4;
+constexpr long long kSymMinItems = 9000;           // measured (profiles/r01_sym_kernel_rotation_split.txt)
+struct SymGeom { long long ntiles, dmax, dtot; int ysplit, rsplit; };
+__host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_split, int tune_rsplit) {
+  SymGeom g;
+  const long long W = 64LL * T;
+  g.ntiles = (n + W - 1) / W;
+  g.dmax = (g.ntiles - 1) / 2;
+  g.dtot = g.dmax + ((g.ntiles % 2 == 0 && g.ntiles > 1) ? 1 : 0);
+  const long long nt1 = g.ntiles > 0 ? g.ntiles : 1;
+  long long ys = tune_split > 0 ? tune_split : (kSymTargetWaves + nt1 - 1) / nt1;
+  if (ys > kSymMaxSplit) ys = kSymMaxSplit;
+  if (ys > g.dtot) ys = g.dtot;
+  if (ys < 1) ys = 1;
+  long long rs = 1;
+  if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) rs = tune_rsplit;
+  else while (rs < kSymMaxRsplit && nt1 * ys * rs < kSymMinItems) rs *= 2;
+  g.ysplit = (int)ys;
+  g.rsplit = (int)rs;
+  return g;
+}
+
+// acc += (long long)(v * scale): order-independent accumulation of an fp32 partial sum
+__device__ __forceinline__ void fx_add(long long* acc, float v, float scale) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)(v * scale));
+}
 
 // lane l receives the value of lane l+1 (wrapping): data moves one lane down
 __device__ __forceinline__ float dpp_rol1(float v) {
@@ -82,9 +133,12 @@ pair_sym_f32(SymArgs a) {
   static_assert(T == 4 || T == 8, "T vortices per lane, read as T/4 ds_read_b128 per component");
   if (a.n_dev) {
     a.n = *a.n_dev;
-    a.ntiles = (a.n + 64LL * T - 1) / (64LL * T);
-    a.dmax = (a.ntiles - 1) / 2;
-    a.i_count = a.ntiles;
+    const SymGeom gm = sym_geometry(a.n, T, a.tune_split, a.tune_rsplit);
+    a.ntiles = gm.ntiles;
+    a.dmax = gm.dmax;
+    a.i_count = gm.ntiles;
+    a.ysplit = gm.ysplit;
+    a.rsplit = gm.rsplit;
   }
   constexpr int H = T / 2;
   constexpr int kWaves = kBlock / 64;
@@ -92,7 +146,7 @@ pair_sym_f32(SymArgs a) {
   __shared__ __attribute__((aligned(16))) float slab[kWaves][kComp][64 * T];
 
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: tile indices stay scalar
   const long long wid = (long long)blockIdx.x * kWaves + wv;
   if (wid >= a.i_count * a.ysplit * a.rsplit) return;   // whole waves leave together; no block-wide barrier is used
   const long long I = a.i_first + wid % a.i_count;
@@ -118,8 +172,12 @@ pair_sym_f32(SymArgs a) {
   long long d_hi = d_lo + per;  // exclusive
   if (d_hi > dtot + 1) d_hi = dtot + 1;
 
-  // my targets (duplicated into register pairs: the packed ops pair two SOURCES against one target)
+  // my targets (duplicated into register pairs: the packed ops pair two SOURCES against one target).  With local
+  // origins a 512-vortex tile (T = 8) spans NS = 2 origin blocks: the targets are then kept once per origin block
+  // of the partner tile (xq / zq[s]: referred to the origin of J's s-th block), selected by the source's block.
+  constexpr int NS = T / 4;
   f32x2 xp[T], zp[T], gp[T], au[T], aw[T], xpl[T], zpl[T];
+  f32x2 xq[NS][T], zq[NS][T];
   float x0[T], z0[T], g0[T], xl0[T], zl0[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -132,6 +190,25 @@ pair_sym_f32(SymArgs a) {
     au[t] = (f32x2){0.f, 0.f}; aw[t] = (f32x2){0.f, 0.f};
   }
   const f32x2 vc4 = {a.vc4, a.vc4};
+  const float fxs = a.scale->scale;
+  // local origins: the origins of this tile's NS origin blocks (vortex I*W + lane + 64 t lies in block t / 4)
+  const bool local = !HILO && a.cx != nullptr;
+  float oix[NS], oiz[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    oix[q] = 0.0f; oiz[q] = 0.0f;
+    if (local) { oix[q] = a.cx[((I * W) >> kOriginShift) + q]; oiz[q] = a.cz[((I * W) >> kOriginShift) + q]; }
+  }
+#pragma unroll
+  for (int q = 0; q < NS; ++q)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      // diagonal tile: block t / 4 of I against block q of I
+      const float ddx = oix[t / 4] - oix[q], ddz = oiz[t / 4] - oiz[q];
+      xq[q][t] = (f32x2){x0[t] + ddx, x0[t] + ddx};
+      zq[q][t] = (f32x2){z0[t] + ddz, z0[t] + ddz};
+    }
+  float chk = 0.0f;   // sum of everything this lane hands to the accumulators: not finite <=> some partial is not
 
   // ---- diagonal tile: ordered evaluation, i-side only (contains the self pairs) ----------------
   if (y == 0) {
@@ -149,8 +226,8 @@ pair_sym_f32(SymArgs a) {
       for (int m = 0; m < H; ++m) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          f32x2 dx = xp[t] - xj[m];
-          f32x2 dz = zp[t] - zj[m];
+          f32x2 dx = (HILO ? xp[t] : xq[m / 2][t]) - xj[m];
+          f32x2 dz = (HILO ? zp[t] : zq[m / 2][t]) - zj[m];
           if (HILO) { dx = dx + (xpl[t] - xjl[m]); dz = dz + (zpl[t] - zjl[m]); }
           f32x2 r2 = dx * dx;
           r2 = __builtin_elementwise_fma(dz, dz, r2);
@@ -171,6 +248,23 @@ pair_sym_f32(SymArgs a) {
     if (even && d == dtot && I >= a.ntiles / 2) break;  // the half-way offset pairs each tile twice
     long long J = I + d;
     if (J >= a.ntiles) J -= a.ntiles;
+    if (local) {
+      // refer my targets to the origins of the partner tile's blocks: one rounding of (origin_I - origin_J) + offset
+      // per target and block pair; neighbouring blocks keep their relative precision, far ones do not need it
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        // (re-read rather than kept in registers: T loads per 64 * T * T pair evaluations)
+        const long long i = I * W + lane + 64LL * t;
+        const bool ok = i < a.n;
+        const float xi = ok ? a.x[i] : kPadPosF, zi = ok ? a.z[i] : kPadPosF;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const long long jb = ((J * W) >> kOriginShift) + q;
+          const float xx = xi + (oix[t / 4] - a.cx[jb]), zz = zi + (oiz[t / 4] - a.cz[jb]);
+          xq[q][t] = (f32x2){xx, xx}; zq[q][t] = (f32x2){zz, zz};
+        }
+      }
+    }
     {
       float x[T], z[T], g[T], xl[T], zl[T];
 #pragma unroll
@@ -202,8 +296,8 @@ pair_sym_f32(SymArgs a) {
       for (int m = 0; m < H; ++m) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          f32x2 dx = xp[t] - xj[m];
-          f32x2 dz = zp[t] - zj[m];
+          f32x2 dx = (HILO ? xp[t] : xq[m / 2][t]) - xj[m];
+          f32x2 dz = (HILO ? zp[t] : zq[m / 2][t]) - zj[m];
           if (HILO) { dx = dx + (xpl[t] - xjl[m]); dz = dz + (zpl[t] - zjl[m]); }
           f32x2 r2 = dx * dx;
           r2 = __builtin_elementwise_fma(dz, dz, r2);
@@ -228,8 +322,8 @@ pair_sym_f32(SymArgs a) {
 #pragma unroll
     for (int m = 0; m < H; ++m) {
       const long long j0 = J * W + home + 64LL * (2 * m), j1 = j0 + 64;
-      if (j0 < a.n) { atomicAdd(&a.acc_u[j0], -bu[m].x); atomicAdd(&a.acc_w[j0], -bw[m].x); }
-      if (j1 < a.n) { atomicAdd(&a.acc_u[j1], -bu[m].y); atomicAdd(&a.acc_w[j1], -bw[m].y); }
+      if (j0 < a.n) { fx_add(&a.acc_u[j0], -bu[m].x, fxs); fx_add(&a.acc_w[j0], -bw[m].x, fxs); chk += bu[m].x + bw[m].x; }
+      if (j1 < a.n) { fx_add(&a.acc_u[j1], -bu[m].y, fxs); fx_add(&a.acc_w[j1], -bw[m].y, fxs); chk += bu[m].y + bw[m].y; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next tile
@@ -238,73 +332,152 @@ pair_sym_f32(SymArgs a) {
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const long long i = I * W + lane + 64LL * t;
-    if (i < a.n) { atomicAdd(&a.acc_u[i], au[t].x + au[t].y); atomicAdd(&a.acc_w[i], aw[t].x + aw[t].y); }
+    if (i < a.n) {
+      const float su = au[t].x + au[t].y, sw = aw[t].x + aw[t].y;
+      fx_add(&a.acc_u[i], su, fxs); fx_add(&a.acc_w[i], sw, fxs);
+      chk += su + sw;
+    }
   }
+  if (!(__builtin_fabsf(chk) < __builtin_inff())) atomicAdd(reinterpret_cast<unsigned long long*>(a.bad), 1ULL);
+}
+
+// One workgroup: the fixed-point scale of a launch from sum |Gamma| (summed in a fixed order -> the same bits every
+// time, on every GPU that holds the same array).  |raw sum| <= sum|Gamma| max_r r / sqrt(r^4 + vc^4) = sum|Gamma| /
+// (sqrt(2) vc); the scale leaves a factor 4 of headroom under 2^63 on top of that.  Also clears the launch's NaN flag.
+constexpr int kPrepBlock = 1024;
+__device__ __forceinline__ void sym_scale_from_sum(double sum_abs, double vc4, SymScale* out, long long* bad) {
+  const double vc = sqrt(sqrt(vc4));
+  const double bound = sum_abs / (1.4142135623730951 * vc);
+  int e = 0;
+  if (bound > 0.0 && bound < 1.0e300) (void)frexp(bound, &e);    // bound < 2^e
+  else if (!(bound == 0.0) && bad) atomicAdd(reinterpret_cast<unsigned long long*>(bad), 1ULL);   // NaN / inf strengths
+  int k = 61 - e;
+  if (k > 120) k = 120;
+  if (k < -120) k = -120;
+  out->scale = (float)ldexp(1.0, k);
+  out->pad = 0.0f;
+  out->inv = ldexp(1.0, -k);
+}
+
+__global__ void __launch_bounds__(kPrepBlock)
+sym_prepare(const float* g, long long n, double vc4, SymScale* out, long long* bad) {
+  __shared__ double part[kPrepBlock / 64];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += kPrepBlock) s += (double)__builtin_fabsf(g[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < kPrepBlock / 64; ++w) tot += part[w];
+    *bad = 0;
+    sym_scale_from_sum(tot, vc4, out, bad);
+  }
+}
+
+// fixed-point raw sum -> fp32 raw sum (NaN when the launch met a non-finite partial sum)
+__device__ __forceinline__ float fx_read(const long long* acc, long long i, const SymScale* sc, const long long* bad) {
+  if (*bad != 0) return __builtin_nanf("");
+  return (float)((double)acc[i] * sc->inv);
 }
 
 // acc -> velocities
 __global__ void __launch_bounds__(kBlock)
-finish_sym(const float* acc_u, const float* acc_w, long long n, float* u, float* w) {
+finish_sym(const long long* acc_u, const long long* acc_w, const SymScale* sc, const long long* bad, long long n, float* u,
+           float* w) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float s = (float)kInv2PiD;
-  u[i] = acc_u[i] * s;
-  w[i] = -acc_w[i] * s;
+  u[i] = fx_read(acc_u, i, sc, bad) * s;
+  w[i] = -fx_read(acc_w, i, sc, bad) * s;
 }
 
 // raw sums of targets [t_first, t_first + nt) (sum_u[i], sum_w[i] belong to target t_first + i) -> Euler step
 __global__ void __launch_bounds__(kBlock)
-finish_sym_advect(const float* sum_u, const float* sum_w, const float* x, const float* z, long long t_first, long long nt,
-                  float dt, float* x_out, float* z_out) {
+finish_sym_advect(const long long* sum_u, const long long* sum_w, const SymScale* sc, const long long* bad, const float* x,
+                  const float* z, long long t_first, long long nt, float dt, float* x_out, float* z_out) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nt) return;
   const float s = (float)kInv2PiD;
-  x_out[i] = __builtin_fmaf(dt, sum_u[i] * s, x[t_first + i]);
-  z_out[i] = __builtin_fmaf(dt, -sum_w[i] * s, z[t_first + i]);
+  x_out[i] = __builtin_fmaf(dt, fx_read(sum_u, i, sc, bad) * s, x[t_first + i]);
+  z_out[i] = __builtin_fmaf(dt, -fx_read(sum_w, i, sc, bad) * s, z[t_first + i]);
 }
 
-// Resident-wake Euler step from the symmetric kernel's raw sums, plus the velocity induced by the nfoil
-// bound vortices staged behind the wake at index n (LUDVM.py:1106, :1115, :1124: <= 256 sources, so the
-// sum is done right here, one target per thread, instead of in a launch of its own): float64 update of
-// the master copy, refresh of the fp32 mirrors (LUDVM.py:1108-1127).  HILO as in the pair kernels.
-template <bool HILO>
-__global__ void __launch_bounds__(kBlock)
-finish_wake_advect_sym(const float* acc_u, const float* acc_w, long long nt, int nfoil, float vc4, double dt, double* x64,
-                       double* z64, float* xh, float* xl, float* zh, float* zl, const float* g32, double* u_out,
+// What `nsrc` extra sources staged in the float64 master arrays at [first, first + nsrc) -- the bound vortices of a
+// time step (LUDVM.py:1106, :1115, :1124), in the overlapped march also the vortices just shed -- induce on this
+// thread's vortex at (xi, zi): a few hundred sources, so the sum is done right in the Euler finisher, one target
+// per thread.  Positions are taken from the masters relative to the first staged source (the airfoil: what is
+// near it keeps full precision), circulations from g32.  Every thread of the workgroup must call this.
+constexpr int kFoilChunk = 256;
+__device__ __forceinline__ void staged_sources_on(bool on, double xi, double zi, const double* x64, const double* z64,
+                                                  const float* g32, long long first, int nsrc, float vc4, float& fu,
+                                                  float& fw, int nextra = 0, const double* extra = nullptr) {
+  // `extra` = [x0, x1, z0, z1, g0, g1]: up to two more sources kept outside the wake arrays (the vortices shed in
+  // an overlapped march step: their wake entries are being moved by the very kernel that calls this)
+  __shared__ float fx[kFoilChunk], fz[kFoilChunk], fg[kFoilChunk];
+  fu = 0.0f; fw = 0.0f;
+  const int ntot = nsrc + nextra;
+  if (ntot <= 0) return;                       // uniform over the workgroup
+  const double ax = nsrc > 0 ? x64[first] : extra[0], az = nsrc > 0 ? z64[first] : extra[2];
+  const float xr = (float)(xi - ax), zr = (float)(zi - az);
+  for (int base = 0; base < ntot; base += kFoilChunk) {
+    const int cnt = ntot - base < kFoilChunk ? ntot - base : kFoilChunk;
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+      const int q = base + t;
+      if (q < nsrc) {
+        fx[t] = (float)(x64[first + q] - ax);
+        fz[t] = (float)(z64[first + q] - az);
+        fg[t] = g32[first + q];
+      } else {
+        fx[t] = (float)(extra[q - nsrc] - ax);
+        fz[t] = (float)(extra[2 + q - nsrc] - az);
+        fg[t] = (float)extra[4 + q - nsrc];
+      }
+    }
+    __syncthreads();
+    if (on) {
+      for (int j = 0; j < cnt; ++j) {
+        const float dx = xr - fx[j], dz = zr - fz[j];
+        const float r2 = __builtin_fmaf(dz, dz, dx * dx);
+        const float k = fg[j] * __builtin_amdgcn_rsqf(__builtin_fmaf(r2, r2, vc4));
+        fu = __builtin_fmaf(dz, k, fu);
+        fw = __builtin_fmaf(dx, k, fw);
+      }
+    }
+  }
+}
+
+// Resident-wake Euler step from the symmetric kernel's raw sums, plus the velocity induced by the nfoil bound
+// vortices staged behind the wake at index nt: float64 update of the master copy, refresh of the fp32 mirrors
+// (LUDVM.py:1108-1127).  One workgroup = one origin block (see finish_wake_advect).
+__global__ void __launch_bounds__(kFinBlock)
+finish_wake_advect_sym(const long long* acc_u, const long long* acc_w, const SymScale* sc, const long long* bad, long long nt,
+                       int nfoil, float vc4, double dt, double* x64, double* z64, Mirrors m, const float* g32, double* u_out,
                        double* w_out, const long long* n_dev = nullptr, TailDuty td = TailDuty{}) {
-  __shared__ float fx[kBlock], fz[kBlock], fg[kBlock], fxl[HILO ? kBlock : 1], fzl[HILO ? kBlock : 1];
-  const int tid = threadIdx.x;
+  __shared__ float org[2];
   if (n_dev) nt = *n_dev;          // device-resident march: the wake size lives on the device
-  if (tid < nfoil) {
-    fx[tid] = xh[nt + tid]; fz[tid] = zh[nt + tid]; fg[tid] = g32[nt + tid];
-    if (HILO) { fxl[tid] = xl[nt + tid]; fzl[tid] = zl[nt + tid]; }
+  tail_duty_block0(td, nt);
+  const long long i = (long long)blockIdx.x * kFinBlock + threadIdx.x;
+  const bool on = i < nt;
+  const double xo = on ? x64[i] : 0.0, zo = on ? z64[i] : 0.0;
+  float fu, fw;
+  staged_sources_on(on, xo, zo, x64, z64, g32, nt, nfoil, vc4, fu, fw);
+  double xn = 0.0, zn = 0.0;
+  if (on) {
+    const float s = (float)kInv2PiD;
+    const float su = (fx_read(acc_u, i, sc, bad) + fu) * s, sw = -(fx_read(acc_w, i, sc, bad) + fw) * s;
+    if (u_out) { u_out[i] = (double)su; w_out[i] = (double)sw; }
+    xn = xo + dt * (double)su;
+    zn = zo + dt * (double)sw;
+    if (i == origin_index(blockIdx.x, nt)) { org[0] = (float)xn; org[1] = (float)zn; m.cx[blockIdx.x] = org[0]; m.cz[blockIdx.x] = org[1]; }
   }
   __syncthreads();
-  tail_duty_block0(td, nt);
-  const long long i = (long long)blockIdx.x * kBlock + tid;
-  if (i >= nt) return;
-  const float s = (float)kInv2PiD;
-  float fu = 0.0f, fw = 0.0f;
-  const float xi = xh[i], zi = zh[i];
-  const float xil = HILO ? xl[i] : 0.0f, zil = HILO ? zl[i] : 0.0f;
-  for (int j = 0; j < nfoil; ++j) {
-    float dx = xi - fx[j], dz = zi - fz[j];
-    if (HILO) { dx += xil - fxl[j]; dz += zil - fzl[j]; }
-    const float r2 = __builtin_fmaf(dz, dz, dx * dx);
-    const float k = fg[j] * __builtin_amdgcn_rsqf(__builtin_fmaf(r2, r2, vc4));
-    fu = __builtin_fmaf(dz, k, fu);
-    fw = __builtin_fmaf(dx, k, fw);
-  }
-  const float su = (acc_u[i] + fu) * s, sw = -(acc_w[i] + fw) * s;
-  if (u_out) { u_out[i] = (double)su; w_out[i] = (double)sw; }
-  const double xn = x64[i] + dt * (double)su;
-  const double zn = z64[i] + dt * (double)sw;
-  // all reads of the old mirrors by this block happened above (own entry only); other blocks read the foil
-  // entries [nt, nt + nfoil), which are not written here
+  if (!on) return;
   x64[i] = xn;
   z64[i] = zn;
-  split_hilo(xn, xh[i], xl[i]);
-  split_hilo(zn, zh[i], zl[i]);
+  store_mirrors(m, i, xn, zn, org[0], org[1]);
   tail_duty(td, i, nt, xn, zn);
 }
 

@@ -100,8 +100,8 @@ class Engine:
         self._check(self._lib.ludvm_set_sym_tuning(self._ctx, int(vortices_per_lane), int(rotation_split)))
 
     def set_symmetric(self, mode=1):
-        """0: always the direct kernel (bitwise reproducible); 1: self-interaction launches may use the
-        symmetric kernel (each unordered pair once; float atomics)."""
+        """0: always the direct kernel; 1: self-interaction launches may use the symmetric kernel (each unordered
+        pair once, 64-bit fixed-point accumulation: also bitwise reproducible); n >= 2: the same from n vortices."""
         self._check(self._lib.ludvm_set_symmetric(self._ctx, int(mode)))
 
     # -- stateless pair sum ----------------------------------------------------------------------
@@ -135,13 +135,20 @@ class Engine:
         self._check(self._lib.ludvm_advect_dev_f32(self._ctx, d_xs, d_zs, d_gs, ns, t_first, nt, float(v_core),
                                                    float(dt), d_x_out, d_z_out))
 
-    def sym_accumulate_dev(self, d_x, d_z, d_g, n, tile_first, tile_count, v_core, d_acc_u, d_acc_w):
-        self._check(self._lib.ludvm_sym_accumulate_dev_f32(self._ctx, d_x, d_z, d_g, n, tile_first, tile_count,
-                                                           float(v_core), d_acc_u, d_acc_w))
+    def sym_scale_dev(self, d_g, n, v_core, d_scale):
+        """Fixed-point scale of the symmetric kernel's raw sums for circulations d_g[n] -> the 32-byte device record
+        d_scale (the same bits on every GPU that holds the same circulations)."""
+        self._check(self._lib.ludvm_sym_scale_dev_f32(self._ctx, d_g, n, float(v_core), d_scale))
 
-    def advect_from_sums_dev(self, d_sum_u, d_sum_w, d_x, d_z, t_first, nt, dt, d_x_out, d_z_out):
-        self._check(self._lib.ludvm_advect_from_sums_dev_f32(self._ctx, d_sum_u, d_sum_w, d_x, d_z, t_first, nt,
-                                                             float(dt), d_x_out, d_z_out))
+    def sym_accumulate_dev(self, d_x, d_z, d_g, n, tile_first, tile_count, v_core, d_scale, d_acc_u, d_acc_w, d_bad):
+        """This owner's share of the unordered pairs, ADDED as 64-bit fixed-point integers into d_acc_u / d_acc_w
+        (int64[n], zeroed by the caller); d_bad (int64[1]) counts non-finite partial sums."""
+        self._check(self._lib.ludvm_sym_accumulate_dev_f32(self._ctx, d_x, d_z, d_g, n, tile_first, tile_count,
+                                                           float(v_core), d_scale, d_acc_u, d_acc_w, d_bad))
+
+    def advect_from_sums_dev(self, d_sum_u, d_sum_w, d_scale, d_bad, d_x, d_z, t_first, nt, dt, d_x_out, d_z_out):
+        self._check(self._lib.ludvm_advect_from_sums_dev_f32(self._ctx, d_sum_u, d_sum_w, d_scale, d_bad, d_x, d_z,
+                                                             t_first, nt, float(dt), d_x_out, d_z_out))
 
     # -- resident wake ---------------------------------------------------------------------------
     def wake_reserve(self, capacity):
@@ -290,6 +297,16 @@ class Engine:
         self._check(self._lib.ludvm_flowfield_f32(self._ctx, float(xmin), float(zmin), float(dr), int(nx), int(nz),
                                                   _pd(xs), _pd(zs), _pd(g), len(xs), float(v_core), _pf(u), _pf(w)))
         return u.reshape(nx, nz), w.reshape(nx, nz)
+
+    def flowfield_vorticity(self, xmin, zmin, dr, nx, nz, circulation, xw, zw, v_core):
+        """(u, w, ome) float32 [nx, nz]: velocity field and its vorticity (LUDVM.py:1224-1292) in one device round
+        trip -- the stencil runs on the fields where they are."""
+        g, xs, zs = _f64(circulation), _f64(xw), _f64(zw)
+        u, w, ome = (np.empty(nx * nz, np.float32) for _ in range(3))
+        self._check(self._lib.ludvm_flowfield_vorticity_f32(self._ctx, float(xmin), float(zmin), float(dr), int(nx), int(nz),
+                                                            _pd(xs), _pd(zs), _pd(g), len(xs), float(v_core), _pf(u), _pf(w),
+                                                            _pf(ome)))
+        return u.reshape(nx, nz), w.reshape(nx, nz), ome.reshape(nx, nz)
 
     def flowfield_dev(self, xmin, zmin, dr, nx, nz, d_xs, d_zs, d_gs, ns, v_core, d_u, d_w):
         self._check(self._lib.ludvm_flowfield_dev_f32(self._ctx, float(xmin), float(zmin), float(dr), int(nx), int(nz),

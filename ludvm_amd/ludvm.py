@@ -24,7 +24,15 @@ from .engine import Engine
 
 __all__ = ["LUDVM", "SparseHistory"]
 
-_FULL_HISTORY_MAX_NT = 2001  # above this the [nt, 2, nt-1] trajectory arrays (LUDVM.py:615-616) are not allocated
+# The reference's dense trajectory arrays path['TEV'|'LEV'] are [nt, 2, nt-1] float64 (LUDVM.py:615-616): 32 nt^2 bytes.
+# 'auto' keeps them -- and float64 pair sums, which cost nothing at those wake sizes -- while they fit this budget
+# (nt <= 8191: every case the reference itself can run in a few minutes); beyond it rows are kept at
+# snapshot_steps only and the wake-on-wake sums run in fp32 with local origins.
+_DENSE_HISTORY_BUDGET_BYTES = 2 << 30
+
+
+def _dense_history_fits(nt):
+    return 32 * nt * nt <= _DENSE_HISTORY_BUDGET_BYTES
 
 
 def naca4_mean_line(digits, x):
@@ -76,12 +84,13 @@ class LUDVM:
     the whole simulation runs inside the constructor.  Keyword-only extras:
       engine     an existing ludvm_amd.engine.Engine to use (default: a new one on `device`)
       device     HIP device ordinal
-      precision  arithmetic of the wake-on-wake pair sums: 'f32', 'f32x2' (hi+lo fp32 positions), 'f64', or 'auto'
-                 (default): 'f64' for runs short enough to keep the reference's dense history (nt <= 2001, wake
-                 <= 4000 vortices: fp64 costs nothing there and the reference's numbers are reproduced to ~1e-5
-                 over the whole run), 'f32' beyond.  The Npanels-target sums always run in fp64
+      precision  arithmetic of the wake-on-wake pair sums: 'f32' (fp32 on local-origin positions: offsets from the
+                 origin of each 256-vortex block of the wake), 'f32x2' (hi+lo fp32 positions), 'f64', or 'auto'
+                 (default): 'f64' for runs short enough to keep the reference's dense history (nt <= 8191, wake
+                 <= 16 000 vortices: fp64 costs little there and the reference's numbers are reproduced to ~1e-5
+                 over the whole README run), 'f32' beyond.  The Npanels-target sums always run in fp64
       history    'full' (dense path arrays as in the reference), 'sparse' (rows only at
-                 snapshot_steps + last step) or 'auto' (full up to nt = 2001)
+                 snapshot_steps + last step) or 'auto' (full while the arrays fit 2 GiB, nt <= 8191)
       snapshot_steps  iterable of time-step indices to record when history is sparse
       run        False builds geometry and kinematics only
       checkpoint_every, checkpoint_path   write an .npz checkpoint every so many steps (0 = never);
@@ -131,14 +140,23 @@ class LUDVM:
 
         if precision not in ('auto', 'f32', 'f32x2', 'f64'):
             raise ValueError("precision must be 'auto', 'f32', 'f32x2' or 'f64'")
-        if precision == 'auto':
-            # an fp32 rounding difference grows ~10x per 12 steps once the wake rolls up (DESIGN.md section 2): in fp32
-            # the README case ends 0.1 away from the reference on Cl, in fp64 4e-5 -- at the same speed for small wakes
-            precision = 'f64' if self.nt <= _FULL_HISTORY_MAX_NT else 'f32'
         if history not in ('auto', 'full', 'sparse'):
             raise ValueError("history must be 'auto', 'full' or 'sparse'")
+        fits = _dense_history_fits(self.nt)
+        if (precision == 'auto' or history == 'auto') and not fits and verbose:
+            import warnings
+            warnings.warn(f"LUDVM: nt = {self.nt}: the reference's dense trajectory history would need "
+                          f"{32 * self.nt * self.nt / 2**30:.1f} GiB; 'auto' keeps rows at snapshot_steps only "
+                          "(history='sparse') and runs the wake-on-wake sums in fp32 with local origins "
+                          "(precision='f32').  Pass history='full' / precision='f64' to override.", stacklevel=2)
+        if precision == 'auto':
+            # an fp32 rounding difference grows ~10x per 12 steps once the wake rolls up (DESIGN.md section 2): in fp32
+            # the README case ends 0.1 away from the reference on Cl, in fp64 4e-5 -- at the same speed for small wakes.
+            # Long runs (config 2) are chaotic beyond ~1000 steps in any arithmetic: 'f32' (local origins) passes the
+            # whole-horizon statistical test against float64 runs (tests/test_gpu_cfg2_stats.py)
+            precision = 'f64' if fits else 'f32'
         self.precision = precision
-        self.history = ('full' if self.nt <= _FULL_HISTORY_MAX_NT else 'sparse') if history == 'auto' else history
+        self.history = ('full' if fits else 'sparse') if history == 'auto' else history
         self.snapshot_steps = {int(s) for s in snapshot_steps}
         self.checkpoint_every, self.checkpoint_path = int(checkpoint_every), checkpoint_path
         self.march = bool(march)
@@ -256,29 +274,6 @@ class LUDVM:
         self.alpha_e = alpha - np.arctan2(h_dot, U)
         self.hpiv, self.h_dot = h, h_dot
         self.xpiv, self.x_dot = x, -U * np.ones(self.nt)
-        return None
-
-    def motion_plunge(self, G=1, T=2, alpha_m=0, h0=0, x0=0.25):
-        """Plunge manoeuvre V(t) = -Vmax sin^2(pi t / T), constant pitch (LUDVM.py:459-547).  The
-        reference's one-argument np.arctan2 call (:520) raises; the effective angle of attack is
-        taken as alpha - atan2(h_dot, Uinf), as in motion_sinusoidal (:428)."""
-        pi, U, t = np.pi, self.Uinf, self.t
-        alpha_m = alpha_m * pi / 180
-        Vmax, T = G * U, T * self.chord / U
-        self.G, self.T = G, T
-        during = t <= T
-        h = np.where(during, h0 - Vmax * t / 2 + Vmax * T / (4 * pi) * np.sin(2 * pi * t / T), 0.0)
-        if (~during).any() and during.any():
-            h[~during] = h[during][-1]
-        h_dot = np.where(during, -Vmax * np.sin(pi * t / T) ** 2, 0.0)
-        alpha = alpha_m * np.ones(self.nt)
-        x = x0 - U * t
-        self._rigid_body_path(x, h, alpha)
-        self.alpha, self.alpha_dot = alpha, np.zeros(self.nt)
-        self.alpha_e = alpha - np.arctan2(h_dot, U)
-        self.hpiv, self.h_dot = h, h_dot
-        self.xpiv, self.x_dot = x, -U * np.ones(self.nt)
-        self.phi, self.h_max, self.f = 0.0, 0.0, 1.0 / T
         return None
 
     # ------------------------------------------------------------------------------------------
@@ -841,11 +836,19 @@ class LUDVM:
         zw = np.concatenate([tev[1], lev[1], free[1], gp[1]])
         return g, xw, zw
 
+    @staticmethod
+    def flowfield_rows_needed(tsteps):
+        """History rows `flowfield(tsteps=...)` reads: the reference takes TEV / LEV positions from row s - 1 and FREE
+        positions from row s (LUDVM.py:1212-1213).  A run with history='sparse' must have recorded them:
+        LUDVM(..., snapshot_steps=LUDVM.flowfield_rows_needed(tsteps))."""
+        return sorted({r for s in tsteps for r in ((int(s) - 1, int(s)) if int(s) > 0 else (0,))})
+
     def flowfield(self, xmin=-10, xmax=0, zmin=-4, zmax=4, dr=0.02, tsteps=[0, 1, 2]):
         """Velocity and vorticity on the uniform mesh arange(xmin, xmax, dr) x arange(zmin, zmax, dr)
         at the requested time steps (LUDVM.py:1186-1298).  The mesh points are generated on the
         device (x-major, as meshgrid(indexing='ij') ravels, :1194-1195); wake and bound vortices go in
-        one launch; the vorticity stencil (:1224-1292) is a device kernel."""
+        one launch; the vorticity stencil (:1224-1292) runs on the device on the velocity fields where they
+        are, and the three fields come back together."""
         x1, z1 = np.arange(xmin, xmax, dr), np.arange(zmin, zmax, dr)
         nx, nz = len(x1), len(z1)
         x, z = np.meshgrid(x1, z1, indexing='ij')
@@ -853,70 +856,24 @@ class LUDVM:
         u = np.zeros([nsteps, nx, nz])
         w = np.zeros([nsteps, nx, nz])
         ome = np.zeros([nsteps, nx, nz])
+        fused = hasattr(self.engine, 'flowfield_vorticity')
         for ii, s in enumerate(tsteps):
             if self.verbose:
                 print('Flowfield tstep =', s)
-            g, xw, zw = self._flowfield_sources(int(s))
-            uf, wf = self.engine.flowfield(xmin, zmin, dr, nx, nz, g, xw, zw, self.v_core)
-            u[ii], w[ii] = uf, wf
-            ome[ii] = self.engine.vorticity(uf, wf, dr)
+            try:
+                g, xw, zw = self._flowfield_sources(int(s))
+            except KeyError as e:
+                raise KeyError(f"flowfield(tsteps=[{int(s)}]) reads the history rows of steps {int(s) - 1} and {int(s)}, "
+                               f"which this run (history='sparse') did not record: construct it with "
+                               f"snapshot_steps=LUDVM.flowfield_rows_needed(tsteps) = "
+                               f"{self.flowfield_rows_needed(tsteps)}") from e
+            if fused:
+                u[ii], w[ii], ome[ii] = self.engine.flowfield_vorticity(xmin, zmin, dr, nx, nz, g, xw, zw, self.v_core)
+            else:
+                uf, wf = self.engine.flowfield(xmin, zmin, dr, nx, nz, g, xw, zw, self.v_core)
+                u[ii], w[ii] = uf, wf
+                ome[ii] = self.engine.vorticity(uf, wf, dr)
         self.x_ff, self.z_ff = x, z
         self.u_ff, self.w_ff = u, w
         self.ome_ff = ome
-        return None
-
-    # ------------------------------------------------------------------------------------------
-    # post-processing
-    # ------------------------------------------------------------------------------------------
-    def animation(self, step=1, ani_interval=10):
-        """Matplotlib animation of airfoil, TEVs, LEVs and free vortices (LUDVM.py:1301-1351); needs
-        history='full'.  matplotlib is imported here, not at module import."""
-        import matplotlib.pyplot as plt
-        from matplotlib.animation import FuncAnimation
-        if self.history != 'full':
-            raise RuntimeError("animation needs history='full'")
-        fig, ax = plt.subplots()
-        ln, = plt.plot([], [], 'k.', animated=True, markersize=2)
-        ln_tev, = plt.plot([], [], 'r*', markersize=1, animated=True)
-        ln_lev, = plt.plot([], [], 'b*', markersize=1, animated=True)
-        ln_free, = plt.plot([], [], 'g*', markersize=1, animated=True)
-        P = self.path
-
-        def init():
-            ax.set_xlim(P['airfoil'][-1, 0, 0], 2)
-            ax.set_ylim(-3, 3)
-            ax.set_aspect('equal')
-            return ln,
-
-        def update(i):
-            ln.set_data(P['airfoil_gamma_points'][i + 1, 0, :], P['airfoil_gamma_points'][i + 1, 1, :])
-            ln_tev.set_data(P['TEV'][i + 1, 0, :i + 1], P['TEV'][i + 1, 1, :i + 1])
-            if self.LEV_shed[i] != -1:
-                self.ilev2 = int(self.LEV_shed[i])
-            if self.ilev2 > 0:
-                ln_lev.set_data(P['LEV'][i + 1, 0, :self.ilev2 + 1], P['LEV'][i + 1, 1, :self.ilev2 + 1])
-            if self.n_freevort != 1:
-                ln_free.set_data(P['FREE'][i + 1, 0, :], P['FREE'][i + 1, 1, :])
-            return ln, ln_tev, ln_lev, ln_free
-
-        ani = FuncAnimation(fig, func=update, frames=np.arange(0, self.nt - 1, step), init_func=init, blit=True,
-                            interval=ani_interval, repeat=False)
-        plt.show()
-        return ani
-
-    def propulsive_efficiency(self, T=None):
-        """Per-period mean thrust over mean power coefficient (LUDVM.py:1353-1372; the reference's bare
-        `Uinf` at :1367 is self.Uinf here)."""
-        if T is None:
-            T = 1 / self.f
-        tt = self.t / T
-        Nt = int(np.floor(tt[-1]))
-        Ctm, Cpm = np.zeros(Nt), np.zeros(Nt)
-        for ii in range(Nt):
-            ind = np.where(np.logical_and(tt >= ii - 1, tt < ii))
-            Ctm[ii] = np.mean(self.Ct[ind])
-            Cpm[ii] = np.mean(abs(self.h_dot[ind] / self.Uinf * self.Cl[ind])
-                              + abs(self.alpha_dot[ind] * self.Cm[ind] * self.chord / self.Uinf))
-        self.tt = tt
-        self.etap = Ctm / Cpm
         return None

@@ -16,10 +16,13 @@ symmetric (default) -- each unordered pair evaluated once, chip-wide 1.5x faster
     1. symmetric kernel over the rank's own I-tiles of the global tile ring: J = I + d (mod NT),
        d <= NT/2, so a rank's work depends only on how many tiles it owns (exactly 1/G of the job) and
        touches its own block plus the next half of the ring; raw (u, w) sums of BOTH partners are
-       accumulated into a full-length buffer [2, N];
-    2. one reduce-scatter (sum) of that buffer: each rank receives the complete sums of its own block
-       (8 B per vortex over xGMI, ~1 ms at N = 8e6 against ~1 s of pair arithmetic);
-    3. Euler update of the own block into the send slot, then the same all-gather as above.
+       accumulated, as 64-bit fixed-point integers, into a full-length buffer [2, N] (+ one NaN counter);
+    2. ONE all-reduce (integer sum) of that buffer (16 B per vortex over xGMI, ~1-2 ms at N = 8e6 against
+       ~1 s of pair arithmetic).  Integer addition is associative, so every rank ends up with the same
+       bits -- the bits one GPU owning all tiles would have produced -- whatever the ring order of the
+       collective;
+    3. every rank Euler-updates ALL N vortices from the complete sums (O(N), replicated): no position
+       exchange is needed, and the replicas cannot drift apart.
 
 The pair arithmetic is injected (`kernel`): the product passes HipShardKernel (HIP engine, device
 pointers); the CPU tests pass a checker built on the oracle to cover the sharding / collective logic
@@ -52,15 +55,25 @@ class HipShardKernel:
         self.engine.advect_dev(xs.data_ptr(), zs.data_ptr(), gs.data_ptr(), xs.numel(), t_first, nt, v_core, dt,
                                x_out.data_ptr(), z_out.data_ptr())
 
-    def sym_accumulate(self, xs, zs, gs, tile_first, tile_count, v_core, acc_u, acc_w):
-        self._check(xs, zs, gs, acc_u, acc_w)
-        self.engine.sym_accumulate_dev(xs.data_ptr(), zs.data_ptr(), gs.data_ptr(), xs.numel(), tile_first, tile_count,
-                                       v_core, acc_u.data_ptr(), acc_w.data_ptr())
+    def sym_scale(self, gs, v_core, scale):
+        """scale: uint8[32] device tensor receiving the fixed-point scale record for circulations gs."""
+        self._check(gs)
+        self.engine.sym_scale_dev(gs.data_ptr(), gs.numel(), v_core, scale.data_ptr())
 
-    def advect_from_sums(self, sum_u, sum_w, xs, zs, t_first, nt, dt, x_out, z_out):
-        self._check(sum_u, sum_w, xs, zs, x_out, z_out)
-        self.engine.advect_from_sums_dev(sum_u.data_ptr(), sum_w.data_ptr(), xs.data_ptr(), zs.data_ptr(), t_first, nt,
-                                         dt, x_out.data_ptr(), z_out.data_ptr())
+    def sym_accumulate(self, xs, zs, gs, tile_first, tile_count, v_core, scale, acc):
+        """acc: int64[2 * n + 1] = raw u sums | raw w sums | NaN counter (zeroed by the caller)."""
+        self._check(xs, zs, gs)
+        n = xs.numel()
+        base = acc.data_ptr()
+        self.engine.sym_accumulate_dev(xs.data_ptr(), zs.data_ptr(), gs.data_ptr(), n, tile_first, tile_count, v_core,
+                                       scale.data_ptr(), base, base + 8 * n, base + 16 * n)
+
+    def advect_from_sums(self, acc, scale, xs, zs, t_first, nt, dt, x_out, z_out):
+        self._check(xs, zs, x_out, z_out)
+        n = xs.numel()
+        base = acc.data_ptr()
+        self.engine.advect_from_sums_dev(base + 8 * t_first, base + 8 * (n + t_first), scale.data_ptr(), base + 16 * n,
+                                         xs.data_ptr(), zs.data_ptr(), t_first, nt, dt, x_out.data_ptr(), z_out.data_ptr())
 
 
 def flowfield_rows(nx, world, rank):
@@ -161,40 +174,32 @@ class ShardedWake:
         self._recv = torch.empty([g, 2, n_loc], dtype=torch.float32, device=device)
         self._xz = torch.empty([2, n_pad], dtype=torch.float32, device=device)
         if self.symmetric:
-            self._acc = torch.empty([2, n_pad], dtype=torch.float32, device=device)
-            self._own = torch.empty([2, n_loc], dtype=torch.float32, device=device)
+            # raw sums of all vortices as 64-bit fixed point: u[n_pad] | w[n_pad] | NaN counter
+            self._acc = torch.zeros([2 * n_pad + 1], dtype=torch.int64, device=device)
+            self._scale = torch.zeros([32], dtype=torch.uint8, device=device)
+            self.kernel.sym_scale(self.gs, self.v_core, self._scale)     # circulations do not change: once
 
     @property
     def pairs_per_step(self):
         """Whole-job ordered pair interactions of one step (self pairs count; padding does not)."""
         return float(self.n) * float(self.n)
 
-    def _reduce_own_sums(self):
-        """Sum the per-rank partial (u, w) sums and keep this rank's block: one reduce-scatter."""
-        acc, own, g = self._acc, self._own, self.world
-        if g == 1 and not self.force:
-            return acc[0, : self.n_loc], acc[1, : self.n_loc]
-        backend = dist.get_backend(self.group)
-        if backend == "nccl":
-            # [2, G, n_loc] -> [G, 2, n_loc] so that chunk r of the flat input is rank r's (u, w) block
-            stage = acc.view(2, g, self.n_loc).permute(1, 0, 2).contiguous()
-            dist.reduce_scatter_tensor(own.view(-1), stage.view(-1), op=dist.ReduceOp.SUM, group=self.group)
-        else:  # gloo (CPU tests, one-GPU rehearsals) has no reduce_scatter: all-reduce and slice
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
-            own.copy_(acc[:, self.lo:self.lo + self.n_loc])
-        return own[0], own[1]
-
     def step(self):
-        send = self._send
         if self.symmetric:
+            # own I-tiles of the global tile ring -> raw sums of both partners; ONE integer all-reduce; every rank
+            # then moves every vortex itself (identical bits everywhere: no position exchange)
             self._acc.zero_()
             tiles = self.n_loc // SYM_TILE
-            self.kernel.sym_accumulate(self.xs, self.zs, self.gs, self.rank * tiles, tiles, self.v_core,
-                                       self._acc[0], self._acc[1])
-            su, sw = self._reduce_own_sums()
-            self.kernel.advect_from_sums(su, sw, self.xs, self.zs, self.lo, self.n_loc, self.dt, send[0], send[1])
-        else:
-            self.kernel.advect(self.xs, self.zs, self.gs, self.lo, self.n_loc, self.v_core, self.dt, send[0], send[1])
+            self.kernel.sym_accumulate(self.xs, self.zs, self.gs, self.rank * tiles, tiles, self.v_core, self._scale,
+                                       self._acc)
+            if self.world > 1 or self.force:
+                dist.all_reduce(self._acc, op=dist.ReduceOp.SUM, group=self.group)
+            nxt = self._xz if self.xs.data_ptr() != self._xz.data_ptr() else self._xz2()
+            self.kernel.advect_from_sums(self._acc, self._scale, self.xs, self.zs, 0, self.n_pad, self.dt, nxt[0], nxt[1])
+            self.xs, self.zs = nxt[0], nxt[1]
+            return
+        send = self._send
+        self.kernel.advect(self.xs, self.zs, self.gs, self.lo, self.n_loc, self.v_core, self.dt, send[0], send[1])
         if self.world > 1 or self.force:
             dist.all_gather_into_tensor(self._recv.view(-1), send.view(-1), group=self.group)
             # [G, 2, n_loc] -> [2, G*n_loc].  In-place reuse of _xz is safe: in stream order the pair
@@ -204,6 +209,11 @@ class ShardedWake:
         else:
             self._xz[:, : self.n_loc].copy_(send)
             self.xs, self.zs = self._xz[0], self._xz[1]
+
+    def _xz2(self):
+        if not hasattr(self, "_xz_b"):
+            self._xz_b = torch.empty_like(self._xz)
+        return self._xz_b
 
     def positions(self):
         """Current (x, z) of the N real vortices as float32 numpy arrays."""

@@ -37,6 +37,10 @@ def test_bench_json_contract(symmetric):
         assert key in r, key
     assert r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and r["kernel_launches_timed"] == 3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    ex = r["executed"]       # what the ALU issued: 9 FLOP per ordered pair in the symmetric kernel, 13 in the direct one
+    assert ex["flop_per_pair"] == (9 if symmetric else 13) and r["flop_per_pair"] == 13
+    assert abs(ex["frac"] * 13 - r["frac"] * ex["flop_per_pair"]) < 1e-9 and ex["frac"] <= r["frac"]
+    assert len(d["repeat_values"]) == 3 and all(v > 0 for v in d["repeat_values"])
     # whole-job value is consistent with the step time, and the kernel time is inside the step time
     assert abs(d["value"] - 40000.0**2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert r["kernel_ms_avg"] <= d["ms_per_step"] * 1.02
@@ -52,8 +56,8 @@ def test_bench_config4_shape_on_one_gpu():
 
 
 def test_sharded_wake_collectives_on_the_real_rccl_backend():
-    """One rank, backend "nccl" (= RCCL): the reduce-scatter / all-gather calls of the sharded step with the
-    layouts used at G > 1 (identities in a one-rank group) against the same step without collectives
+    """One rank, backend "nccl" (= RCCL): the int64 all-reduce / fp32 all-gather calls of the sharded step with the
+    layouts used at G > 1 (identities in a one-rank group) against the same step without collectives, bit for bit
     (tools/rccl_one_rank.py, in a child process so that the process group does not outlive the test)."""
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -83,6 +87,8 @@ def test_bench_two_ranks_through_the_launcher():
     d = _launch(2, {"LUDVM_BENCH_BACKEND": "gloo"}, "--vortices", "120000", "--steps", "2", "--warmup", "1")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "config 4" in d["config"]["workload"]
     assert d["config"]["collective_backend"] == "gloo" and d["config"]["kernel_variant"] == "symmetric"
+    assert d["config"]["ranks"] == 2 and len(d["config"]["pair_kernel_ms_per_rank"]) == 2
+    assert "all_reduce" in d["config"]["collective"]
     assert abs(d["value"] - 120000.0**2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
 

@@ -278,8 +278,8 @@ def test_error_reporting(eng):
 
 def test_full_size_config3_properties(eng):
     """N = 1e6 all-pairs (BASELINE config 3), direct and symmetric kernels: sampled targets against the
-    C oracle, impulse invariant; the direct kernel is bitwise reproducible and exactly linear under
-    power-of-two scaling, the symmetric one (float atomics) reproduces to rounding."""
+    C oracle, impulse invariant; BOTH kernels are bitwise reproducible (the symmetric one accumulates in 64-bit fixed
+    point, whose integer atomics commute) and the direct one is exactly linear under power-of-two scaling."""
     import torch
     n = 1_000_000
     rng = np.random.default_rng(20260101)
@@ -310,12 +310,13 @@ def test_full_size_config3_properties(eng):
             assert abs(np.sum(gd * w)) < 1e-4 * np.sum(np.abs(gd * w))
             u2, w2 = run(dg)
             u4, w4 = run(dg * 4.0)
+            assert np.array_equal(u, u2) and np.array_equal(w, w2), mode
             if mode == 0:
-                assert np.array_equal(u, u2) and np.array_equal(w, w2)
                 assert np.array_equal(u4, 4.0 * u) and np.array_equal(w4, 4.0 * w)
             else:
+                # the fp32 partial sums scale exactly, their truncation to the fixed-point grid need not
                 scale = max(np.abs(u).max(), np.abs(w).max())
-                assert np.abs(u - u2).max() < 1e-5 * scale and np.abs(u4 - 4.0 * u).max() < 4e-5 * scale
+                assert np.abs(u4 - 4.0 * u).max() < 1e-6 * scale
         scale = max(np.abs(res[0][0]).max(), np.abs(res[0][1]).max())
         assert np.abs(res[0][0] - res[1][0]).max() < 1e-5 * scale and np.abs(res[0][1] - res[1][1]).max() < 1e-5 * scale
     finally:
@@ -361,8 +362,8 @@ def test_symmetric_kernel_tile_edges(eng, n):
 @pytest.mark.parametrize("ranks,n", [(2, 70000), (3, 100000), (8, 300001)])
 def test_symmetric_tile_ring_partition(eng, ranks, n):
     """Multi-GPU building block on one GPU: the owners of the tile ring, run one after the other with
-    separate accumulators, add up to the full self-interaction (what the reduce-scatter does), and one
-    owner's block step equals the direct advection of that block."""
+    separate accumulators, add up (integer sums: what the all-reduce does) to BIT FOR BIT the self-interaction
+    one owner of all tiles computes, and one owner's block step equals the direct advection of that block."""
     import torch
     from ludvm_amd._ffi import SYM_TILE as tile
     n_loc = ((n + ranks - 1) // ranks + tile - 1) // tile * tile
@@ -375,34 +376,81 @@ def test_symmetric_tile_ring_partition(eng, ranks, n):
     dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     try:
-        total = torch.zeros([2, n_pad], device=dev)
+        scale = torch.zeros([32], dtype=torch.uint8, device=dev)
+        eng.sym_scale_dev(dg.data_ptr(), n_pad, 0.065, scale.data_ptr())
         tiles = n_loc // tile
+
+        def accumulate(first, count, acc):
+            base = acc.data_ptr()
+            eng.sym_accumulate_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n_pad, first, count, 0.065, scale.data_ptr(),
+                                   base, base + 8 * n_pad, base + 16 * n_pad)
+        total = torch.zeros([2 * n_pad + 1], dtype=torch.int64, device=dev)
         for r in range(ranks):
-            acc = torch.zeros([2, n_pad], device=dev)
-            eng.sym_accumulate_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n_pad, r * tiles, tiles, 0.065,
-                                   acc[0].data_ptr(), acc[1].data_ptr())
+            acc = torch.zeros_like(total)
+            accumulate(r * tiles, tiles, acc)
             total += acc
+        one = torch.zeros_like(total)
+        accumulate(0, ranks * tiles, one)
         torch.cuda.synchronize()
-        u = (total[0] / (2 * np.pi)).cpu().numpy()
-        w = (-total[1] / (2 * np.pi)).cpu().numpy()
-        eng.set_symmetric(0)
+        assert torch.equal(total, one) and int(total[-1]) == 0
+        # ... and the whole-array entry point produces exactly these sums too
         du, dw = torch.empty(n_pad, device=dev), torch.empty(n_pad, device=dev)
+        eng.set_symmetric(1)
+        eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n_pad, dx.data_ptr(), dz.data_ptr(), n_pad, 0.065,
+                       du.data_ptr(), dw.data_ptr())
+        torch.cuda.synchronize()
+        us, ws = du.cpu().numpy().copy(), dw.cpu().numpy().copy()
+        eng.set_symmetric(0)
         eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n_pad, dx.data_ptr(), dz.data_ptr(), n_pad, 0.065,
                        du.data_ptr(), dw.data_ptr())
         torch.cuda.synchronize()
         ud, wd = du.cpu().numpy(), dw.cpu().numpy()
-        scale = max(np.abs(ud[:n]).max(), np.abs(wd[:n]).max())
-        assert np.abs(u[:n] - ud[:n]).max() < 1e-5 * scale and np.abs(w[:n] - wd[:n]).max() < 1e-5 * scale
+        sc = max(np.abs(ud[:n]).max(), np.abs(wd[:n]).max())
+        assert np.abs(us[:n] - ud[:n]).max() < 1e-5 * sc and np.abs(ws[:n] - wd[:n]).max() < 1e-5 * sc
         # padding vortices (zero strength, 1e6 away) only feel the far field of the net circulation
-        assert np.abs(u[n:]).max() < 1e-6 * scale and np.abs(w[n:]).max() < 1e-6 * scale
-        # block step of the last owner from its summed block
+        assert np.abs(us[n:]).max() < 1e-6 * sc and np.abs(ws[n:]).max() < 1e-6 * sc
+        # block step of the last owner from the summed integers: the same velocities, bit for bit
         lo = (ranks - 1) * n_loc
         xo, zo = torch.empty(n_loc, device=dev), torch.empty(n_loc, device=dev)
-        eng.advect_from_sums_dev(total[0, lo:].data_ptr(), total[1, lo:].data_ptr(), dx.data_ptr(), dz.data_ptr(), lo,
-                                 n_loc, 0.05, xo.data_ptr(), zo.data_ptr())
+        base = total.data_ptr()
+        eng.advect_from_sums_dev(base + 8 * lo, base + 8 * (n_pad + lo), scale.data_ptr(), base + 16 * n_pad, dx.data_ptr(),
+                                 dz.data_ptr(), lo, n_loc, 0.05, xo.data_ptr(), zo.data_ptr())
         torch.cuda.synchronize()
-        np.testing.assert_allclose(xo.cpu().numpy(), x[lo:] + 0.05 * ud[lo:], rtol=0, atol=1e-5 * scale * 0.05 + 1e-6)
-        np.testing.assert_allclose(zo.cpu().numpy(), z[lo:] + 0.05 * wd[lo:], rtol=0, atol=1e-5 * scale * 0.05 + 1e-6)
+        assert np.abs(xo.cpu().numpy() - (x[lo:] + 0.05 * us[lo:])).max() < 1e-6      # (fma vs mul + add)
+        np.testing.assert_allclose(xo.cpu().numpy(), x[lo:] + 0.05 * ud[lo:], rtol=0, atol=1e-5 * sc * 0.05 + 1e-6)
+        np.testing.assert_allclose(zo.cpu().numpy(), z[lo:] + 0.05 * wd[lo:], rtol=0, atol=1e-5 * sc * 0.05 + 1e-6)
+    finally:
+        eng.set_symmetric(1)
+        eng.set_stream(None)
+
+
+def test_symmetric_kernel_propagates_nan_like_the_reference(eng):
+    """A NaN source position poisons the sum at every target in the reference (LUDVM.py:565-569); the fixed-point
+    accumulators cannot hold a NaN, so the launch counts non-finite partial sums and the finisher returns NaN."""
+    import torch
+    n = 30000
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-10, 0, n).astype(np.float32)
+    z = rng.uniform(-2, 2, n).astype(np.float32)
+    g = (rng.standard_normal(n) / n).astype(np.float32)
+    x[12345] = np.nan
+    dev = torch.device("cuda", 0)
+    dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
+    du, dw = torch.zeros_like(dx), torch.zeros_like(dx)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for mode in (0, 1):
+            eng.set_symmetric(mode)
+            eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, dx.data_ptr(), dz.data_ptr(), n, 0.065,
+                           du.data_ptr(), dw.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.isnan(du).all() and torch.isnan(dw).all(), mode
+        # a clean launch afterwards is clean again
+        dx[12345] = -1.0
+        eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, dx.data_ptr(), dz.data_ptr(), n, 0.065,
+                       du.data_ptr(), dw.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.isfinite(du).all() and torch.isfinite(dw).all()
     finally:
         eng.set_symmetric(1)
         eng.set_stream(None)
@@ -560,13 +608,16 @@ def test_symmetric_kernel_rotation_split_variants(eng, n):
         eng.set_stream(None)
 
 
-@pytest.mark.parametrize("prec_code,tol100", [(2, 1e-9), (0, 1e-2)])
-def test_integration_md_binding_drives_the_reference_loop(prec_code, tol100):
+@pytest.mark.parametrize("prec_code,win", [(2, {100: 1e-9}), (1, {50: 1e-6, 75: 1e-4, 100: 1e-2}),
+                                           (0, {50: 1e-5, 75: 1e-3, 100: 6e-2})])
+def test_integration_md_binding_drives_the_reference_loop(prec_code, win):
     """INTEGRATION.md option B as printed: the raw-ctypes binding of ludvm_induce_f64 is executed from the document
     and bound over `induced_velocity` of the CPU restatement of the reference class (the reference file itself does
     not travel to the GPU box); every call site of the reference's own time loop then runs through the C ABI.
     Against the reference's golden README run: identical LEV shedding; fp64 mode to rounding over the first 100
-    steps, fp32 inside SURVEY's T2 bound (1e-2)."""
+    steps; hi+lo fp32 inside SURVEY's T2 bound (1e-2 over the first 100 steps); fp32 in windows that widen with the
+    flow's amplification (~10x per 12 steps), measured 3.5e-2 at step 100 with every sum -- the chord sums too -- in
+    fp32 (deterministic kernels: the figure repeats)."""
     import os
     import re
     from conftest import CONFIG1, ROOT
@@ -586,8 +637,11 @@ def test_integration_md_binding_drives_the_reference_loop(prec_code, tol100):
     g2 = load_golden("g2_config1.npz")
     sim = Bound(**CONFIG1)
     assert np.array_equal(sim.LEV_shed, g2["LEV_shed"])
+    print("binding, precision", prec_code, {hi: max(float(np.abs(getattr(sim, n)[:hi] - g2[n][:hi]).max()) for n in ("Cl", "Cd", "Cm"))
+                                            for hi in (50, 75, 100)})
     for name in ("Cl", "Cd", "Cm"):
-        assert np.abs(getattr(sim, name)[:100] - g2[name][:100]).max() <= tol100, name
+        for hi, tol in win.items():
+            assert np.abs(getattr(sim, name)[:hi] - g2[name][:hi]).max() <= tol, (name, hi)
     if prec_code == 2:
         np.testing.assert_allclose(sim.path["TEV"][50], g2["TEV_50"], rtol=0, atol=1e-9)
     ns["_hip"].ludvm_destroy(ns["_ctx"])

@@ -140,27 +140,69 @@ def test_wake_advect_is_one_reference_roll_up_step(eng, precision, tol):
     np.testing.assert_allclose(x2, xn + dt * u2, rtol=0, atol=tol * scale * dt + 1e-15)
 
 
-def test_wake_advect_symmetric_hilo_late_time_wake(eng):
-    """The config-2 regime (|x| ~ 50, spacing ~ 1e-3, v_core = 1.3e-3): hi+lo positions keep the
-    symmetric roll-up at 1e-5 where plain fp32 positions lose three digits."""
+@pytest.mark.parametrize("layout", ["sheet", "interleaved"])
+def test_wake_advect_late_time_wake_keeps_1e5_in_fp32(eng, layout):
+    """The config-2 regime (|x| ~ 50, spacing ~ 1e-3, v_core = 1.3e-3).  Plain fp32 coordinates lose three digits there
+    (1.4e-3 of max|u|); 'f32' stores offsets from the origin of each 256-vortex block and keeps 1e-5 at the
+    speed of plain fp32, hi+lo positions ('f32x2') keep 1e-6.  'interleaved' is the order a run stores while it sheds
+    LEVs: trailing- and leading-edge vortices alternate, a chord apart, so an origin block is a chord long whatever its
+    vortex count -- 2.2e-5 there (plain fp32: 3.8e-4).  Symmetric kernel and direct kernel."""
     from oracle import c_oracle
     rng = np.random.default_rng(31)
     n = 40000
-    x = -50.0 + np.sort(rng.uniform(0, 40, n))                  # a sheet ~1e-3 apart, far from the origin
-    z = 0.3 * np.sin(0.7 * x) + 1e-3 * rng.standard_normal(n)
+    if layout == "sheet":
+        x = -50.0 + np.sort(rng.uniform(0, 40, n))                  # a sheet ~1e-3 apart, far from the origin
+        z = 0.3 * np.sin(0.7 * x) + 1e-3 * rng.standard_normal(n)
+    else:
+        m = n // 2
+        xt = -10.0 - np.arange(m) * 2e-3
+        xl = xt - 1.0
+        x, z = np.empty(n), np.empty(n)
+        x[0::2], x[1::2] = xt, xl
+        z[0::2] = 0.3 * np.sin(0.7 * xt) + 1e-3 * rng.standard_normal(m)
+        z[1::2] = 0.2 + 0.3 * np.cos(0.5 * xl) + 1e-3 * rng.standard_normal(m)
     g = rng.standard_normal(n) * 1e-3
     vc, dt = 1.3e-3, 1e-3
     ur, wr = c_oracle.induced_velocity(g, x, z, x, z, vc)
     scale = max(np.abs(ur).max(), np.abs(wr).max())
-    err = {}
     try:
+        for mode in (1, 0):
+            eng.set_symmetric(mode)
+            err = {}
+            for prec in ("f32", "f32x2"):
+                eng.wake_clear()
+                eng.wake_append(x, z, g)
+                u, w = eng.wake_advect(dt, [], [], [], vc, precision=prec, return_velocity=True)
+                err[prec] = max(np.abs(u - ur).max(), np.abs(w - wr).max()) / scale
+                xn, zn = eng.wake_read(0, n)
+                np.testing.assert_allclose(xn, x + dt * u, rtol=0, atol=2e-14)     # float64 Euler step of the masters (fma or not)
+            # the interleaved order keeps a chord between the two families inside every origin block: 2.2e-5 measured
+            # with the symmetric kernel, 3.7e-5 with the direct one
+            assert err["f32"] < (1e-5 if layout == "sheet" else 5e-5) and err["f32x2"] < 2e-6, (mode, err)
+    finally:
         eng.set_symmetric(1)
-        for prec in ("f32", "f32x2"):
-            eng.wake_clear()
-            eng.wake_append(x, z, g)
-            u, w = eng.wake_advect(dt, [], [], [], vc, precision=prec, return_velocity=True)
-            err[prec] = max(np.abs(u - ur).max(), np.abs(w - wr).max()) / scale
-        assert err["f32x2"] < 1e-5 and err["f32x2"] < 0.1 * err["f32"], err
+
+
+def test_resident_wake_roll_up_repeats_bit_for_bit(eng):
+    """Two roll-up steps from the same state give the same bits in every precision and with either kernel: the direct
+    kernel sums its partial slabs in a fixed order, the symmetric kernel accumulates in 64-bit fixed point (integer
+    atomics commute).  The reference is deterministic; so is this."""
+    rng = np.random.default_rng(8)
+    n, nf = 70001, 80
+    x, z, g = rng.uniform(-30, -20, n), rng.uniform(-2, 2, n), rng.standard_normal(n) / n
+    fx, fz, fg = np.linspace(-30.9, -30.0, nf), 0.02 * np.cos(np.linspace(0, 2, nf)), rng.standard_normal(nf) / 100
+    try:
+        for mode in (1, 0):
+            eng.set_symmetric(mode)
+            for prec in ("f32", "f32x2"):
+                runs = []
+                for _ in range(2):
+                    eng.wake_clear()
+                    eng.wake_append(x, z, g)
+                    eng.wake_advect(5e-2, fx, fz, fg, 0.065, precision=prec)
+                    eng.wake_advect(5e-2, fx, fz, fg, 0.065, precision=prec)
+                    runs.append(eng.wake_read(0, n))
+                assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]), (mode, prec)
     finally:
         eng.set_symmetric(1)
 
@@ -226,16 +268,18 @@ def test_time_loop_config1_fp64_mode_tier_T3(eng, g2, march):
 
 
 @pytest.mark.parametrize("precision,win", [
-    ("f32", {50: 1e-5, 75: 1e-3, 100: 1e-1}),
+    ("f32", {50: 1e-6, 75: 1e-4, 100: 1e-2}),
     ("f32x2", {50: 1e-6, 75: 1e-4, 100: 1e-2}),
 ])
 @pytest.mark.parametrize("march", [True, False])
 def test_time_loop_config1_fp32_tier_T2(eng, g2, precision, win, march):
     """fp32 wake roll-up (chord sums stay fp64): wake positions to 1e-5 through step 50, identical LEV
     shedding pattern over all 400 steps, loads inside windows that widen with time -- the wake is
-    chaotic, a rounding-level difference grows ~10x every ~12 steps once it rolls up
-    (measured on MI355X: fp32 3.6e-7 / 1.8e-4 / 2.6e-2 and hi+lo 5e-8 / 1.5e-5 / 1.8e-3 for steps
-    < 50 / 75 / 100) -- and late times are compared on the period average only."""
+    chaotic, a rounding-level difference grows ~10x every ~12 steps once it rolls up.
+    Measured on MI355X (tools/t2_windows.py, profiles/r02_t2_windows.txt; the kernels are deterministic, so these
+    repeat exactly): fp32 on local origins 1.1e-7 / 1.8e-5 / 1.1e-3 for steps < 50 / 75 / 100, hi+lo positions
+    6e-8 / 1.3e-5 / 1.1e-3 -- both inside SURVEY's T2 bound of 1e-2 over the first 100 steps (round 1's plain fp32
+    coordinates: 3.6e-7 / 1.8e-4 / 2.6e-2).  Late times are compared on the period average only."""
     from ludvm_amd import LUDVM
     sim = LUDVM(**CONFIG1, verbose=False, engine=eng, precision=precision, march=march)
     assert np.array_equal(sim.LEV_shed, g2["LEV_shed"])
@@ -395,18 +439,56 @@ def test_march_fills_every_result_like_the_per_step_path(eng, precision, tol):
     assert a.path["LEV"][a.nt - 1].shape == b.path["LEV"][b.nt - 1].shape
 
 
-def test_march_repeats_bit_for_bit_in_the_direct_regime(eng):
-    """Wakes below the symmetric threshold use the direct kernels, whose summation order the march fixes from
-    the call's arguments alone (not from how far the host runs ahead of the device): two runs agree to the
-    last bit, as the per-step path does."""
-    from ludvm_amd import LUDVM
-    kw = dict(CONFIG1, tf=10)
-    a = LUDVM(**kw, verbose=False, engine=eng, precision="f32", history="sparse")
-    b = LUDVM(**kw, verbose=False, engine=eng, precision="f32", history="sparse")
-    for name in ("Cl", "Cd", "Cm", "LESP"):
-        assert np.array_equal(getattr(a, name), getattr(b, name)), name
-    assert np.array_equal(a.path["TEV"][a.nt - 1], b.path["TEV"][b.nt - 1])
-    assert np.array_equal(a.circulation["TEV"], b.circulation["TEV"])
+@pytest.mark.parametrize("threshold", [0, 8, 100])
+def test_march_repeats_bit_for_bit(threshold):
+    """Two marched runs agree to the last bit -- with the direct kernels (threshold 0: the default 16 384, never reached
+    here), and with overlapped symmetric steps from 8 / 100 vortices on.  What fixes the bits: the launch geometry of
+    every step is derived from the wake size after a step the host KNOWS to be finished (progress ring), never from
+    how far it happens to run ahead; partial slabs are summed in a fixed order; the symmetric kernel's fixed-point
+    atomics commute."""
+    from ludvm_amd import Engine, LUDVM
+    e = Engine(0)
+    try:
+        if threshold:
+            e.set_symmetric(threshold)
+        kw = dict(CONFIG1, tf=10)
+        for prec in ("f32", "f32x2"):
+            a = LUDVM(**kw, verbose=False, engine=e, precision=prec, history="sparse")
+            b = LUDVM(**kw, verbose=False, engine=e, precision=prec, history="sparse")
+            for name in ("Cl", "Cd", "Cm", "LESP"):
+                assert np.array_equal(getattr(a, name), getattr(b, name)), (name, prec)
+            assert np.array_equal(a.path["TEV"][a.nt - 1], b.path["TEV"][b.nt - 1])
+            assert np.array_equal(a.circulation["TEV"], b.circulation["TEV"])
+    finally:
+        e.close()
+
+
+def test_march_and_overlap_logic_isolated_from_rounding():
+    """Deterministic A/B of the overlapped step against the serial one (LUDVM_MARCH_OVERLAP=0) on the same symmetric
+    kernels: the two differ only in how the vortices shed in a step are handled (their velocity from the fp64 chord
+    launch instead of the fp32 pair kernel; their influence on the old wake summed in the finisher), i.e. at fp32
+    rounding level -- 2e-6 on the loads while the flow has not amplified it, identical shedding.  Before the kernels
+    were deterministic this comparison was blurred by atomics reordering."""
+    import os
+    from ludvm_amd import Engine, LUDVM
+    e = Engine(0)
+    try:
+        e.set_symmetric(8)
+        kw = dict(CONFIG1, tf=6)
+        ov = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse")
+        os.environ["LUDVM_MARCH_OVERLAP"] = "0"
+        try:
+            se = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse")
+            se2 = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse")
+        finally:
+            del os.environ["LUDVM_MARCH_OVERLAP"]
+        assert np.array_equal(se.Cl, se2.Cl)
+        assert np.array_equal(ov.LEV_shed, se.LEV_shed)
+        for name in ("Cl", "Cd", "Cm"):
+            d = np.abs(getattr(ov, name) - getattr(se, name))
+            assert d[:60].max() <= 2e-5, (name, d[:60].max())
+    finally:
+        e.close()
 
 
 def test_march_in_several_calls_continues_the_state(eng):
@@ -477,7 +559,7 @@ def test_march_rejects_bad_calls(eng):
 
 
 @pytest.mark.parametrize("precision,win", [
-    ("f32", {50: 1e-5, 75: 1e-3, 100: 1e-1}),
+    ("f32", {50: 1e-6, 75: 1e-4, 100: 1e-2}),
     ("f32x2", {50: 1e-6, 75: 1e-4, 100: 1e-2}),
 ])
 def test_march_overlapped_steps_against_golden(precision, win, g2):
@@ -497,10 +579,7 @@ def test_march_overlapped_steps_against_golden(precision, win, g2):
                 np.testing.assert_allclose(row, gold[:, :row.shape[1]], rtol=0, atol=1e-5, err_msg=f"{key}@{s}")
         for name in ("Cl", "Cd", "Cm"):
             for hi, tol in win.items():
-                # the last window has ~4x margin with the deterministic kernels; the float atomics used here reorder
-                # between runs, so it gets 3x more
-                lim = 3 * tol if hi == 100 else tol
-                assert np.abs(getattr(sim, name)[:hi] - g2[name][:hi]).max() <= lim, (name, hi)
+                assert np.abs(getattr(sim, name)[:hi] - g2[name][:hi]).max() <= tol, (name, hi)
             assert abs(np.mean(getattr(sim, name)[200:]) - np.mean(g2[name][200:])) <= 5e-2, name
         c = sim.circulation
         assert abs(c["bound"][399] + c["TEV"].sum() + c["LEV"].sum() - c["IC"]) < 1e-9      # Kelvin
@@ -525,9 +604,8 @@ def test_march_overlapped_steps_match_the_per_step_path(threshold):
         assert (a.itev, a.ilev) == (b.itev, b.ilev)
         for name in ("Cl", "Cd", "Cm"):
             d = np.abs(getattr(a, name) - getattr(b, name))
-            # rounding differences grow ~10x per 12 steps: 6e-6 at step 60 measured, ~3e-4 expected at 80, 4e-2 seen at
-            # 100 (float atomics reorder between runs, so the later bound is kept two orders away)
-            assert d[:60].max() <= 2e-5 and d[:80].max() <= 1e-1, (name, d[:60].max(), d[:80].max())
+            # by step 100 each fp32 trajectory is up to 2.6e-2 from the golden run (tier T2 allows 1e-1 there)
+            assert d[:60].max() <= 2e-5 and d[:100].max() <= 1e-1, (name, d[:60].max(), d[:100].max())
         assert np.abs(a.circulation["TEV"][:60] - b.circulation["TEV"][:60]).max() <= 1e-5
         assert a.path["TEV"][a.nt - 1].shape == b.path["TEV"][b.nt - 1].shape
     finally:
@@ -583,7 +661,7 @@ def test_march_overlapped_in_several_calls_and_resumed(tmp_path):
             assert np.array_equal(one.LEV_shed, other.LEV_shed)
             for name in ("Cl", "Cd", "Cm"):
                 d = np.abs(getattr(one, name) - getattr(other, name))
-                assert d[:60].max() <= 2e-5 and d[:80].max() <= 1e-1, (name, d[:60].max(), d[:80].max())
+                assert d[:60].max() <= 2e-5 and d.max() <= 1e-1, (name, d[:60].max(), d.max())
             assert (one.itev, one.ilev) == (other.itev, other.ilev)
     finally:
         e.close()
@@ -668,7 +746,7 @@ def test_march_fuzz_against_the_per_step_path():
     import subprocess
     import sys
     from conftest import ROOT
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_march.py"), "--cases", "24", "--seed", "4"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_march.py"), "--cases", "24", "--seed", "7"],
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-1500:])
     last = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])

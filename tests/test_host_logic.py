@@ -138,14 +138,6 @@ def test_constructor_validation():
         LUDVM(**dict(CONFIG1, method="Newton", tf=0.2), engine=FakeEngine(), verbose=False)
 
 
-def test_plunge_and_efficiency_run():
-    s = LUDVM(**dict(CONFIG1, tf=1), engine=FakeEngine(), verbose=False)
-    s.propulsive_efficiency(T=0.5)          # the reference raises NameError here (LUDVM.py:1367)
-    assert s.etap.shape == (2,)
-    s.motion_plunge(G=1, T=2, alpha_m=4)    # the reference raises TypeError here (LUDVM.py:520)
-    assert s.alpha_e.shape == (s.nt,) and np.all(np.isfinite(s.alpha_e))
-
-
 @pytest.mark.parametrize("history", ["full", "sparse"])
 def test_checkpoint_resume_is_bitwise_with_a_deterministic_engine(tmp_path, sim1, history):
     ck = str(tmp_path / "run.npz")
@@ -188,15 +180,3 @@ def test_dat_section_and_sin_motion(tmp_path):
     assert abs(m.hpiv[0]) < 1e-15 and abs(m.alpha[0] - np.deg2rad(10)) < 1e-12
     with pytest.raises(ValueError):
         m.motion_sinusoidal(motion="saw")
-
-
-def test_animation_builds_headless(sim1):
-    import matplotlib
-    matplotlib.use("Agg", force=True)
-    ani = sim1.animation(step=100, ani_interval=1)
-    assert ani is not None
-    import matplotlib.pyplot as plt
-    plt.close("all")
-    sp = LUDVM(**dict(CONFIG1, tf=0.5), engine=FakeEngine(), verbose=False, history="sparse")
-    with pytest.raises(RuntimeError):
-        sp.animation()

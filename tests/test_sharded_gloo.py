@@ -1,6 +1,7 @@
 """CPU tier: the multi-GPU shard step (ludvm_amd/sharded.py) under gloo with world_size 2 and 3.
 The pair arithmetic is the oracle's (tests only); what is under test is the partition of targets,
-the single all-gather, the re-layout of the gathered blocks and padding when N % G != 0."""
+the single collective per step (all-gather of positions, or integer all-reduce of the fixed-point sums), the
+re-layout of the gathered blocks and padding when N % G != 0."""
 import os
 import socket
 
@@ -26,14 +27,26 @@ class OracleShardKernel:
         x_out.copy_(torch.from_numpy((x[sl] + dt * u).astype(np.float32)))
         z_out.copy_(torch.from_numpy((z[sl] + dt * w).astype(np.float32)))
 
-    def sym_accumulate(self, xs, zs, gs, tile_first, tile_count, v_core, acc_u, acc_w):
+    def sym_scale(self, gs, v_core, scale):
+        """The library's rule: a power of two that keeps sum|Gamma| / (sqrt(2) v_core) under 2^61 (opaque record;
+        here: float64 [S, 1/S])."""
+        bound = float(np.abs(gs.numpy().astype(np.float64)).sum()) / (np.sqrt(2.0) * v_core)
+        k = 61 - (int(np.frexp(bound)[1]) if bound > 0 else 0)
+        scale.view(torch.float64)[0] = 2.0 ** k
+        scale.view(torch.float64)[1] = 2.0 ** -k
+
+    def sym_accumulate(self, xs, zs, gs, tile_first, tile_count, v_core, scale, acc):
         x, z, g = xs.numpy().astype(np.float64), zs.numpy().astype(np.float64), gs.numpy().astype(np.float64)
         from ludvm_amd._ffi import SYM_TILE
         n, W = len(x), SYM_TILE
         nt = (n + W - 1) // W
         even = nt % 2 == 0 and nt > 1
         dtot = (nt - 1) // 2 + (1 if even else 0)
-        au, aw = np.zeros(n), np.zeros(n)
+        S = float(scale.view(torch.float64)[0])
+        au, aw = np.zeros(n, np.int64), np.zeros(n, np.int64)
+
+        def fx(v):          # one fp32 partial sum -> fixed point, as the kernel adds it
+            return np.trunc(v.astype(np.float32).astype(np.float64) * S).astype(np.int64)
 
         def block(isl, jsl):
             dx = x[isl, None] - x[None, jsl]
@@ -44,26 +57,31 @@ class OracleShardKernel:
         for I in range(tile_first, tile_first + tile_count):
             isl = slice(I * W, min(n, (I + 1) * W))
             dx, dz, s = block(isl, isl)                     # diagonal tile: ordered, i-side only
-            au[isl] += (g[None, isl] * dz * s).sum(1)
-            aw[isl] += (g[None, isl] * dx * s).sum(1)
+            au[isl] += fx((g[None, isl] * dz * s).sum(1))
+            aw[isl] += fx((g[None, isl] * dx * s).sum(1))
             for d in range(1, dtot + 1):
                 if even and d == dtot and I >= nt // 2:
                     break
                 J = (I + d) % nt
                 jsl = slice(J * W, min(n, (J + 1) * W))
                 dx, dz, s = block(isl, jsl)
-                au[isl] += (g[None, jsl] * dz * s).sum(1)
-                aw[isl] += (g[None, jsl] * dx * s).sum(1)
-                au[jsl] -= (g[isl, None] * dz * s).sum(0)   # j feels the opposite of what i feels
-                aw[jsl] -= (g[isl, None] * dx * s).sum(0)
-        acc_u += torch.from_numpy(au.astype(np.float32))
-        acc_w += torch.from_numpy(aw.astype(np.float32))
+                au[isl] += fx((g[None, jsl] * dz * s).sum(1))
+                aw[isl] += fx((g[None, jsl] * dx * s).sum(1))
+                au[jsl] -= fx((g[isl, None] * dz * s).sum(0))   # j feels the opposite of what i feels
+                aw[jsl] -= fx((g[isl, None] * dx * s).sum(0))
+        acc[:n] += torch.from_numpy(au)
+        acc[n:2 * n] += torch.from_numpy(aw)
 
-    def advect_from_sums(self, sum_u, sum_w, xs, zs, t_first, nt, dt, x_out, z_out):
+    def advect_from_sums(self, acc, scale, xs, zs, t_first, nt, dt, x_out, z_out):
+        n = xs.numel()
+        assert int(acc[2 * n]) == 0
+        inv = float(scale.view(torch.float64)[1])
         sl = slice(t_first, t_first + nt)
         k = 1.0 / (2 * np.pi)
-        x_out.copy_(xs[sl] + dt * (sum_u * k))
-        z_out.copy_(zs[sl] - dt * (sum_w * k))
+        su = (acc[:n][sl].numpy().astype(np.float64) * inv).astype(np.float32)
+        sw = (acc[n:2 * n][sl].numpy().astype(np.float64) * inv).astype(np.float32)
+        x_out.copy_(xs[sl] + dt * torch.from_numpy(su * np.float32(k)))
+        z_out.copy_(zs[sl] - dt * torch.from_numpy(sw * np.float32(k)))
 
 
 def _wake(n):

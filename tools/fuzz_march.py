@@ -63,8 +63,7 @@ def main():
             fm, fp_ = first_departure(m), first_departure(p)
             extra = {"march_vs_f64": float(em), "per_step_vs_f64": float(ep), "march_vs_per_step_first_15_steps": float(e15),
                      "shedding_departs_from_f64_at_step": {"march": fm, "per_step": fp_}}
-            # generous on purpose: float atomics reorder between runs, a defect shows as orders of magnitude
-            ok = fm >= fp_ - 12 and em <= 8 * ep + 1e-5 and e15 <= 1e-4
+            ok = fm >= fp_ - 5 and em <= 5 * ep + 1e-5 and e15 <= 1e-4
         if prec == "f64":
             worst["dCl"] = max(worst["dCl"], dcl); worst["dGamma"] = max(worst["dGamma"], dg); worst["drow"] = max(worst["drow"], drow)
         if extra:
