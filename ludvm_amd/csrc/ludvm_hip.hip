@@ -368,9 +368,16 @@ static_assert(64 * 8 == LUDVM_SYM_TILE, "the multi-GPU entry points always use t
 
 // The symmetric kernel accumulates in fixed point, which needs the bound sum|Gamma| / (sqrt(2) v_core) on the raw
 // sums: point vortices (v_core = 0, or so small that v_core^4 vanishes in fp32) take the direct kernel.
-bool use_symmetric(const ludvm_ctx* c, long long n, double vc4) {
+// In the march a symmetric step is an OVERLAPPED step: chord sums and solve run beside the kernel instead of in front
+// of it (~40 us of a ~60 us serial step at 1e4 vortices), so it pays earlier there: from ~11 000 vortices [MI355X]
+// (profiles/r02_march_symmetric_threshold.txt).
+constexpr long long kSymMinNMarch = 11264;
+long long sym_threshold(const ludvm_ctx* c, bool march = false) {
+  return c->sym_mode == 1 ? (march ? kSymMinNMarch : kSymMinN) : (long long)c->sym_mode;
+}
+bool use_symmetric(const ludvm_ctx* c, long long n, double vc4, bool march = false) {
   if (c->sym_mode == 0 || !((float)vc4 > 0.0f)) return false;
-  return n >= (c->sym_mode == 1 ? kSymMinN : (long long)c->sym_mode);
+  return n >= sym_threshold(c, march);
 }
 
 int sym_tile_t(const ludvm_ctx* c, long long n, bool hilo, bool local = false) {
@@ -415,24 +422,31 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   a.scale = o.scale;
   a.bad = o.bad;
   a.vc4 = (float)vc4;
-  long long waves = i_count * gm.ysplit * gm.rsplit;
+  // workgroups: 4 / rsplit items (tile, d-chunk) each
+  auto blocks_of = [](long long items, int rs) { const long long ipb = 4 / rs; return (items + ipb - 1) / ipb; };
+  long long blocks = blocks_of(i_count * gm.ysplit, gm.rsplit);
   if (n_dev) {
     const long long W = 64LL * T;
     for (long long nt = std::max<long long>(1, (std::max<long long>(n_lo, 1) + W - 1) / W); nt <= gm.ntiles; ++nt) {
-      const SymGeom q = sym_geometry(nt * W, T, a.tune_split, a.tune_rsplit);
-      waves = std::max(waves, q.ntiles * q.ysplit * q.rsplit);
+      const SymGeom q = sym_geometry(nt * W, T, a.tune_split, gm.rsplit);    // rsplit fixed by the bound: it picks the kernel
+      blocks = std::max(blocks, blocks_of(q.ntiles * q.ysplit, gm.rsplit));
     }
   }
   TimedLaunch t{};
   bool active = false;
   CHK(timed_begin(c, t, active));
-  const dim3 grid((unsigned)((waves + 3) / 4));
-  if (hilo)
-    hipLaunchKernelGGL((pair_sym_f32<4, true>), grid, dim3(kBlock), 0, c->stream, a);
-  else if (T == 8)
-    hipLaunchKernelGGL((pair_sym_f32<8, false>), grid, dim3(kBlock), 0, c->stream, a);
-  else
-    hipLaunchKernelGGL((pair_sym_f32<4, false>), grid, dim3(kBlock), 0, c->stream, a);
+  const dim3 grid((unsigned)blocks);
+  const dim3 blk(kBlock);
+#define LUDVM_SYM_LAUNCH(TT, HH)                                                                              \
+  switch (gm.rsplit) {                                                                                        \
+    case 1: hipLaunchKernelGGL((pair_sym_f32<TT, HH, 1>), grid, blk, 0, c->stream, a); break;                 \
+    case 2: hipLaunchKernelGGL((pair_sym_f32<TT, HH, 2>), grid, blk, 0, c->stream, a); break;                 \
+    default: hipLaunchKernelGGL((pair_sym_f32<TT, HH, 4>), grid, blk, 0, c->stream, a); break;                \
+  }
+  if (hilo) { LUDVM_SYM_LAUNCH(4, true) }
+  else if (T == 8) { LUDVM_SYM_LAUNCH(8, false) }
+  else { LUDVM_SYM_LAUNCH(4, false) }
+#undef LUDVM_SYM_LAUNCH
   HIPCHK(c, hipGetLastError());
   CHK(timed_end(c, t, active));
   return LUDVM_OK;
@@ -441,6 +455,22 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
 SymScale* ctx_scale(ludvm_ctx* c) { return static_cast<SymScale*>(c->symsc.p); }
 long long* ctx_bad(ludvm_ctx* c) { return reinterpret_cast<long long*>(static_cast<char*>(c->symsc.p) + 64); }
 
+// Fixed-point scale record for circulations g[0, n) into (scale, bad); `partial` = workspace for the chunk sums.
+int launch_sym_prepare(ludvm_ctx* c, const float* g, long long n, double vc4, SymScale* scale, long long* bad) {
+  const long long nparts = (n + kPrepChunk - 1) / kPrepChunk;
+  if (nparts <= 1) {
+    hipLaunchKernelGGL(sym_prepare, dim3(1), dim3(kPrepBlock), 0, c->stream, g, n, vc4, scale, bad, (double*)nullptr);
+  } else {
+    CHK(ensure(c, c->symsc, 128 + (size_t)nparts * sizeof(double)));
+    // (the record itself may live in c->symsc: re-derive the pointers after a grow)
+    double* partial = reinterpret_cast<double*>(static_cast<char*>(c->symsc.p) + 128);
+    hipLaunchKernelGGL(sym_prepare, dim3((unsigned)nparts), dim3(kPrepBlock), 0, c->stream, g, n, vc4, scale, bad, partial);
+    hipLaunchKernelGGL(sym_prepare_final, dim3(1), dim3(64), 0, c->stream, partial, (int)nparts, vc4, scale, bad);
+  }
+  HIPCHK(c, hipGetLastError());
+  return LUDVM_OK;
+}
+
 // Symmetric self-interaction of all of (x, z, g)[0, n) with the context's accumulators: zero them, derive the
 // fixed-point scale from sum|Gamma| (unless the caller -- the march -- maintains it: scale / bad given), run the
 // kernel.  The raw sums are left in c->acc as [acc_u | acc_w], each nt_pad 64-bit integers.
@@ -448,14 +478,13 @@ int launch_sym(ludvm_ctx* c, SymOperands o, long long n, double vc4, long long* 
                long long n_lo = 0) {
   const long long nt_pad = (n + 63) / 64 * 64;
   CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(long long)));
-  CHK(ensure(c, c->symsc, 128));
+  CHK(ensure(c, c->symsc, 128 + (size_t)((n + kPrepChunk - 1) / kPrepChunk) * sizeof(double)));
   HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(long long), c->stream));
   long long* acc = static_cast<long long*>(c->acc.p);
   o.acc_u = acc;
   o.acc_w = acc + nt_pad;
   if (!o.scale) {
-    hipLaunchKernelGGL(sym_prepare, dim3(1), dim3(kPrepBlock), 0, c->stream, o.g, n, vc4, ctx_scale(c), ctx_bad(c));
-    HIPCHK(c, hipGetLastError());
+    CHK(launch_sym_prepare(c, o.g, n, vc4, ctx_scale(c), ctx_bad(c)));
     o.scale = ctx_scale(c);
     o.bad = ctx_bad(c);
   }
@@ -851,10 +880,8 @@ int ludvm_sym_scale_dev_f32(ludvm_ctx* c, const float* d_g, size_t n, float vcor
   if (!((float)(v2 * v2) > 0.0f)) return fail(c, LUDVM_E_ARG, "the symmetric kernel needs v_core > 0 (fixed-point bound)");
   HIPCHK(c, hipSetDevice(c->device));
   char* rec = static_cast<char*>(d_scale);
-  hipLaunchKernelGGL(sym_prepare, dim3(1), dim3(kPrepBlock), 0, c->stream, d_g, (long long)n, v2 * v2,
-                     reinterpret_cast<SymScale*>(rec), reinterpret_cast<long long*>(rec + 16));
-  HIPCHK(c, hipGetLastError());
-  return LUDVM_OK;
+  CHK(ensure(c, c->symsc, 128 + (size_t)((n + kPrepChunk - 1) / kPrepChunk) * sizeof(double)));
+  return launch_sym_prepare(c, d_g, (long long)n, v2 * v2, reinterpret_cast<SymScale*>(rec), reinterpret_cast<long long*>(rec + 16));
 }
 
 int ludvm_sym_accumulate_dev_f32(ludvm_ctx* c, const float* d_x, const float* d_z, const float* d_g, size_t n,
@@ -1075,14 +1102,14 @@ int ludvm_wake_advect_tail(ludvm_ctx* c, double dt, const double* foil_x, const 
 static inline unsigned fin_blocks(long long n) { return (unsigned)((n + kFinBlock - 1) / kFinBlock); }
 
 // (march) where a symmetric launch sized from an upper bound finds its scale and how small the wake may be
-struct MarchSym { const SymScale* scale = nullptr; long long* bad = nullptr; long long n_lo = 0; };
+struct MarchSym { const SymScale* scale = nullptr; long long* bad = nullptr; long long n_lo = 0; bool march = false; };
 
 static int advect_launch(ludvm_ctx* c, size_t n, const long long* n_dev, double dt, size_t nfoil, double vcore,
                          int precision, double* du, double* dw, TailDuty td = TailDuty{}, MarchSym ms = MarchSym{}) {
   const long long ns = (long long)(n + nfoil), nt = (long long)n;
   const double v2 = vcore * vcore;
   const bool hilo = precision == LUDVM_PREC_F32X2;
-  if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt, v2 * v2)) {
+  if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt, v2 * v2, ms.march)) {
     // wake x wake: each unordered pair once; the bound vortices' part is summed in the Euler finisher
     long long nt_pad = 0;
     SymOperands o{};
@@ -1328,9 +1355,11 @@ int march_chord_launch(ludvm_ctx* c, long long n_ub) {
 // workspace a march step may need when the wake holds at most n_ub vortices
 void march_workspace(const ludvm_ctx* c, long long n_ub, int precision, size_t nfoil, size_t& part_bytes, size_t& acc_bytes) {
   const long long nt = std::max<long long>(n_ub, 1);
-  if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt, c->msetup.vc4)) {
+  // (both kernels' workspaces where either may run: the overlapped march switches to the symmetric kernel earlier
+  // than the serial one)
+  if (precision != LUDVM_PREC_F64 && use_symmetric(c, nt, c->msetup.vc4, true))
     acc_bytes = std::max(acc_bytes, (size_t)2 * (size_t)((nt + 63) / 64 * 64) * sizeof(long long));
-  } else {
+  if (precision == LUDVM_PREC_F64 || !use_symmetric(c, nt, c->msetup.vc4, false)) {
     Plan p = make_plan(c, nt, nt + (long long)nfoil, precision);
     const size_t elt = precision == LUDVM_PREC_F64 ? 8 : 4;
     part_bytes = std::max(part_bytes, (size_t)p.nsplit * 2 * (size_t)p.nt_pad * elt);
@@ -1408,7 +1437,7 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   const bool overlap_ok = !(ov_env && ov_env[0] == '0');
   hipStream_t const main_stream = c->stream;
   const double vc4 = m.vc4;
-  const long long thr = c->sym_mode == 1 ? kSymMinN : (long long)c->sym_mode;
+  const long long thr = sym_threshold(c, overlap_ok);      // serial symmetric steps pay from the usual size only
   for (long long s = first_step; s < first_step + count; ++s) {
     const long long rel = s - first_step;
     if (rel % kSyncEvery == 0) {
@@ -1431,7 +1460,7 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
     const long long n_ub = p_n + 2 * (s - p_step);
     const long long n_lo = p_n + (s - 1 - p_step);      // ... and before it: at least one per step
     n_before = std::min<long long>(n_before, n_ub);
-    const bool symreg = precision != LUDVM_PREC_F64 && use_symmetric(c, n_ub, vc4);
+    const bool symreg = precision != LUDVM_PREC_F64 && use_symmetric(c, n_ub, vc4, overlap_ok);
     // overlapped steps need an old wake that already fills the symmetric kernel
     const bool fork = symreg && overlap_ok && n_lo >= thr;
     const double* krow_s = kin + (size_t)s * krow;
@@ -1449,7 +1478,7 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
                          c->mir(), c->g32, c->progress_dev);
       HIPCHK(c, hipGetLastError());
       MarchSym ms;
-      ms.scale = &S->sc[(s + 1) & 1]; ms.bad = &S->sym_bad; ms.n_lo = n_lo + 1;
+      ms.scale = &S->sc[(s + 1) & 1]; ms.bad = &S->sym_bad; ms.n_lo = n_lo + 1; ms.march = overlap_ok;
       CHK(advect_launch(c, (size_t)n_ub, &S->n, m.dt, nfoil, c->march_vcore, precision, nullptr, nullptr, td, ms));
       overlapped = false;    // the serial symmetric step leaves its sums in the accumulators
     } else {

@@ -121,6 +121,8 @@ pair_f32(PairArgs a) {
   __shared__ __attribute__((aligned(16))) float lg[TILE];
   __shared__ __attribute__((aligned(16))) float lxl[HILO ? TILE : 4];
   __shared__ __attribute__((aligned(16))) float lzl[HILO ? TILE : 4];
+  constexpr int kSegs = LOCAL ? (TILE + kOriginBlock - 1) / kOriginBlock : 1;
+  __shared__ float lox[kSegs], loz[kSegs];      // LOCAL: origins of the tile's source blocks, staged with the tile
 
   const float* __restrict__ xs = static_cast<const float*>(a.xs);
   const float* __restrict__ zs = static_cast<const float*>(a.zs);
@@ -192,6 +194,10 @@ pair_f32(PairArgs a) {
         lzl[l] = ok ? a.zsl[si] : 0.0f;
       }
     }
+    if (LOCAL && tid < kSegs && base + (long long)tid * kOriginBlock < s_end) {
+      lox[tid] = a.scx[(base >> kOriginShift) + tid];
+      loz[tid] = a.scz[(base >> kOriginShift) + tid];
+    }
     __syncthreads();
 
     // two-level sum: a tile's 1024 contributions are summed on their own and then added to the running
@@ -207,7 +213,7 @@ pair_f32(PairArgs a) {
       // the segment's sources share one origin: refer this lane's targets to it
       const long long sidx = base + seg;
       if (sidx >= s_end) break;
-      const float ox = a.scx[sidx >> kOriginShift], oz = a.scz[sidx >> kOriginShift];
+      const float ox = lox[seg >> kOriginShift], oz = loz[seg >> kOriginShift];
 #pragma unroll
       for (int t = 0; t < TPL; ++t) {
         float x, z;

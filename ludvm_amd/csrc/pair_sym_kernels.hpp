@@ -90,9 +90,17 @@ __host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_spl
   return g;
 }
 
-// acc += (long long)(v * scale): order-independent accumulation of an fp32 partial sum
+// acc += floor(v * scale): order-independent accumulation of an fp32 partial sum.  The 64-bit integer is put together
+// from two 32-bit conversions (6 VALU instructions; the compiler's float -> int64 sequence takes ~16, and there are
+// 4 T of these per tile pair): t = v * scale is exact (power-of-two scale), h = floor(t / 2^32) fits an int32 because
+// |t| < 2^63, and the remainder t - h 2^32 is an exact fp32 number in [0, 2^32).
 __device__ __forceinline__ void fx_add(long long* acc, float v, float scale) {
-  atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)(v * scale));
+  const float t = v * scale;
+  const float h = __builtin_floorf(t * 2.3283064365386963e-10f);            // 2^-32
+  const float r = __builtin_fmaf(-h, 4294967296.0f, t);
+  const unsigned lo = (unsigned)r;
+  const int hi = (int)h;
+  atomicAdd(reinterpret_cast<unsigned long long*>(acc), ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)lo);
 }
 
 // lane l receives the value of lane l+1 (wrapping): data moves one lane down
@@ -127,37 +135,51 @@ __device__ __forceinline__ void slab_load(const float* l, int home4, f32x2 (&out
 // the 2*T J-accumulator registers travel between lanes (v_mov_b32_dpp, 4 issue cycles each on gfx950).
 // HILO: positions are hi+lo fp32 pairs, dx = (xh_i - xh_j) + (xl_i - xl_j), +4 packed ops
 // per two unordered pairs; everything after the difference is plain fp32.
-template <int T, bool HILO = false>
+//
+// Work items and waves.  An item is (tile I, d-chunk y); with rsplit = R > 1 (mid-size launches: too few tile pairs
+// to keep every SIMD busy to the end) the 64 rotation steps of each of its tile pairs are shared by R waves OF ONE
+// WORKGROUP (a workgroup holds 4 / R items).  Their partial sums -- R sets of 2 T values per lane for the J side of
+// every tile pair, and for the I side at the end -- are added through LDS in a fixed order before they go to the
+// accumulators: the atomics, whose 64-B requests at the memory side are what limits mid sizes [MI355X], are issued
+// once per item instead of once per wave.  Every wave of a workgroup runs the same number of tile-pair rounds
+// (`per`), valid or not, so the workgroup barriers inside are uniform.
+// RED = false (the 512-vortex tile, whose register budget has no room for it, and R = 1): every wave adds its own
+// partial sums to the accumulators.
+template <int T, bool HILO = false, int R = 1, bool RED = (R > 1 && T == 4)>
 __global__ void __launch_bounds__(kBlock)
 pair_sym_f32(SymArgs a) {
   static_assert(T == 4 || T == 8, "T vortices per lane, read as T/4 ds_read_b128 per component");
+  static_assert(R == 1 || R == 2 || R == 4, "waves per item");
+  static_assert(!RED || R > 1, "nothing to reduce with one wave per item");
   if (a.n_dev) {
+    // (rsplit stays what the host chose from its bound on n: it selects this very instantiation)
     a.n = *a.n_dev;
-    const SymGeom gm = sym_geometry(a.n, T, a.tune_split, a.tune_rsplit);
+    const SymGeom gm = sym_geometry(a.n, T, a.tune_split, R);
     a.ntiles = gm.ntiles;
     a.dmax = gm.dmax;
     a.i_count = gm.ntiles;
     a.ysplit = gm.ysplit;
-    a.rsplit = gm.rsplit;
   }
   constexpr int H = T / 2;
   constexpr int kWaves = kBlock / 64;
   constexpr int kComp = HILO ? 5 : 3;
   __shared__ __attribute__((aligned(16))) float slab[kWaves][kComp][64 * T];
+  // partial sums of the R waves of an item (double-buffered by round)
+  __shared__ float red[RED ? 2 : 1][RED ? kWaves : 1][RED ? 2 * T : 1][RED ? 64 : 1];
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: tile indices stay scalar
-  const long long wid = (long long)blockIdx.x * kWaves + wv;
-  if (wid >= a.i_count * a.ysplit * a.rsplit) return;   // whole waves leave together; no block-wide barrier is used
-  const long long I = a.i_first + wid % a.i_count;
-  const int yr = (int)(wid / a.i_count);
-  const int y = yr / a.rsplit;
-  // Mid-size launches have too few tile pairs to keep every SIMD busy to the end, so a tile pair's 64 rotation
-  // steps can be shared by rsplit waves: this one does steps [k_lo, k_hi).  A J accumulator set that starts in
-  // lane l at step k_lo belongs to home lane (l + k_lo) and, one lane per step, sits in lane (home - k_hi) after
-  // the last step -- it is added to its vortices from there (the sums are atomics anyway).
-  const int k_lo = (yr % a.rsplit) * (64 / a.rsplit);
-  const int k_hi = k_lo + 64 / a.rsplit;
+  const int r = wv % R;                    // this wave's share of the rotation steps
+  const int w0 = wv - r;                   // first wave of the item in the workgroup
+  const long long item = (long long)blockIdx.x * (kWaves / R) + wv / R;
+  const bool active = item < a.i_count * a.ysplit;
+  if (!RED && !active) return;             // no barriers on this path: whole waves leave
+  const long long I = a.i_first + (active ? item % a.i_count : 0);
+  const int y = active ? (int)(item / a.i_count) : 0;
+  // This wave does rotation steps [k_lo, k_hi) of every tile pair.  A J accumulator set that starts in lane l at step
+  // k_lo belongs to home lane (l + k_lo) and, one lane per step, sits in lane (home - k_hi) after the last step.
+  const int k_lo = r * (64 / R);
+  const int k_hi = k_lo + 64 / R;
   const long long W = 64LL * T;
   float* const lx = slab[wv][0];
   float* const lz = slab[wv][1];
@@ -182,7 +204,7 @@ pair_sym_f32(SymArgs a) {
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const long long i = I * W + lane + 64LL * t;
-    const bool ok = i < a.n;
+    const bool ok = active && i < a.n;
     x0[t] = ok ? a.x[i] : kPadPosF; z0[t] = ok ? a.z[i] : kPadPosF; g0[t] = ok ? a.g[i] : 0.0f;
     xl0[t] = (HILO && ok) ? a.xl[i] : 0.0f; zl0[t] = (HILO && ok) ? a.zl[i] : 0.0f;
     xp[t] = (f32x2){x0[t], x0[t]}; zp[t] = (f32x2){z0[t], z0[t]}; gp[t] = (f32x2){g0[t], g0[t]};
@@ -197,7 +219,7 @@ pair_sym_f32(SymArgs a) {
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     oix[q] = 0.0f; oiz[q] = 0.0f;
-    if (local) { oix[q] = a.cx[((I * W) >> kOriginShift) + q]; oiz[q] = a.cz[((I * W) >> kOriginShift) + q]; }
+    if (local && active) { oix[q] = a.cx[((I * W) >> kOriginShift) + q]; oiz[q] = a.cz[((I * W) >> kOriginShift) + q]; }
   }
 #pragma unroll
   for (int q = 0; q < NS; ++q)
@@ -211,7 +233,7 @@ pair_sym_f32(SymArgs a) {
   float chk = 0.0f;   // sum of everything this lane hands to the accumulators: not finite <=> some partial is not
 
   // ---- diagonal tile: ordered evaluation, i-side only (contains the self pairs) ----------------
-  if (y == 0) {
+  if (active && y == 0) {
     slab_store<T>(lx, lane * 4, x0); slab_store<T>(lz, lane * 4, z0); slab_store<T>(lg, lane * 4, g0);
     if (HILO) { slab_store<T>(lxl, lane * 4, xl0); slab_store<T>(lzl, lane * 4, zl0); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -244,98 +266,149 @@ pair_sym_f32(SymArgs a) {
   }
 
   // ---- off-diagonal tiles: each unordered pair once, both sides accumulated --------------------
-  for (long long d = d_lo; d < d_hi; ++d) {
-    if (even && d == dtot && I >= a.ntiles / 2) break;  // the half-way offset pairs each tile twice
+  // (`per` rounds for every wave of the workgroup; a round without a tile pair only takes part in the barrier)
+  for (long long dd = 0; dd < per; ++dd) {
+    const long long d = d_lo + dd;
+    const bool valid = active && d < d_hi && !(even && d == dtot && I >= a.ntiles / 2);  // the half-way offset pairs each tile twice
     long long J = I + d;
     if (J >= a.ntiles) J -= a.ntiles;
-    if (local) {
-      // refer my targets to the origins of the partner tile's blocks: one rounding of (origin_I - origin_J) + offset
-      // per target and block pair; neighbouring blocks keep their relative precision, far ones do not need it
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        // (re-read rather than kept in registers: T loads per 64 * T * T pair evaluations)
-        const long long i = I * W + lane + 64LL * t;
-        const bool ok = i < a.n;
-        const float xi = ok ? a.x[i] : kPadPosF, zi = ok ? a.z[i] : kPadPosF;
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          const long long jb = ((J * W) >> kOriginShift) + q;
-          const float xx = xi + (oix[t / 4] - a.cx[jb]), zz = zi + (oiz[t / 4] - a.cz[jb]);
-          xq[q][t] = (f32x2){xx, xx}; zq[q][t] = (f32x2){zz, zz};
-        }
-      }
-    }
-    {
-      float x[T], z[T], g[T], xl[T], zl[T];
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const long long j = J * W + lane + 64LL * t;
-        const bool ok = j < a.n;
-        x[t] = ok ? a.x[j] : kPadPosF; z[t] = ok ? a.z[j] : kPadPosF; g[t] = ok ? a.g[j] : 0.0f;
-        xl[t] = (HILO && ok) ? a.xl[j] : 0.0f; zl[t] = (HILO && ok) ? a.zl[j] : 0.0f;
-      }
-      slab_store<T>(lx, lane * 4, x); slab_store<T>(lz, lane * 4, z); slab_store<T>(lg, lane * 4, g);
-      if (HILO) { slab_store<T>(lxl, lane * 4, xl); slab_store<T>(lzl, lane * 4, zl); }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!RED && !valid) continue;
     f32x2 bu[H], bw[H];
 #pragma unroll
     for (int m = 0; m < H; ++m) { bu[m] = (f32x2){0.f, 0.f}; bw[m] = (f32x2){0.f, 0.f}; }
-
-    // (issuing the reads of step k+1 ahead of the arithmetic of step k measured no gain: with 4-5
-    // waves per SIMD the LDS latency is already covered)
-    for (int k = k_lo; k < k_hi; ++k) {
-      // at step k this lane holds the accumulators of the J vortices whose home lane is (lane + k) % 64
-      const int pos = ((lane + k) & 63) * 4;
-      f32x2 xj[H], zj[H], gj[H], xjl[H], zjl[H];
-      slab_load<T>(lx, pos, xj); slab_load<T>(lz, pos, zj); slab_load<T>(lg, pos, gj);
-      if (HILO) { slab_load<T>(lxl, pos, xjl); slab_load<T>(lzl, pos, zjl); }
-#pragma unroll
-      for (int m = 0; m < H; ++m) {
+    if (valid) {
+      if (local) {
+        // refer my targets to the origins of the partner tile's blocks: one rounding of (origin_I - origin_J) + offset
+        // per target and block pair; neighbouring blocks keep their relative precision, far ones do not need it
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          f32x2 dx = (HILO ? xp[t] : xq[m / 2][t]) - xj[m];
-          f32x2 dz = (HILO ? zp[t] : zq[m / 2][t]) - zj[m];
-          if (HILO) { dx = dx + (xpl[t] - xjl[m]); dz = dz + (zpl[t] - zjl[m]); }
-          f32x2 r2 = dx * dx;
-          r2 = __builtin_elementwise_fma(dz, dz, r2);
-          const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
-          const f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
-          const f32x2 sj = s * gj[m];      // strength of j acting on i
-          const f32x2 si = s * gp[t];      // strength of i acting on j
-          au[t] = __builtin_elementwise_fma(dz, sj, au[t]);
-          aw[t] = __builtin_elementwise_fma(dx, sj, aw[t]);
-          bu[m] = __builtin_elementwise_fma(dz, si, bu[m]);
-          bw[m] = __builtin_elementwise_fma(dx, si, bw[m]);
+          // (re-read rather than kept in registers: T loads per 64 * T * T pair evaluations)
+          const long long i = I * W + lane + 64LL * t;
+          const bool ok = i < a.n;
+          const float xi = ok ? a.x[i] : kPadPosF, zi = ok ? a.z[i] : kPadPosF;
+#pragma unroll
+          for (int q = 0; q < NS; ++q) {
+            const long long jb = ((J * W) >> kOriginShift) + q;
+            const float xx = xi + (oix[t / 4] - a.cx[jb]), zz = zi + (oiz[t / 4] - a.cz[jb]);
+            xq[q][t] = (f32x2){xx, xx}; zq[q][t] = (f32x2){zz, zz};
+          }
         }
       }
-      // hand the J accumulators to the lane that meets the same J vortices next step (lane - 1)
+      {
+        float x[T], z[T], g[T], xl[T], zl[T];
 #pragma unroll
-      for (int m = 0; m < H; ++m) { bu[m] = dpp_rol1(bu[m]); bw[m] = dpp_rol1(bw[m]); }
+        for (int t = 0; t < T; ++t) {
+          const long long j = J * W + lane + 64LL * t;
+          const bool ok = j < a.n;
+          x[t] = ok ? a.x[j] : kPadPosF; z[t] = ok ? a.z[j] : kPadPosF; g[t] = ok ? a.g[j] : 0.0f;
+          xl[t] = (HILO && ok) ? a.xl[j] : 0.0f; zl[t] = (HILO && ok) ? a.zl[j] : 0.0f;
+        }
+        slab_store<T>(lx, lane * 4, x); slab_store<T>(lz, lane * 4, z); slab_store<T>(lg, lane * 4, g);
+        if (HILO) { slab_store<T>(lxl, lane * 4, xl); slab_store<T>(lzl, lane * 4, zl); }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      // (issuing the reads of step k+1 ahead of the arithmetic of step k measured no gain: with 4-5
+      // waves per SIMD the LDS latency is already covered)
+      for (int k = k_lo; k < k_hi; ++k) {
+        // at step k this lane holds the accumulators of the J vortices whose home lane is (lane + k) % 64
+        const int pos = ((lane + k) & 63) * 4;
+        f32x2 xj[H], zj[H], gj[H], xjl[H], zjl[H];
+        slab_load<T>(lx, pos, xj); slab_load<T>(lz, pos, zj); slab_load<T>(lg, pos, gj);
+        if (HILO) { slab_load<T>(lxl, pos, xjl); slab_load<T>(lzl, pos, zjl); }
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            f32x2 dx = (HILO ? xp[t] : xq[m / 2][t]) - xj[m];
+            f32x2 dz = (HILO ? zp[t] : zq[m / 2][t]) - zj[m];
+            if (HILO) { dx = dx + (xpl[t] - xjl[m]); dz = dz + (zpl[t] - zjl[m]); }
+            f32x2 r2 = dx * dx;
+            r2 = __builtin_elementwise_fma(dz, dz, r2);
+            const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
+            const f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+            const f32x2 sj = s * gj[m];      // strength of j acting on i
+            const f32x2 si = s * gp[t];      // strength of i acting on j
+            au[t] = __builtin_elementwise_fma(dz, sj, au[t]);
+            aw[t] = __builtin_elementwise_fma(dx, sj, aw[t]);
+            bu[m] = __builtin_elementwise_fma(dz, si, bu[m]);
+            bw[m] = __builtin_elementwise_fma(dx, si, bw[m]);
+          }
+        }
+        // hand the J accumulators to the lane that meets the same J vortices next step (lane - 1)
+#pragma unroll
+        for (int m = 0; m < H; ++m) { bu[m] = dpp_rol1(bu[m]); bw[m] = dpp_rol1(bw[m]); }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next tile
     }
     // after step k_hi - 1 and its rotation this lane holds the set of home lane (lane + k_hi) % 64 (with all 64
     // steps done: its own); j feels the opposite of what i feels.
-    // home lane h holds vortices J*W + h + 64*t as packed elements t = 0..T-1
+    // home lane h holds vortices J*W + h + 64*t as packed elements t = 0..T-1; component c = 4 m + {0: u of element
+    // 2m, 1: u of 2m+1, 2: w of 2m, 3: w of 2m+1}
     const int home = (lane + k_hi) & 63;
+    if constexpr (!RED) {
+      if (valid) {
 #pragma unroll
-    for (int m = 0; m < H; ++m) {
-      const long long j0 = J * W + home + 64LL * (2 * m), j1 = j0 + 64;
-      if (j0 < a.n) { fx_add(&a.acc_u[j0], -bu[m].x, fxs); fx_add(&a.acc_w[j0], -bw[m].x, fxs); chk += bu[m].x + bw[m].x; }
-      if (j1 < a.n) { fx_add(&a.acc_u[j1], -bu[m].y, fxs); fx_add(&a.acc_w[j1], -bw[m].y, fxs); chk += bu[m].y + bw[m].y; }
+        for (int m = 0; m < H; ++m) {
+          const long long j0 = J * W + home + 64LL * (2 * m), j1 = j0 + 64;
+          if (j0 < a.n) { fx_add(&a.acc_u[j0], -bu[m].x, fxs); fx_add(&a.acc_w[j0], -bw[m].x, fxs); chk += bu[m].x + bw[m].x; }
+          if (j1 < a.n) { fx_add(&a.acc_u[j1], -bu[m].y, fxs); fx_add(&a.acc_w[j1], -bw[m].y, fxs); chk += bu[m].y + bw[m].y; }
+        }
+      }
+    } else {
+      auto& rb = red[dd & 1];
+      if (valid) {
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+          rb[wv][4 * m + 0][home] = bu[m].x; rb[wv][4 * m + 1][home] = bu[m].y;
+          rb[wv][4 * m + 2][home] = bw[m].x; rb[wv][4 * m + 3][home] = bw[m].y;
+        }
+      }
+      __syncthreads();
+      if (valid) {
+        // the R waves of the item share the 2 T components; each adds the R partials in wave order
+#pragma unroll
+        for (int c = 0; c < 2 * T; ++c) {
+          if (c % R != r) continue;
+          float v = 0.0f;
+#pragma unroll
+          for (int q = 0; q < R; ++q) v += rb[w0 + q][c][lane];
+          const long long j = J * W + lane + 64LL * (2 * (c / 4) + (c & 1));
+          if (j < a.n) { fx_add((c & 2) ? &a.acc_w[j] : &a.acc_u[j], -v, fxs); chk += v; }
+        }
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next tile
   }
 
+  // ---- the I side ------------------------------------------------------------------------------------------------
+  if constexpr (!RED) {
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const long long i = I * W + lane + 64LL * t;
-    if (i < a.n) {
-      const float su = au[t].x + au[t].y, sw = aw[t].x + aw[t].y;
-      fx_add(&a.acc_u[i], su, fxs); fx_add(&a.acc_w[i], sw, fxs);
-      chk += su + sw;
+    for (int t = 0; t < T; ++t) {
+      const long long i = I * W + lane + 64LL * t;
+      if (i < a.n) {
+        const float su = au[t].x + au[t].y, sw = aw[t].x + aw[t].y;
+        fx_add(&a.acc_u[i], su, fxs); fx_add(&a.acc_w[i], sw, fxs);
+        chk += su + sw;
+      }
+    }
+  } else {
+    auto& rb = red[per & 1];
+#pragma unroll
+    for (int t = 0; t < T; ++t) { rb[wv][2 * t][lane] = au[t].x + au[t].y; rb[wv][2 * t + 1][lane] = aw[t].x + aw[t].y; }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < 2 * T; ++c) {
+        if (c % R != r) continue;
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < R; ++q) v += rb[w0 + q][c][lane];
+        const long long i = I * W + lane + 64LL * (c / 2);
+        if (i < a.n) { fx_add((c & 1) ? &a.acc_w[i] : &a.acc_u[i], v, fxs); chk += v; }
+      }
     }
   }
   if (!(__builtin_fabsf(chk) < __builtin_inff())) atomicAdd(reinterpret_cast<unsigned long long*>(a.bad), 1ULL);
@@ -359,21 +432,51 @@ __device__ __forceinline__ void sym_scale_from_sum(double sum_abs, double vc4, S
   out->inv = ldexp(1.0, -k);
 }
 
-__global__ void __launch_bounds__(kPrepBlock)
-sym_prepare(const float* g, long long n, double vc4, SymScale* out, long long* bad) {
+// sum |g| over [first, first + count) by one workgroup, in a fixed order: 8 independent running sums per thread
+// (8 loads in flight), a fixed shuffle tree per wavefront, the wave partials in order.  Every thread returns it.
+__device__ __forceinline__ double block_abs_sum(const float* g, long long first, long long count) {
   __shared__ double part[kPrepBlock / 64];
-  double s = 0.0;
-  for (long long i = threadIdx.x; i < n; i += kPrepBlock) s += (double)__builtin_fabsf(g[i]);
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long end = first + count;
+  long long i = first + threadIdx.x;
+  for (; i + 7 * kPrepBlock < end; i += 8 * kPrepBlock) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int w = 0; w < kPrepBlock / 64; ++w) tot += part[w];
-    *bad = 0;
-    sym_scale_from_sum(tot, vc4, out, bad);
+    for (int k = 0; k < 8; ++k) s[k] += (double)__builtin_fabsf(g[i + k * kPrepBlock]);
   }
+  for (int k = 0; i < end; i += kPrepBlock, ++k) s[k & 7] += (double)__builtin_fabsf(g[i]);
+  double t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+  __syncthreads();
+  double tot = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += part[w];
+  return tot;
+}
+
+// Fixed-point scale of a launch from sum |Gamma|.  Up to kPrepChunk vortices: one workgroup does it all.  Beyond:
+// gridDim.x workgroups each sum a contiguous chunk into partial[blockIdx.x] and sym_prepare_final adds those in order.
+constexpr long long kPrepChunk = 65536;
+__global__ void __launch_bounds__(kPrepBlock)
+sym_prepare(const float* g, long long n, double vc4, SymScale* out, long long* bad, double* partial) {
+  if (gridDim.x == 1) {
+    const double tot = block_abs_sum(g, 0, n);
+    if (threadIdx.x == 0) { *bad = 0; sym_scale_from_sum(tot, vc4, out, bad); }
+    return;
+  }
+  const long long first = (long long)blockIdx.x * kPrepChunk;
+  const long long cnt = n - first < kPrepChunk ? n - first : kPrepChunk;
+  const double tot = block_abs_sum(g, first, cnt);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(64)
+sym_prepare_final(const double* partial, int nparts, double vc4, SymScale* out, long long* bad) {
+  if (threadIdx.x != 0) return;
+  double tot = 0.0;
+  for (int k = 0; k < nparts; ++k) tot += partial[k];
+  *bad = 0;
+  sym_scale_from_sum(tot, vc4, out, bad);
 }
 
 // fixed-point raw sum -> fp32 raw sum (NaN when the launch met a non-finite partial sum)

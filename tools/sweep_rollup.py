@@ -1,0 +1,39 @@
+"""One roll-up step of the resident wake (ludvm_wake_advect: pair kernel + Euler finisher, no host read-back) over the
+wake size, per precision and kernel: microseconds per step.  Run on the GPU box.
+    python tools/sweep_rollup.py [sizes...]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ludvm_amd import Engine  # noqa: E402
+
+eng = Engine(0)
+if os.environ.get("SYM_T"):
+    eng.set_sym_tuning(int(os.environ["SYM_T"]), int(os.environ.get("SYM_R", "0")))
+rng = np.random.default_rng(1)
+sizes = [int(a) for a in sys.argv[1:]] or [8192, 11264, 12288, 14336, 16384, 20480, 24576, 32768, 40960, 49152, 65536]
+fx, fz, fg = np.linspace(-30.9, -30.0, 80), np.zeros(80), rng.standard_normal(80) / 100
+for n in sizes:
+    x = -30.0 + np.sort(rng.uniform(0, 1e-3 * n, n))
+    z = 0.3 * np.sin(0.7 * x) + 1e-3 * rng.standard_normal(n)
+    g = rng.standard_normal(n) * 1e-3
+    res = {"n": n}
+    for mode, mname in ((2, "sym"), (0, "direct")):
+        eng.set_symmetric(mode)
+        for prec in ("f32", "f32x2"):
+            eng.wake_clear()
+            eng.wake_append(x, z, g)
+            reps = max(5, min(300, int(4e10 / (n * n))))
+            for _ in range(3):
+                eng.wake_advect(1e-6, fx, fz, fg, 1.3e-3, precision=prec)
+            eng.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.wake_advect(1e-6, fx, fz, fg, 1.3e-3, precision=prec)
+            eng.synchronize()
+            res[f"{mname}_{prec}_us"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+    print(json.dumps(res), flush=True)
