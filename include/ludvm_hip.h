@@ -90,6 +90,23 @@ int ludvm_set_symmetric(ludvm_ctx* ctx, int mode);
  * rotation steps of one tile pair.  Results change only through the partition into fp32 partial sums. */
 int ludvm_set_sym_tuning(ludvm_ctx* ctx, int vortices_per_lane, int rotation_split);
 
+/* Sharding ONE simulation's roll-up over several GPUs (LUDVM.time_loop, LUDVM.py:1095-1127, with a wake too large
+ * for one GPU to be quick about).  Every GPU holds the whole wake and runs the whole time loop -- chord sums, solve,
+ * Euler step: everything that is O(N) or smaller -- but evaluates only tile block `rank` of `world` of the symmetric
+ * kernel's unordered pairs, accumulating into d_acc (caller-owned device memory, e.g. a torch int64 tensor; at
+ * least 16 (wake capacity + 64) + 16 bytes).  Before each Euler finisher the library calls
+ *     allreduce(user, d_buf, count, hip_stream)
+ * which must enqueue, on hip_stream, an in-place SUM all-reduce of the `count` 64-bit integers at d_buf (a prefix of
+ * d_acc) over all owners, and return 0 (e.g. torch.distributed.all_reduce on RCCL).  Integer sums commute, so every
+ * owner reads the same bits -- those one GPU owning all tiles would have produced -- and the replicated state cannot
+ * drift apart.  Roll-ups of fewer than min_vortices vortices (a collective per step costs more than it saves there;
+ * ~1e5 on xGMI) are done whole by every owner, without the hook.  world == 1 restores the unsharded behaviour.  On a
+ * sharded context every symmetric launch of min_vortices or more is collective: all owners must issue the same calls
+ * in the same order. */
+typedef int (*ludvm_allreduce_fn)(void* user, void* d_buf, size_t count, void* hip_stream);
+int ludvm_set_shard(ludvm_ctx* ctx, int rank, int world, size_t min_vortices, ludvm_allreduce_fn allreduce, void* user,
+                    void* d_acc, size_t acc_bytes);
+
 /* ---- stateless pair sum: backs LUDVM.induced_velocity (LUDVM.py:549-570) ------------------ */
 
 /* u[p] =  sum_w g[w]*(zt[p]-zs[w]) / (2 pi sqrt(r^4 + vcore^4))
@@ -268,6 +285,13 @@ int ludvm_flowfield_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, siz
 int ludvm_flowfield_vorticity_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz,
                                   const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
                                   float* u, float* w, float* ome);
+/* Rows [row_first, row_first + row_count) of that nx x nz grid only -- the same numbers, bit for bit, that the
+ * whole-grid call returns for them (the grid coordinates are generated from the global row index; with ome wanted,
+ * one halo row per interior side is evaluated internally).  Outputs are row_count * nz each.  This is the unit a
+ * multi-GPU flow field shards by: each GPU evaluates a block of rows, nothing is exchanged. */
+int ludvm_flowfield_rows_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz, size_t row_first,
+                             size_t row_count, const double* xs, const double* zs, const double* gs, size_t ns,
+                             double vcore, float* u, float* w, float* ome);
 /* Same as ludvm_flowfield_f32, device-resident fp32 sources and outputs (asynchronous). */
 int ludvm_flowfield_dev_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz,
                             const float* d_xs, const float* d_zs, const float* d_gs, size_t ns, float vcore,

@@ -32,6 +32,7 @@ SIGNATURES = {
     "ludvm_synchronize": [c_void_p],
     "ludvm_set_tuning": [c_void_p, c_int, c_int],
     "ludvm_set_symmetric": [c_void_p, c_int],
+    "ludvm_set_shard": [c_void_p, c_int, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t],
     "ludvm_set_sym_tuning": [c_void_p, c_int, c_int],
     "ludvm_induce_f64": [c_void_p, _pd, _pd, _pd, c_size_t, _pd, _pd, c_size_t, c_double, c_int, _pd, _pd],
     "ludvm_induce_f32": [c_void_p, _pf, _pf, _pf, c_size_t, _pf, _pf, c_size_t, c_float, _pf, _pf],
@@ -64,6 +65,8 @@ SIGNATURES = {
                             c_double, _pf, _pf],
     "ludvm_flowfield_vorticity_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, _pd, _pd, _pd, c_size_t,
                                       c_double, _pf, _pf, _pf],
+    "ludvm_flowfield_rows_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, c_size_t, c_size_t, _pd, _pd, _pd,
+                                 c_size_t, c_double, _pf, _pf, _pf],
     "ludvm_flowfield_dev_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_float, c_void_p, c_void_p],
     "ludvm_vorticity_f32": [c_void_p, _pf, _pf, c_size_t, c_size_t, c_double, _pf],
@@ -71,6 +74,8 @@ SIGNATURES = {
     "ludvm_kernel_timing": [c_void_p, c_int],
     "ludvm_kernel_time_ms": [c_void_p, c_int, POINTER(c_double), POINTER(c_longlong)],
 }
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_void_p)
 
 _lib = None
 

@@ -41,6 +41,7 @@ struct ludvm_ctx {
   int tune_split = 0;
   int sym_mode = 1;
   int tune_sym_t = 0, tune_sym_rsplit = 0;   // ludvm_set_sym_tuning (0 = heuristics)
+  int grid_kernel = 2;                       // flow-field grids: 2 = 2 x 4 patch per lane, 1 = 4 points of a row (LUDVM_GRID_KERNEL)
   long long small_tile_max = 14000;          // direct fp32 launches with at most this many sources use 256-source tiles
   long long small_tile_max_f64 = 12000;      // fp64 launches with at most this many sources use 128-source tiles
                                              // (roll-up step 52 -> 26 us at 2400 vortices, 87 -> 72 at 8192 [MI355X])
@@ -72,6 +73,15 @@ struct ludvm_ctx {
   hipEvent_t march_ev[2] = {nullptr, nullptr};
   hipStream_t stream_b = nullptr;              // the solve chain beside the roll-up (overlapped march steps)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
+  // sharded roll-up (ludvm_set_shard): this context evaluates tile block `shard_rank` of `shard_world`; the hook sums
+  // the fixed-point accumulators over the contexts / processes before every Euler finisher
+  int shard_rank = 0, shard_world = 1;
+  long long shard_min_n = 0;    // wakes smaller than this are not worth a collective per step: every owner does them whole
+  ludvm_allreduce_fn reduce_hook = nullptr;
+  void* reduce_user = nullptr;
+  void* ext_acc = nullptr;      // caller-owned accumulator memory (e.g. a torch tensor the hook all-reduces)
+  size_t ext_acc_bytes = 0;
 
   // kernel timing
   bool timing = false;
@@ -253,6 +263,15 @@ int drain_timing(ludvm_ctx* c) {
   return LUDVM_OK;
 }
 
+// workgroups of a flow-field grid launch: 256 lanes of 4 row points, or of 2 x 4 patches
+long long grid_kernel_blocks(const ludvm_ctx* c, const PairArgs& a) {
+  if (c->grid_kernel == 2) {
+    const long long nrows = a.nt / a.grid_nz, patches = ((nrows + 1) / 2) * (a.grid_nz / 4);
+    return (patches + kBlock - 1) / kBlock;
+  }
+  return (a.nt + (long long)kBlock * 4 - 1) / ((long long)kBlock * 4);
+}
+
 // Launch the main pair kernel described by `a` (sources, targets and vc4 filled in by the caller)
 // under plan `p`; a.part / a.u / a.w / a.nt_pad / a.chunk are completed here.  With more than one
 // split the results are left in c->part for a finisher; with one split they go to (u, w).
@@ -285,19 +304,22 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
   } else if (a.scx != nullptr) {
     // local-origin fp32 (LUDVM_PREC_F32 wherever the library lays the positions out itself)
     if (a.grid_nz > 0 && a.grid_nz % 4 == 0 && c->tune_tpl == 0) {
-      const long long ttiles = (a.nt + (long long)kBlock * 4 - 1) / ((long long)kBlock * 4);
-      grid = dim3((unsigned)ttiles, grid.y, 1);
-      if (p.tile == kTileF32Small)
-        hipLaunchKernelGGL((pair_f32<4, kTileF32Small, false, true, true>), grid, dim3(kBlock), 0, c->stream, a);
-      else
-        hipLaunchKernelGGL((pair_f32<4, kTileF32, false, true, true>), grid, dim3(kBlock), 0, c->stream, a);
+      // flow-field grid: a 2 x 4 patch (or 4 points of a row) per lane; the plan's grid is recomputed for it
+      grid = dim3((unsigned)grid_kernel_blocks(c, a), grid.y, 1);
+      if (c->grid_kernel == 2) {
+        if (p.tile == kTileF32Small) hipLaunchKernelGGL((pair_f32<8, kTileF32Small, false, 2, true>), grid, dim3(kBlock), 0, c->stream, a);
+        else hipLaunchKernelGGL((pair_f32<8, kTileF32, false, 2, true>), grid, dim3(kBlock), 0, c->stream, a);
+      } else {
+        if (p.tile == kTileF32Small) hipLaunchKernelGGL((pair_f32<4, kTileF32Small, false, 1, true>), grid, dim3(kBlock), 0, c->stream, a);
+        else hipLaunchKernelGGL((pair_f32<4, kTileF32, false, 1, true>), grid, dim3(kBlock), 0, c->stream, a);
+      }
     } else if (p.tile == kTileF32Small) {
-      hipLaunchKernelGGL((pair_f32<1, kTileF32Small, false, false, true>), grid, dim3(kBlock), 0, c->stream, a);
+      hipLaunchKernelGGL((pair_f32<1, kTileF32Small, false, 0, true>), grid, dim3(kBlock), 0, c->stream, a);
     } else {
       switch (p.tpl) {
-        case 1: hipLaunchKernelGGL((pair_f32<1, kTileF32, false, false, true>), grid, dim3(kBlock), 0, c->stream, a); break;
-        case 2: hipLaunchKernelGGL((pair_f32<2, kTileF32, false, false, true>), grid, dim3(kBlock), 0, c->stream, a); break;
-        default: hipLaunchKernelGGL((pair_f32<4, kTileF32, false, false, true>), grid, dim3(kBlock), 0, c->stream, a); break;
+        case 1: hipLaunchKernelGGL((pair_f32<1, kTileF32, false, 0, true>), grid, dim3(kBlock), 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL((pair_f32<2, kTileF32, false, 0, true>), grid, dim3(kBlock), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL((pair_f32<4, kTileF32, false, 0, true>), grid, dim3(kBlock), 0, c->stream, a); break;
       }
     }
   } else if (p.tile == kTileF32Small && !(a.grid_nz > 0)) {
@@ -312,14 +334,15 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
       default: hipLaunchKernelGGL((pair_f32<4, kTileF32, true>), grid, dim3(kBlock), 0, c->stream, a); break;
     }
   } else if (a.grid_nz > 0 && a.grid_nz % 4 == 0 && c->tune_tpl == 0) {
-    // flow-field grid: 4 consecutive points of a row per lane (shared dx); same target count per block
-    // as TPL = 4, so the plan's grid is recomputed for it
-    const long long ttiles = (a.nt + (long long)kBlock * 4 - 1) / ((long long)kBlock * 4);
-    grid = dim3((unsigned)ttiles, grid.y, 1);
-    if (p.tile == kTileF32Small)
-      hipLaunchKernelGGL((pair_f32<4, kTileF32Small, false, true>), grid, dim3(kBlock), 0, c->stream, a);
-    else
-      hipLaunchKernelGGL((pair_f32<4, kTileF32, false, true>), grid, dim3(kBlock), 0, c->stream, a);
+    // flow-field grid: a 2 x 4 patch (or 4 points of a row) per lane; the plan's grid is recomputed for it
+    grid = dim3((unsigned)grid_kernel_blocks(c, a), grid.y, 1);
+    if (c->grid_kernel == 2) {
+      if (p.tile == kTileF32Small) hipLaunchKernelGGL((pair_f32<8, kTileF32Small, false, 2>), grid, dim3(kBlock), 0, c->stream, a);
+      else hipLaunchKernelGGL((pair_f32<8, kTileF32, false, 2>), grid, dim3(kBlock), 0, c->stream, a);
+    } else {
+      if (p.tile == kTileF32Small) hipLaunchKernelGGL((pair_f32<4, kTileF32Small, false, 1>), grid, dim3(kBlock), 0, c->stream, a);
+      else hipLaunchKernelGGL((pair_f32<4, kTileF32, false, 1>), grid, dim3(kBlock), 0, c->stream, a);
+    }
   } else {
     switch (p.tpl) {
       case 1: hipLaunchKernelGGL((pair_f32<1, kTileF32, false>), grid, dim3(kBlock), 0, c->stream, a); break;
@@ -400,7 +423,7 @@ struct SymOperands {
 // is a function of n and T alone (sym_geometry).  n_dev (march): the vortex count is read on the device; it lies in
 // [n_lo, n], and the grid is sized for the largest wave count any such n needs.
 int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, long long i_first, long long i_count, double vc4,
-                     const long long* n_dev = nullptr, long long n_lo = 0) {
+                     const long long* n_dev = nullptr, long long n_lo = 0, bool sharded = false) {
   SymArgs a{};
   a.x = o.x; a.z = o.z; a.g = o.g; a.n = n;
   a.n_dev = n_dev;
@@ -410,6 +433,8 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   if (hilo) T = 4;
   a.tune_split = c->tune_split;
   a.tune_rsplit = c->tune_sym_rsplit;
+  a.shard_rank = (n_dev && sharded) ? c->shard_rank : 0;       // (host-sized launches get their tile block as arguments)
+  a.shard_world = (n_dev && sharded) ? c->shard_world : 1;
   const SymGeom gm = sym_geometry(n, T, a.tune_split, a.tune_rsplit);
   a.ntiles = gm.ntiles;
   a.dmax = gm.dmax;
@@ -432,6 +457,8 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
       blocks = std::max(blocks, blocks_of(q.ntiles * q.ysplit, gm.rsplit));
     }
   }
+  if (!n_dev && i_count == 0) return LUDVM_OK;     // an owner without tiles (fewer tiles than owners)
+  blocks = std::max<long long>(blocks, 1);         // (n_dev: the share is decided on the device; surplus waves leave)
   TimedLaunch t{};
   bool active = false;
   CHK(timed_begin(c, t, active));
@@ -450,6 +477,37 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   HIPCHK(c, hipGetLastError());
   CHK(timed_end(c, t, active));
   return LUDVM_OK;
+}
+
+// The symmetric kernel's accumulators: [2 NaN counters | acc_u nt_pad | acc_w nt_pad] 64-bit integers, in the context's
+// own buffer or in the caller's (ludvm_set_shard).  *acc points at acc_u; the counters sit at acc[-2], acc[-1].
+int acc_buffer(ludvm_ctx* c, long long nt_pad, long long** acc) {
+  const size_t bytes = ((size_t)2 * (size_t)nt_pad + 2) * sizeof(long long);
+  if (c->ext_acc) {
+    if (bytes > c->ext_acc_bytes) return fail(c, LUDVM_E_NOMEM, "the accumulator buffer given to ludvm_set_shard is too small");
+    *acc = static_cast<long long*>(c->ext_acc) + 2;
+    return LUDVM_OK;
+  }
+  CHK(ensure(c, c->acc, bytes));
+  *acc = static_cast<long long*>(c->acc.p) + 2;
+  return LUDVM_OK;
+}
+
+// Sum the accumulators (and their NaN counters) over all owners, in place and stream-ordered, before they are read.
+bool sharded_at(const ludvm_ctx* c, long long n) { return c->shard_world > 1 && n >= c->shard_min_n; }
+
+int reduce_accumulators(ludvm_ctx* c, long long* acc, long long nt_pad) {
+  if (c->shard_world <= 1) return LUDVM_OK;
+  if (!c->reduce_hook) return fail(c, LUDVM_E_STATE, "sharded roll-up without an all-reduce hook");
+  const int rc = c->reduce_hook(c->reduce_user, acc - 2, (size_t)(2 * nt_pad + 2), c->stream);
+  if (rc != 0) return fail(c, LUDVM_E_STATE, "the all-reduce hook reported a failure");
+  return LUDVM_OK;
+}
+
+// tile block of a shard owner
+void shard_tiles(const ludvm_ctx* c, long long ntiles, long long* first, long long* count) {
+  *first = ntiles * c->shard_rank / c->shard_world;
+  *count = ntiles * (c->shard_rank + 1) / c->shard_world - *first;
 }
 
 SymScale* ctx_scale(ludvm_ctx* c) { return static_cast<SymScale*>(c->symsc.p); }
@@ -474,13 +532,13 @@ int launch_sym_prepare(ludvm_ctx* c, const float* g, long long n, double vc4, Sy
 // Symmetric self-interaction of all of (x, z, g)[0, n) with the context's accumulators: zero them, derive the
 // fixed-point scale from sum|Gamma| (unless the caller -- the march -- maintains it: scale / bad given), run the
 // kernel.  The raw sums are left in c->acc as [acc_u | acc_w], each nt_pad 64-bit integers.
-int launch_sym(ludvm_ctx* c, SymOperands o, long long n, double vc4, long long* nt_pad_out, const long long* n_dev = nullptr,
-               long long n_lo = 0) {
+int launch_sym(ludvm_ctx* c, SymOperands o, long long n, double vc4, long long* nt_pad_out, const long long** acc_out,
+               const long long** bad_out, const long long* n_dev = nullptr, long long n_lo = 0) {
   const long long nt_pad = (n + 63) / 64 * 64;
-  CHK(ensure(c, c->acc, (size_t)2 * (size_t)nt_pad * sizeof(long long)));
+  long long* acc = nullptr;
+  CHK(acc_buffer(c, nt_pad, &acc));
   CHK(ensure(c, c->symsc, 128 + (size_t)((n + kPrepChunk - 1) / kPrepChunk) * sizeof(double)));
-  HIPCHK(c, hipMemsetAsync(c->acc.p, 0, (size_t)2 * (size_t)nt_pad * sizeof(long long), c->stream));
-  long long* acc = static_cast<long long*>(c->acc.p);
+  HIPCHK(c, hipMemsetAsync(acc - 2, 0, ((size_t)2 * (size_t)nt_pad + 2) * sizeof(long long), c->stream));
   o.acc_u = acc;
   o.acc_w = acc + nt_pad;
   if (!o.scale) {
@@ -488,10 +546,17 @@ int launch_sym(ludvm_ctx* c, SymOperands o, long long n, double vc4, long long* 
     o.scale = ctx_scale(c);
     o.bad = ctx_bad(c);
   }
+  const bool sharded = sharded_at(c, n);      // (n: exact, or the march's bound -- the same number on every owner)
+  if (sharded) o.bad = acc - 2;               // counted where the all-reduce sees it
   const int T = sym_tile_t(c, n, o.xl && o.zl, o.cx != nullptr);
   const long long ntiles = (n + 64LL * T - 1) / (64LL * T);
-  CHK(launch_sym_tiles(c, T, o, n, 0, ntiles, vc4, n_dev, n_lo));
+  long long first = 0, count = ntiles;
+  if (sharded) shard_tiles(c, ntiles, &first, &count);
+  CHK(launch_sym_tiles(c, T, o, n, first, count, vc4, n_dev, n_lo, sharded));
+  if (sharded) CHK(reduce_accumulators(c, acc, nt_pad));
   *nt_pad_out = nt_pad;
+  *acc_out = acc;
+  *bad_out = o.bad;
   return LUDVM_OK;
 }
 
@@ -572,6 +637,7 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
     return LUDVM_E_HIP;
   }
   c->stream = c->own_stream;
+  if (const char* gk = std::getenv("LUDVM_GRID_KERNEL")) c->grid_kernel = (gk[0] == 'r' || gk[0] == '1') ? 1 : 2;
   if (small_env) { c->small_tile_max = std::atoll(small_env); c->small_tile_max_f64 = std::min<long long>(c->small_tile_max, 12000); }
   const char* small64_env = std::getenv("LUDVM_SMALL_TILE_MAX_F64");
   if (small64_env) c->small_tile_max_f64 = std::atoll(small64_env);
@@ -652,6 +718,23 @@ int ludvm_set_sym_tuning(ludvm_ctx* c, int vortices_per_lane, int rotation_split
     return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (heuristic), 1, 2 or 4");
   c->tune_sym_t = vortices_per_lane;
   c->tune_sym_rsplit = rotation_split;
+  return LUDVM_OK;
+}
+
+int ludvm_set_shard(ludvm_ctx* c, int rank, int world, size_t min_vortices, ludvm_allreduce_fn allreduce, void* user,
+                    void* d_acc, size_t acc_bytes) {
+  if (!c) return LUDVM_E_ARG;
+  if (world < 1 || rank < 0 || rank >= world) return fail(c, LUDVM_E_ARG, "shard: need 0 <= rank < world");
+  if (world > 1 && (!allreduce || !d_acc || acc_bytes < 64)) return fail(c, LUDVM_E_ARG, "shard: world > 1 needs a hook and an accumulator buffer");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->shard_rank = rank;
+  c->shard_world = world;
+  c->shard_min_n = (long long)min_vortices;
+  c->reduce_hook = world > 1 ? allreduce : nullptr;
+  c->reduce_user = user;
+  c->ext_acc = world > 1 ? d_acc : nullptr;
+  c->ext_acc_bytes = world > 1 ? acc_bytes : 0;
   return LUDVM_OK;
 }
 
@@ -749,10 +832,10 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
       SymOperands o{};
       o.x = fxs; o.z = fzs; o.g = fgs;
       if (hilo) { o.xl = fxsl; o.zl = fzsl; } else { o.cx = sox; o.cz = soz; }
-      CHK(launch_sym(c, o, (long long)ns, a.vc4, &nt_pad));
-      const long long* acc = static_cast<const long long*>(c->acc.p);
+      const long long *acc = nullptr, *bad = nullptr;
+      CHK(launch_sym(c, o, (long long)ns, a.vc4, &nt_pad, &acc, &bad));
       hipLaunchKernelGGL(finish_sym, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, ctx_scale(c),
-                         ctx_bad(c), (long long)nt, fu, fw);
+                         bad, (long long)nt, fu, fw);
       HIPCHK(c, hipGetLastError());
     } else {
       a.xs = fxs; a.zs = fzs; a.gs = fgs;
@@ -827,10 +910,10 @@ int ludvm_induce_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, con
     long long nt_pad = 0;
     SymOperands o{};
     o.x = d_xs; o.z = d_zs; o.g = d_gs;
-    CHK(launch_sym(c, o, (long long)ns, v2 * v2, &nt_pad));
-    const long long* acc = static_cast<const long long*>(c->acc.p);
+    const long long *acc = nullptr, *bad = nullptr;
+    CHK(launch_sym(c, o, (long long)ns, v2 * v2, &nt_pad, &acc, &bad));
     hipLaunchKernelGGL(finish_sym, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad, ctx_scale(c),
-                       ctx_bad(c), (long long)nt, d_u, d_w);
+                       bad, (long long)nt, d_u, d_w);
     HIPCHK(c, hipGetLastError());
     return LUDVM_OK;
   }
@@ -853,10 +936,10 @@ int ludvm_advect_dev_f32(ludvm_ctx* c, const float* d_xs, const float* d_zs, con
     long long nt_pad = 0;
     SymOperands o{};
     o.x = d_xs; o.z = d_zs; o.g = d_gs;
-    CHK(launch_sym(c, o, (long long)ns, v2 * v2, &nt_pad));
-    const long long* acc = static_cast<const long long*>(c->acc.p);
+    const long long *acc = nullptr, *bad = nullptr;
+    CHK(launch_sym(c, o, (long long)ns, v2 * v2, &nt_pad, &acc, &bad));
     hipLaunchKernelGGL(finish_sym_advect, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, acc, acc + nt_pad,
-                       ctx_scale(c), ctx_bad(c), d_xs, d_zs, 0LL, (long long)nt, dt, d_x_out, d_z_out);
+                       ctx_scale(c), bad, d_xs, d_zs, 0LL, (long long)nt, dt, d_x_out, d_z_out);
     HIPCHK(c, hipGetLastError());
     return LUDVM_OK;
   }
@@ -1117,10 +1200,10 @@ static int advect_launch(ludvm_ctx* c, size_t n, const long long* n_dev, double 
     if (hilo) { o.x = c->xh; o.z = c->zh; o.xl = c->xl; o.zl = c->zl; }
     else { o.x = c->xr; o.z = c->zr; o.cx = c->cx; o.cz = c->cz; }
     o.scale = ms.scale; o.bad = ms.bad;
-    CHK(launch_sym(c, o, nt, v2 * v2, &nt_pad, n_dev, ms.n_lo));
-    const long long* acc = static_cast<const long long*>(c->acc.p);
+    const long long *acc = nullptr, *bad = nullptr;
+    CHK(launch_sym(c, o, nt, v2 * v2, &nt_pad, &acc, &bad, n_dev, ms.n_lo));
     hipLaunchKernelGGL(finish_wake_advect_sym, dim3(fin_blocks(nt)), dim3(kFinBlock), 0, c->stream, acc, acc + nt_pad,
-                       ms.scale ? ms.scale : ctx_scale(c), ms.bad ? ms.bad : ctx_bad(c), nt, (int)nfoil, (float)(v2 * v2), dt,
+                       ms.scale ? ms.scale : ctx_scale(c), bad, nt, (int)nfoil, (float)(v2 * v2), dt,
                        c->x64, c->z64, c->mir(), c->g32, du, dw, n_dev, td);
     HIPCHK(c, hipGetLastError());
     return LUDVM_OK;
@@ -1393,7 +1476,9 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
     march_workspace(c, n0 + 2 * k, precision, nfoil, part_bytes, acc_bytes);
   march_workspace(c, n0 + 2 * count, precision, nfoil, part_bytes, acc_bytes);
   CHK(ensure(c, c->part, part_bytes + (1 << 20)));
-  if (acc_bytes) CHK(ensure(c, c->acc, acc_bytes + (1 << 20)));
+  if (acc_bytes && !c->ext_acc) CHK(ensure(c, c->acc, acc_bytes + (1 << 20)));
+  if (acc_bytes && c->ext_acc && acc_bytes + 16 > c->ext_acc_bytes)
+    return fail(c, LUDVM_E_NOMEM, "march: the accumulator buffer given to ludvm_set_shard is too small for this stretch");
   CHK(ensure(c, c->symsc, 128));
   CHK(ensure(c, c->march_rows, (size_t)count * row_doubles * 8));
   if (hist) CHK(ensure(c, c->march_hist, (size_t)count * 2 * hist_nmax * 8));
@@ -1486,9 +1571,13 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
       // while chord sums and solve run on the second one; they meet at the Euler finisher
       const bool hilo = precision == LUDVM_PREC_F32X2;
       const long long nt_pad = (n_ub + 63) / 64 * 64;
-      long long* acc = static_cast<long long*>(c->acc.p);
+      long long* acc = nullptr;
+      CHK(acc_buffer(c, nt_pad, &acc));
+      const bool sharded = sharded_at(c, n_ub);
       if (!overlapped) {
-        HIPCHK(c, hipMemsetAsync(c->acc.p, 0, c->acc.cap, c->stream));   // march_finish_sym re-zeroes what it reads
+        // (march_finish_sym re-zeroes what it reads, so once is enough)
+        const size_t all = c->ext_acc ? c->ext_acc_bytes : c->acc.cap;
+        HIPCHK(c, hipMemsetAsync(acc - 2, 0, all, c->stream));
         overlapped = true;
       }
       HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
@@ -1511,11 +1600,20 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
       if (hilo) { o.x = c->xh; o.z = c->zh; o.xl = c->xl; o.zl = c->zl; }
       else { o.x = c->xr; o.z = c->zr; o.cx = c->cx; o.cz = c->cz; }
       o.acc_u = acc; o.acc_w = acc + nt_pad;
-      o.scale = &S->sc[s & 1]; o.bad = &S->sym_bad;
-      CHK(launch_sym_tiles(c, T, o, nb, 0, ntiles, vc4, &S->n_old[s & 1], n_lo));
+      o.scale = &S->sc[s & 1];
+      // sharded: this step's NaN counter travels with the sums through the all-reduce (two slots by step parity: the
+      // finisher clears the next step's while blocks of its own launch may still read this step's)
+      long long* bad_step = sharded ? acc - 2 + (s & 1) : nullptr;
+      long long* bad_next = sharded ? acc - 2 + ((s + 1) & 1) : nullptr;
+      o.bad = sharded ? bad_step : &S->sym_bad;
+      long long first = 0, cnt = ntiles;
+      if (sharded) shard_tiles(c, ntiles, &first, &cnt);
+      CHK(launch_sym_tiles(c, T, o, nb, first, cnt, vc4, &S->n_old[s & 1], n_lo, sharded));
+      if (sharded) CHK(reduce_accumulators(c, acc, nt_pad));
       HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
       hipLaunchKernelGGL(march_finish_sym, dim3(fin_blocks(n_ub)), dim3(kFinBlock), 0, c->stream, acc, acc + nt_pad,
-                         &S->sc[s & 1], S, &S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->mir(), c->g32, td);
+                         &S->sc[s & 1], S, &S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->mir(), c->g32, td,
+                         bad_step, bad_next);
       HIPCHK(c, hipGetLastError());
     }
     n_before = n_ub;
@@ -1594,17 +1692,28 @@ static size_t flowfield_upload_bytes(size_t ns) {
 
 int ludvm_flowfield_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, const double* xs,
                         const double* zs, const double* gs, size_t ns, double vcore, float* u, float* w) {
-  return ludvm_flowfield_vorticity_f32(c, xmin, zmin, dr, nx, nz, xs, zs, gs, ns, vcore, u, w, nullptr);
+  return ludvm_flowfield_rows_f32(c, xmin, zmin, dr, nx, nz, 0, nx, xs, zs, gs, ns, vcore, u, w, nullptr);
 }
 
 int ludvm_flowfield_vorticity_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, const double* xs,
                                   const double* zs, const double* gs, size_t ns, double vcore, float* u, float* w, float* ome) {
+  return ludvm_flowfield_rows_f32(c, xmin, zmin, dr, nx, nz, 0, nx, xs, zs, gs, ns, vcore, u, w, ome);
+}
+
+int ludvm_flowfield_rows_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, size_t row_first,
+                             size_t row_count, const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
+                             float* u, float* w, float* ome) {
   if (!c) return LUDVM_E_ARG;
-  const size_t nt = nx * nz;
-  if (nt == 0) return LUDVM_OK;
+  if (row_first + row_count > nx) return fail(c, LUDVM_E_ARG, "rows outside the grid");
+  if (row_count == 0 || nz == 0) return LUDVM_OK;
   if ((ns && (!xs || !zs || !gs)) || !u || !w) return fail(c, LUDVM_E_ARG, "null array");
   if (ome && (nx < 2 || nz < 2)) return fail(c, LUDVM_E_ARG, "vorticity needs nx, nz >= 2");
   HIPCHK(c, hipSetDevice(c->device));
+  // with the vorticity wanted, one halo row on each interior side: the centred differences of the block's edge rows
+  // then need nothing from the rows' other owners (LUDVM.py:1224-1292 keeps one-sided forms for the grid's own edges)
+  const size_t h0 = ome && row_first > 0 ? row_first - 1 : row_first;
+  const size_t h1 = ome && row_first + row_count < nx ? row_first + row_count + 1 : row_first + row_count;
+  const size_t rows = h1 - h0, nt = rows * nz;
   CHK(ensure(c, c->arena, flowfield_upload_bytes(ns) + 3 * Arena::need(nt, 4)));
   Arena ar(c->arena.p);
   float* du = ar.take<float>(nt);
@@ -1618,16 +1727,18 @@ int ludvm_flowfield_vorticity_f32(ludvm_ctx* c, double xmin, double zmin, double
     CHK(flowfield_upload_local(c, ar, xs, zs, gs, ns, a));
     a.nt = (long long)nt;
     a.grid_nz = (long long)nz;
+    a.grid_row0 = (long long)h0;
     a.xmin = xmin; a.zmin = zmin; a.dr = dr;
     const double v2 = vcore * vcore;
     a.vc4 = v2 * v2;
     CHK(induce_device(c, a, a.nt, a.ns, LUDVM_PREC_F32, du, dw));
   }
   // velocity and vorticity leave the device together: the stencil (LUDVM.py:1224-1292) runs on the fields where they are
-  if (ome) CHK(ludvm_vorticity_dev_f32(c, du, dw, nx, nz, (float)dr, dome));
-  HIPCHK(c, hipMemcpyAsync(u, du, nt * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(w, dw, nt * 4, hipMemcpyDeviceToHost, c->stream));
-  if (ome) HIPCHK(c, hipMemcpyAsync(ome, dome, nt * 4, hipMemcpyDeviceToHost, c->stream));
+  if (ome) CHK(ludvm_vorticity_dev_f32(c, du, dw, rows, nz, (float)dr, dome));
+  const size_t off = (row_first - h0) * nz, cnt = row_count * nz;
+  HIPCHK(c, hipMemcpyAsync(u, du + off, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(w, dw + off, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+  if (ome) HIPCHK(c, hipMemcpyAsync(ome, dome + off, cnt * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LUDVM_OK;
 }

@@ -461,9 +461,13 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
 // velocities march_solve left in S->newvel.  The raw sums are zeroed after use, so the accumulators need no memset
 // between steps.  One workgroup = one origin block (see finish_wake_advect).
 __global__ void __launch_bounds__(kFinBlock)
-march_finish_sym(long long* acc_u, long long* acc_w, const SymScale* sc, const MarchState* S, const long long* n_old_p,
-                 int nfoil, float vc4, double dt, double* x64, double* z64, Mirrors m, const float* g32, TailDuty td) {
+march_finish_sym(long long* acc_u, long long* acc_w, const SymScale* sc, MarchState* S, const long long* n_old_p,
+                 int nfoil, float vc4, double dt, double* x64, double* z64, Mirrors m, const float* g32, TailDuty td,
+                 long long* bad_step = nullptr, long long* bad_next = nullptr) {
+  // bad_step / bad_next (sharded roll-up): this step's count of non-finite partial sums, summed over all owners by
+  // the all-reduce that also summed acc_u / acc_w, and the next step's counter, cleared here; S->sym_bad keeps it
   __shared__ float org[2];
+  const bool bad = S->sym_bad != 0 || (bad_step && *bad_step != 0);
   const long long n = S->n, n_old = *n_old_p;
   const int k = (int)(n - n_old);
   tail_duty_block0(td, n);
@@ -477,8 +481,8 @@ march_finish_sym(long long* acc_u, long long* acc_w, const SymScale* sc, const M
     double su, sw;
     if (old) {
       const float s = (float)kInv2PiD;
-      su = (double)((fx_read(acc_u, i, sc, &S->sym_bad) + fu) * s);
-      sw = (double)(-(fx_read(acc_w, i, sc, &S->sym_bad) + fw) * s);
+      su = (double)((fx_read(acc_u, i, sc, bad) + fu) * s);
+      sw = (double)(-(fx_read(acc_w, i, sc, bad) + fw) * s);
       acc_u[i] = 0;
       acc_w[i] = 0;
     } else {
@@ -491,6 +495,10 @@ march_finish_sym(long long* acc_u, long long* acc_w, const SymScale* sc, const M
     if (i == origin_index(blockIdx.x, n)) { org[0] = (float)xn; org[1] = (float)zn; m.cx[blockIdx.x] = org[0]; m.cz[blockIdx.x] = org[1]; }
   }
   __syncthreads();
+  if (bad_step && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bad) S->sym_bad = 1;       // (every block has read S->sym_bad OR *bad_step: both say the same from here on)
+    *bad_next = 0;
+  }
   if (!on) return;
   x64[i] = xn;
   z64[i] = zn;

@@ -57,7 +57,8 @@ struct PairArgs {
   const void* xt; const void* zt;
   const float* xtl; const float* ztl;
   long long nt;
-  long long grid_nz;          // > 0: target p = (xmin + (p / nz) * dr, zmin + (p % nz) * dr)
+  long long grid_nz;          // > 0: target p = (xmin + (grid_row0 + p / nz) * dr, zmin + (p % nz) * dr)
+  long long grid_row0;        //   first grid row of this launch (a block of rows of a larger grid: same coordinates, bit for bit)
   double xmin, zmin, dr;
   // results: direct (nsplit == 1) or partial slabs [split][2][nt_pad] (nsplit > 1)
   void* u; void* w;
@@ -93,7 +94,7 @@ __device__ __forceinline__ PairSizes pair_sizes(const PairArgs& a) {
 __device__ __forceinline__ void grid_point(const PairArgs& a, long long p, double& x, double& z) {
   const long long i = p / a.grid_nz;
   const long long j = p - i * a.grid_nz;
-  x = a.xmin + (double)i * a.dr;
+  x = a.xmin + (double)(a.grid_row0 + i) * a.dr;
   z = a.zmin + (double)j * a.dr;
 }
 
@@ -104,16 +105,21 @@ __device__ __forceinline__ void grid_point(const PairArgs& a, long long p, doubl
 //               after the difference is plain fp32 (removes the cancellation error of
 //               |x| ~ 50 against a vortex spacing of ~1e-3).
 // ---------------------------------------------------------------------------------------------
-// GRIDROW = true (flow-field grids with nz % TPL == 0): a lane owns TPL CONSECUTIVE grid points of one
+// GRID = 1 (flow-field grids with nz % TPL == 0): a lane owns TPL CONSECUTIVE grid points of one
 //               row (same x, z stepping by dr), so dx and dx^2 are computed once per source pair and
-//               shared by the lane's targets: 6 instead of 8 packed ops per two pairs and target.
+//               shared by the lane's targets: 6 + 2 / TPL instead of 8 packed ops per two pairs and target.
+// GRID = 2 (nz % (TPL / 2) == 0): a lane owns a PATCH of 2 rows x TPL / 2 columns, so dx, dx^2 are shared along each
+//               row and dz along each column: 5 + 8 / TPL packed ops (TPL = 8: 6 instead of 6.5 -> issue bound 20
+//               instead of 21 cycles per pair); the same operations on the same operands as GRID = 1, so the
+//               results are bit for bit the same.
 // LOCAL = true: positions are offsets from block origins (see kOriginShift); the targets are re-referred to the
 //               origin of each 256-source segment of the LDS tile (TPL adds per 256 sources).
-template <int TPL, int TILE, bool HILO, bool GRIDROW = false, bool LOCAL = false>
+template <int TPL, int TILE, bool HILO, int GRID = 0, bool LOCAL = false>
 __global__ void __launch_bounds__(kBlock)
 pair_f32(PairArgs a) {
   static_assert(TILE % kBlock == 0, "tile must be a multiple of the block size");
-  static_assert(!(GRIDROW && HILO), "the grid variant is plain fp32");
+  static_assert(!(GRID && HILO), "the grid variants are plain fp32");
+  static_assert(GRID != 2 || TPL % 2 == 0, "a patch is 2 rows");
   static_assert(!(LOCAL && HILO), "local origins replace hi+lo positions");
   static_assert(!LOCAL || TILE <= kOriginBlock || TILE % kOriginBlock == 0, "tile must be whole origin blocks");
   __shared__ __attribute__((aligned(16))) float lx[TILE];
@@ -132,10 +138,23 @@ pair_f32(PairArgs a) {
   const PairSizes sz = pair_sizes(a);
   // a launch sized from an upper bound of the target count (march): blocks without targets leave at once
   // (uniform over the block, before any barrier)
-  if ((long long)blockIdx.x * kBlock * TPL >= sz.nt) return;
-  // targets of this lane: tid, tid+256, ... of the block's slab; or TPL consecutive points (GRIDROW)
-  const long long t0 = GRIDROW ? ((long long)blockIdx.x * kBlock + tid) * TPL : ((long long)blockIdx.x * kBlock) * TPL + tid;
-  constexpr long long kTStride = GRIDROW ? 1 : kBlock;
+  // targets of this lane: tid, tid + 256, ... of the block's slab (GRID = 0); TPL consecutive points of a grid row
+  // (GRID = 1); or a patch of 2 rows x TPL / 2 columns (GRID = 2: patches are numbered along the row pairs)
+  constexpr int kCols = GRID == 2 ? TPL / 2 : 1;
+  const long long lane_id = (long long)blockIdx.x * kBlock + tid;
+  const long long nzq = GRID == 2 ? a.grid_nz / kCols : 1;                   // patches per row pair
+  const long long prow = GRID == 2 ? lane_id / nzq : 0, pcol = GRID == 2 ? lane_id - prow * nzq : 0;
+  auto tindex = [&](int t) -> long long {
+    if (GRID == 2) return (2 * prow + t / kCols) * a.grid_nz + pcol * kCols + t % kCols;   // beyond the grid: >= nt
+    if (GRID == 1) return lane_id * TPL + t;
+    return (long long)blockIdx.x * kBlock * TPL + tid + (long long)t * kBlock;
+  };
+  if (GRID == 2) {
+    const long long nrows = sz.nt / a.grid_nz;
+    if ((long long)blockIdx.x * kBlock >= ((nrows + 1) / 2) * nzq) return;
+  } else if ((long long)blockIdx.x * kBlock * TPL >= sz.nt) {
+    return;
+  }
   const long long s_begin = (long long)blockIdx.y * a.chunk;
   long long s_end = s_begin + a.chunk;
   if (s_end > sz.ns) s_end = sz.ns;
@@ -146,18 +165,18 @@ pair_f32(PairArgs a) {
   float tox[LOCAL ? TPL : 1], toz[LOCAL ? TPL : 1], tlx[LOCAL ? TPL : 1], tlz[LOCAL ? TPL : 1];
 #pragma unroll
   for (int t = 0; t < TPL; ++t) {
-    const long long ti = t0 + (long long)t * kTStride;
+    const long long ti = tindex(t);
     float x = 0.0f, z = 0.0f, xl = 0.0f, zl = 0.0f;
     if (LOCAL) { gxd[t] = 0.0; gzd[t] = 0.0; tox[t] = 0.0f; toz[t] = 0.0f; tlx[t] = 0.0f; tlz[t] = 0.0f; }
     if (ti < sz.nt) {
-      if (a.grid_nz > 0) {
+      if (GRID != 0 || a.grid_nz > 0) {
         double xd, zd;
         grid_point(a, ti, xd, zd);
         x = (float)xd;
         z = (float)zd;
         if (HILO) { xl = (float)(xd - (double)x); zl = (float)(zd - (double)z); }
         if (LOCAL) { gxd[t] = xd; gzd[t] = zd; }
-      } else if (LOCAL) {
+      } else if (LOCAL && GRID == 0) {
         const long long tb = (a.t_index0 + ti) >> kOriginShift;
         tlx[t] = static_cast<const float*>(a.xt)[ti];
         tlz[t] = static_cast<const float*>(a.zt)[ti];
@@ -216,8 +235,11 @@ pair_f32(PairArgs a) {
       const float ox = lox[seg >> kOriginShift], oz = loz[seg >> kOriginShift];
 #pragma unroll
       for (int t = 0; t < TPL; ++t) {
+        // (grid kernels read x of one target per row and z of one per column only)
+        if (GRID == 1 && t != 0) { const float z1 = (float)(gzd[t] - (double)oz); zp[t] = (f32x2){z1, z1}; continue; }
+        if (GRID == 2 && t >= kCols && t % kCols != 0) continue;
         float x, z;
-        if (a.grid_nz > 0) {
+        if (GRID != 0 || a.grid_nz > 0) {
           x = (float)(gxd[t] - (double)ox);
           z = (float)(gzd[t] - (double)oz);
         } else {
@@ -248,7 +270,7 @@ pair_f32(PairArgs a) {
           xl2 = h ? (f32x2){XL.z, XL.w} : (f32x2){XL.x, XL.y};
           zl2 = h ? (f32x2){ZL.z, ZL.w} : (f32x2){ZL.x, ZL.y};
         }
-        if (GRIDROW) {
+        if (GRID == 1) {
           const f32x2 dx = xp[0] - xs2;      // every target of the lane sits in the same grid row
           const f32x2 dxx = dx * dx;
 #pragma unroll
@@ -260,6 +282,25 @@ pair_f32(PairArgs a) {
             s = s * gs2;
             tu[t] = __builtin_elementwise_fma(dz, s, tu[t]);
             tw[t] = __builtin_elementwise_fma(dx, s, tw[t]);
+          }
+          continue;
+        }
+        if (GRID == 2) {
+          // two rows share each column's dz, kCols columns share each row's dx and dx^2
+          f32x2 dxr[2], dxxr[2], dzc[kCols];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) { dxr[r] = xp[r * kCols] - xs2; dxxr[r] = dxr[r] * dxr[r]; }
+#pragma unroll
+          for (int cc = 0; cc < kCols; ++cc) dzc[cc] = zp[cc] - zs2;
+#pragma unroll
+          for (int t = 0; t < TPL; ++t) {
+            const int r = t / kCols, cc = t % kCols;
+            const f32x2 r2 = __builtin_elementwise_fma(dzc[cc], dzc[cc], dxxr[r]);
+            const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
+            f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+            s = s * gs2;
+            tu[t] = __builtin_elementwise_fma(dzc[cc], s, tu[t]);
+            tw[t] = __builtin_elementwise_fma(dxr[r], s, tw[t]);
           }
           continue;
         }
@@ -289,7 +330,7 @@ pair_f32(PairArgs a) {
   const float scale = (float)kInv2PiD;
 #pragma unroll
   for (int t = 0; t < TPL; ++t) {
-    const long long ti = t0 + (long long)t * kTStride;
+    const long long ti = tindex(t);
     if (ti < sz.nt) {
       const float uu = (au[t].x + au[t].y) * scale;
       const float ww = -(aw[t].x + aw[t].y) * scale;

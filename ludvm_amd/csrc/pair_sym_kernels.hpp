@@ -61,6 +61,9 @@ struct SymArgs {
   // rsplit follow from it by the same rule the host uses (sym_geometry); the grid is sized from the host's upper
   // bound and surplus waves leave at once.
   const long long* n_dev;
+  // Sharded roll-up of ONE simulation over several GPUs (ludvm_set_shard): with n_dev the owner's tile block
+  // [i_first, i_first + i_count) is derived on the device from the tile count: tiles [NT r / G, NT (r + 1) / G)
+  int shard_rank, shard_world;
 };
 
 // Launch geometry as a function of the vortex count alone (not of the owner's share, not of a host-side bound):
@@ -157,7 +160,12 @@ pair_sym_f32(SymArgs a) {
     const SymGeom gm = sym_geometry(a.n, T, a.tune_split, R);
     a.ntiles = gm.ntiles;
     a.dmax = gm.dmax;
+    a.i_first = 0;
     a.i_count = gm.ntiles;
+    if (a.shard_world > 1) {
+      a.i_first = gm.ntiles * a.shard_rank / a.shard_world;
+      a.i_count = gm.ntiles * (a.shard_rank + 1) / a.shard_world - a.i_first;
+    }
     a.ysplit = gm.ysplit;
   }
   constexpr int H = T / 2;
@@ -480,9 +488,12 @@ sym_prepare_final(const double* partial, int nparts, double vc4, SymScale* out, 
 }
 
 // fixed-point raw sum -> fp32 raw sum (NaN when the launch met a non-finite partial sum)
-__device__ __forceinline__ float fx_read(const long long* acc, long long i, const SymScale* sc, const long long* bad) {
-  if (*bad != 0) return __builtin_nanf("");
+__device__ __forceinline__ float fx_read(const long long* acc, long long i, const SymScale* sc, bool bad) {
+  if (bad) return __builtin_nanf("");
   return (float)((double)acc[i] * sc->inv);
+}
+__device__ __forceinline__ float fx_read(const long long* acc, long long i, const SymScale* sc, const long long* bad) {
+  return fx_read(acc, i, sc, *bad != 0);
 }
 
 // acc -> velocities

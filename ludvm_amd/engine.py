@@ -104,6 +104,26 @@ class Engine:
         pair once, 64-bit fixed-point accumulation: also bitwise reproducible); n >= 2: the same from n vortices."""
         self._check(self._lib.ludvm_set_symmetric(self._ctx, int(mode)))
 
+    def set_shard(self, rank, world, allreduce=None, d_acc=0, acc_bytes=0, min_vortices=0):
+        """Evaluate only tile block `rank` of `world` of every symmetric roll-up of at least `min_vortices` vortices;
+        `allreduce(count)` must enqueue an in-place sum all-reduce of the first `count` int64 of the accumulator buffer
+        at device address `d_acc` (ludvm_set_shard).  world = 1 undoes it."""
+        if world > 1:
+            def hook(_user, _buf, count, _stream):
+                try:
+                    allreduce(int(count))
+                    return 0
+                except Exception as e:       # never let an exception cross the C frame
+                    self._hook_error = e
+                    return 1
+            self._hook_c = _ffi.ALLREDUCE_FN(hook)        # kept alive as long as the library may call it
+            self._check(self._lib.ludvm_set_shard(self._ctx, int(rank), int(world), int(min_vortices),
+                                                  ctypes.cast(self._hook_c, c_void_p), None, c_void_p(int(d_acc)),
+                                                  int(acc_bytes)))
+        else:
+            self._check(self._lib.ludvm_set_shard(self._ctx, 0, 1, 0, None, None, None, 0))
+            self._hook_c = None
+
     # -- stateless pair sum ----------------------------------------------------------------------
     def induce(self, circulation, xw, zw, xp, zp, v_core, precision="f32"):
         """(u, w) float64 arrays; host arrays in, host arrays out (LUDVM.py:549-570)."""
@@ -307,6 +327,18 @@ class Engine:
                                                             _pd(xs), _pd(zs), _pd(g), len(xs), float(v_core), _pf(u), _pf(w),
                                                             _pf(ome)))
         return u.reshape(nx, nz), w.reshape(nx, nz), ome.reshape(nx, nz)
+
+    def flowfield_rows(self, xmin, zmin, dr, nx, nz, row_first, row_count, circulation, xw, zw, v_core, vorticity=True):
+        """Rows [row_first, row_first + row_count) of the nx x nz grid: (u, w, ome) float32 [row_count, nz], bit for
+        bit what the whole-grid call returns for those rows -- the unit a multi-GPU flow field shards by."""
+        g, xs, zs = _f64(circulation), _f64(xw), _f64(zw)
+        u, w = np.empty(row_count * nz, np.float32), np.empty(row_count * nz, np.float32)
+        ome = np.empty(row_count * nz, np.float32) if vorticity else None
+        self._check(self._lib.ludvm_flowfield_rows_f32(self._ctx, float(xmin), float(zmin), float(dr), int(nx), int(nz),
+                                                       int(row_first), int(row_count), _pd(xs), _pd(zs), _pd(g), len(xs),
+                                                       float(v_core), _pf(u), _pf(w), _pf(ome)))
+        sh = (row_count, nz)
+        return u.reshape(sh), w.reshape(sh), (ome.reshape(sh) if vorticity else None)
 
     def flowfield_dev(self, xmin, zmin, dr, nx, nz, d_xs, d_zs, d_gs, ns, v_core, d_u, d_w):
         self._check(self._lib.ludvm_flowfield_dev_f32(self._ctx, float(xmin), float(zmin), float(dr), int(nx), int(nz),

@@ -98,6 +98,11 @@ class LUDVM:
       march      True (default): stretches of time steps whose history row is not recorded run as a
                  device-resident march (Gamma solve on the GPU, no host round trip per step);
                  False: one device round trip per step throughout
+      distributed  None (default): one GPU.  True or a torch.distributed process group: the simulation is shared by
+                 the ranks of that group, one process per GPU (ludvm_amd/distributed.py) -- every rank constructs the same
+                 object and calls the same methods; flowfield shards the grid rows, induced_velocity the targets,
+                 time_loop the roll-up's unordered pairs (one integer all-reduce per step over RCCL), and every rank
+                 ends up with the reference's full result arrays
     """
 
     def __init__(self, t0=0, tf=12, dt=1.5e-2, chord=1, rho=1.225, Uinf=1,
@@ -107,7 +112,7 @@ class LUDVM:
                  verbose=True, method='Faure',
                  circulation_freevort=None, xy_freevort=None, *,
                  engine=None, device=0, precision='auto', history='auto', snapshot_steps=(), run=True,
-                 checkpoint_every=0, checkpoint_path=None, march=True):
+                 checkpoint_every=0, checkpoint_path=None, march=True, distributed=None):
         self._ctor = dict(t0=t0, tf=tf, dt=dt, chord=chord, rho=rho, Uinf=Uinf, Npoints=Npoints, Ncoeffs=Ncoeffs,
                           LESPcrit=LESPcrit, Naca=Naca, foil_filename=foil_filename, G=G, T=T, alpha_m=alpha_m,
                           alpha_max=alpha_max, k=k, phi=phi, h_max=h_max, method=method, precision=precision,
@@ -163,6 +168,11 @@ class LUDVM:
         if self.checkpoint_every and not checkpoint_path:
             raise ValueError("checkpoint_every needs a checkpoint_path")
         self.engine = engine if engine is not None else Engine(device)  # raises without the HIP library / GPU
+        self._shard = None
+        if distributed is not None and distributed is not False:
+            from .distributed import ShardGroup
+            self._shard = distributed if isinstance(distributed, ShardGroup) else \
+                ShardGroup(None if distributed is True else distributed)
 
         self.start_time = timeit.default_timer()
         if Naca is not None:
@@ -284,6 +294,14 @@ class LUDVM:
         v_core when `viscous == True`, point vortices otherwise (LUDVM.py:549-570).  Any array-likes
         in, two new float64 arrays out; evaluated on the GPU in `self.precision`."""
         v_core = self.v_core if viscous == True else 0  # noqa: E712  (the reference's comparison, :562)
+        sh = self._shard
+        if sh is not None and sh.world > 1 and len(xp) >= sh.min_targets:
+            # targets in contiguous blocks over the ranks (sources replicated), one all-gather of the (u, w) blocks
+            xt, zt = np.asarray(xp, dtype=float).reshape(-1), np.asarray(zp, dtype=float).reshape(-1)
+            lo, hi, _ = sh.block(len(xt))
+            ul, wl = self.engine.induce(circulation, xw, zw, xt[lo:hi], zt[lo:hi], v_core, precision=self.precision)
+            uw = sh.gather_blocks(np.stack([ul, wl], axis=1), len(xt))
+            return np.ascontiguousarray(uw[:, 0]), np.ascontiguousarray(uw[:, 1])
         return self.engine.induce(circulation, xw, zw, xp, zp, v_core, precision=self.precision)
 
     def _chord_frame(self, u1, w1, i):
@@ -382,6 +400,9 @@ class LUDVM:
         # device wake, in shedding order: FREE first, then each step's TEV (and LEV when shed)
         eng.wake_clear()
         eng.wake_reserve(nf + 2 * nv + npan + 2)
+        if self._shard is not None:
+            # the roll-up's unordered pairs in tile blocks over the ranks, one integer all-reduce per step
+            self._shard.attach(eng, nf + 2 * nv + npan + 2)
         eng.wake_append(free0[0], free0[1], g_free)
         tev_slot = np.zeros(nv, dtype=np.int64)
         lev_slot = np.zeros(nv, dtype=np.int64)
@@ -636,6 +657,8 @@ class LUDVM:
                 self._write_checkpoint(i + 1, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
                                        tev_slot, lev_slot)
             i += 1
+        if self._shard is not None:
+            self._shard.detach(eng)
         return None
 
     def _march_stretch(self, i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
@@ -857,6 +880,7 @@ class LUDVM:
         w = np.zeros([nsteps, nx, nz])
         ome = np.zeros([nsteps, nx, nz])
         fused = hasattr(self.engine, 'flowfield_vorticity')
+        sh = self._shard if (self._shard is not None and self._shard.world > 1) else None
         for ii, s in enumerate(tsteps):
             if self.verbose:
                 print('Flowfield tstep =', s)
@@ -867,7 +891,19 @@ class LUDVM:
                                f"which this run (history='sparse') did not record: construct it with "
                                f"snapshot_steps=LUDVM.flowfield_rows_needed(tsteps) = "
                                f"{self.flowfield_rows_needed(tsteps)}") from e
-            if fused:
+            if sh is not None:
+                # grid rows in contiguous blocks over the ranks, nothing exchanged until the finished rows are gathered
+                r0, r1, _ = sh.block(nx)
+                if hasattr(self.engine, 'flowfield_rows'):
+                    ub, wb, ob = self.engine.flowfield_rows(xmin, zmin, dr, nx, nz, r0, r1 - r0, g, xw, zw, self.v_core)
+                else:       # engines without the row entry: the block with one halo row per interior side
+                    h0, h1 = max(0, r0 - 1), min(nx, r1 + 1)
+                    uh, wh = self.engine.flowfield(x1[h0] if h1 > h0 else xmin, zmin, dr, h1 - h0, nz, g, xw, zw, self.v_core)
+                    oh = self.engine.vorticity(uh, wh, dr) if h1 - h0 >= 2 else np.zeros_like(uh)
+                    ub, wb, ob = uh[r0 - h0:r1 - h0], wh[r0 - h0:r1 - h0], oh[r0 - h0:r1 - h0]
+                fields = sh.gather_blocks(np.stack([ub, wb, ob], axis=1).astype(np.float32), nx)     # [nx, 3, nz]
+                u[ii], w[ii], ome[ii] = fields[:, 0], fields[:, 1], fields[:, 2]
+            elif fused:
                 u[ii], w[ii], ome[ii] = self.engine.flowfield_vorticity(xmin, zmin, dr, nx, nz, g, xw, zw, self.v_core)
             else:
                 uf, wf = self.engine.flowfield(xmin, zmin, dr, nx, nz, g, xw, zw, self.v_core)

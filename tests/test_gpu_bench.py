@@ -111,3 +111,42 @@ def test_engine_lifecycle_releases_device_memory():
     assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
     assert d["cycles"] == 300 and abs(d["leaked_MB"]) < 64
+
+
+def _torchrun(nproc, script, extra_env, port):
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", script)]
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+
+
+def test_class_level_sharding_two_ranks_on_one_card():
+    """`LUDVM(..., distributed=True)` with two ranks sharing the one card over gloo (tools/dist_class_check.py): the
+    sharded time loop (tile blocks of the symmetric roll-up + one integer all-reduce per step through ludvm_set_shard's
+    hook, marched and per step, fp32 and hi+lo) and the sharded flow field equal the single-GPU run BIT FOR BIT; the
+    sharded induced_velocity agrees to fp32 rounding."""
+    p = _torchrun(2, "dist_class_check.py", {"LUDVM_DIST_BACKEND": "gloo"}, 29561)
+    assert p.returncode == 0 and "DIST_OK gloo 2" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+
+
+def test_class_level_sharding_on_rccl_with_two_gpus():
+    """The same check on the real backend, one rank per GPU over RCCL: runs wherever two or more GPUs are visible (the
+    driver's 8-GPU node), skips on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL ranks cannot share a card)")
+    p = _torchrun(2, "dist_class_check.py", {}, 29562)
+    assert p.returncode == 0 and "DIST_OK nccl 2" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+
+
+def test_bench_two_ranks_on_rccl_with_two_gpus():
+    """bench.py exactly as the driver launches it for N = 2, on RCCL: skips below two GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL ranks cannot share a card)")
+    for sym in ("1", "0"):
+        d = _launch(2, {}, "--vortices", "200000", "--steps", "2", "--warmup", "1", "--symmetric", sym)
+        assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 2
+        assert len(d["config"]["pair_kernel_ms_per_rank"]) == 2 and d["value"] > 1e11

@@ -236,6 +236,75 @@ def test_flowfield_grid_and_vorticity(eng):
         eng.vorticity(u[:1], w[:1], dr)
 
 
+def test_grid_patch_kernel_equals_the_row_kernel_bit_for_bit():
+    """Flow-field grids run with a 2 x 4 patch of grid points per lane (dx, dx^2 shared along each row, dz along each
+    column: 6 instead of 6.5 packed operations per two pairs and target); LUDVM_GRID_KERNEL=row selects the previous
+    kernel (4 points of one row per lane).  Same operations on the same operands in the same order -> the same bits,
+    for even and odd row counts, one and several source splits, plain and local-origin sources."""
+    import os
+    from ludvm_amd import Engine
+    rng = np.random.default_rng(17)
+    res = {}
+    for kind in ("patch", "row"):
+        os.environ["LUDVM_GRID_KERNEL"] = kind
+        try:
+            e = Engine(0)
+        finally:
+            del os.environ["LUDVM_GRID_KERNEL"]
+        try:
+            out = []
+            r = np.random.default_rng(17)
+            for ns, nx, nz in ((700, 37, 48), (20000, 64, 36), (3000, 1, 8), (5000, 301, 260)):
+                xs, zs, g = r.uniform(-10, 0, ns) - 20.0, r.uniform(-2, 2, ns), r.standard_normal(ns) / 50
+                u, w, ome = e.flowfield_rows(-30.0, -2.0, 0.0173, nx, nz, 0, nx, g, xs, zs, 0.065, vorticity=nx > 1)
+                out.append((u, w, ome))
+            res[kind] = out
+        finally:
+            e.close()
+    for a, b in zip(res["patch"], res["row"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert (a[2] is None and b[2] is None) or np.array_equal(a[2], b[2])
+
+
+def test_flowfield_over_a_far_wake_keeps_1e5(eng):
+    """The reference evaluates flowfield in float64 (LUDVM.py:1206, :1216-1217).  Over a config-2 wake -- |x| ~ 50,
+    vortices 1e-3 apart, v_core = 1.3e-3 -- plain fp32 coordinates lose three digits; the host entry
+    stores the sources as offsets from the origin of their 256-source block and refers the float64 grid points to
+    those origins: 1e-5 of max|u| against the oracle, at the speed of the plain fp32 grid kernel.  The fused
+    velocity + vorticity call returns exactly what the two separate calls return."""
+    rng = np.random.default_rng(41)
+    ns = 30000
+    xs = -50.0 + np.sort(rng.uniform(0, 30, ns))
+    zs = 0.3 * np.sin(0.7 * xs) + 1e-3 * rng.standard_normal(ns)
+    g = rng.standard_normal(ns) * 1e-3
+    vc = 1.3e-3
+    import torch
+    dev = torch.device("cuda", 0)
+    for k, (xmin, zmin, dr, nx, nz) in enumerate(((-35.0, -0.6, 0.01, 96, 120), (-30.3, 0.1, 0.0013, 41, 37))):   # nz % 4 == 0 and not
+        u, w = eng.flowfield(xmin, zmin, dr, nx, nz, g, xs, zs, vc)
+        X, Z = np.meshgrid(xmin + np.arange(nx) * dr, zmin + np.arange(nz) * dr, indexing="ij")
+        ur, wr = c_oracle.induced_velocity(g, xs, zs, X.ravel(), Z.ravel(), vc)
+        err = _rel(u.ravel(), w.ravel(), ur, wr)
+        assert err < 1e-5, (nx, nz, err)
+        u2, w2, ome2 = eng.flowfield_vorticity(xmin, zmin, dr, nx, nz, g, xs, zs, vc)
+        assert np.array_equal(u, u2) and np.array_equal(w, w2)
+        assert np.array_equal(ome2, eng.vorticity(u, w, dr))
+        if k == 0:
+            # the grid that crosses the sheet, with plain fp32 coordinates for comparison (device fp32 entry: the caller's
+            # layout is used as it is)
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            try:
+                dx, dz, dg = (torch.from_numpy(a.astype(np.float32)).to(dev) for a in (xs, zs, g))
+                du, dw = torch.empty(nx * nz, device=dev), torch.empty(nx * nz, device=dev)
+                eng.flowfield_dev(xmin, zmin, dr, nx, nz, dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), ns, vc, du.data_ptr(),
+                                  dw.data_ptr())
+                torch.cuda.synchronize()
+                plain = _rel(du.cpu().numpy(), dw.cpu().numpy(), ur, wr)
+                assert plain > 20 * err, (plain, err)
+            finally:
+                eng.set_stream(None)
+
+
 def test_flowfield_row_blocks_with_halo_equal_the_full_grid(eng):
     """Multi-GPU flow field on one GPU: the row blocks of 3 owners (each with its halo rows) reproduce
     the single-launch fields bit for bit in (u, w) and in the vorticity."""

@@ -40,6 +40,9 @@ def statistics(sim, periods=5):
         a = getattr(sim, name)
         out[name + "_mean"] = [float(a[1 + p * per:1 + (p + 1) * per].mean()) for p in range(periods)]
         out[name + "_rms"] = [float(a[1 + p * per:1 + (p + 1) * per].std()) for p in range(periods)]
+        # robust spread: median absolute deviation (the rms is dominated by a few load spikes of |Cl| ~ 70 per period)
+        out[name + "_mad"] = [float(np.median(np.abs(a[1 + p * per:1 + (p + 1) * per] - np.median(a[1 + p * per:1 + (p + 1) * per]))))
+                              for p in range(periods)]
         out[name + "_absmax"] = float(np.abs(a[1:]).max())
     C = sim.circulation
     shed = sim.LEV_shed[1:] != -1
@@ -62,9 +65,12 @@ def statistics(sim, periods=5):
 def run_one(kind, args):
     from ludvm_amd import LUDVM, Engine
     eng = Engine(0)
-    prec = {"f64": "f64", "f64b": "f64", "f32": "f32", "f32x2": "f32x2", "auto": "auto"}[kind.split(":")[0]]
-    if kind.startswith("f64b"):
+    base = kind.split(":")[0]
+    prec = "f64" if base.startswith("f64") else base
+    if base == "f64b":
         eng.set_tuning(0, 7)           # same arithmetic, sums cut into different partial sums
+    elif base.startswith("f64s"):
+        eng.set_tuning(0, int(base[4:]))   # f64s<k>: every launch's sources cut into k partial sums
     march = ":step" not in kind
     kw = dict(CFG2)
     kw["tf"] = args.tf
@@ -83,8 +89,8 @@ def compare(a, b):
     """Largest per-period differences between two statistics records."""
     d = {}
     for name in ("Cl", "Cd", "Cm"):
-        d["d_" + name + "_mean"] = float(np.max(np.abs(np.array(a[name + "_mean"]) - np.array(b[name + "_mean"]))))
-        d["d_" + name + "_rms"] = float(np.max(np.abs(np.array(a[name + "_rms"]) - np.array(b[name + "_rms"]))))
+        for st in ("mean", "rms", "mad"):
+            d[f"d_{name}_{st}"] = float(np.max(np.abs(np.array(a[f"{name}_{st}"]) - np.array(b[f"{name}_{st}"]))))
     d["d_lev"] = abs(a["lev"] - b["lev"])
     d["d_lev_per_period"] = int(np.max(np.abs(np.array(a["lev_per_period"]) - np.array(b["lev_per_period"]))))
     return d
@@ -96,6 +102,8 @@ if __name__ == "__main__":
     ap.add_argument("--tf", type=float, default=50.0)
     ap.add_argument("--out", default="gpurun_out/cfg2_stats.json")
     ap.add_argument("--series", default="", help="also store the Cl/Cd/Cm series and shedding flags (npz)")
+    ap.add_argument("--golden", default="", help="write the float64 ensemble record the GPU test compares against (json) "
+                    "and, next to it, the first 1000 steps of the first run's loads (npz)")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     recs, series, sheds = {}, {}, {}
@@ -117,5 +125,30 @@ if __name__ == "__main__":
         print(f"{kinds[0]} vs {k}:", json.dumps(c), flush=True)
     with open(a.out, "w") as f:
         json.dump({"runs": recs, "compare": cmp_}, f, indent=1)
+    if a.golden:
+        ens = [k for k in kinds if k.startswith("f64")]
+        stats = {}
+        for name in ("Cl_mean", "Cl_rms", "Cl_mad", "Cd_mean", "Cd_rms", "Cd_mad", "Cm_mean", "Cm_rms", "Cm_mad", "lev_per_period"):
+            v = np.array([recs[k][name] for k in ens], dtype=float)          # [runs, periods]
+            var = v.var(0, ddof=1)
+            # periods 2.. are statistically alike (the starting transient is over): their variances pooled give a
+            # spread estimate with (runs - 1) * (periods - 1) degrees of freedom instead of runs - 1
+            stats[name] = {"mean": v.mean(0).tolist(), "std": np.sqrt(var).tolist(), "std_pooled": float(np.sqrt(var[1:].mean())),
+                           "min": v.min(0).tolist(), "max": v.max(0).tolist()}
+        for name in ("lev", "Cl_absmax", "Cd_absmax", "Cm_absmax", "gamma_abs_sum"):
+            v = np.array([recs[k][name] for k in ens], dtype=float)
+            stats[name] = {"mean": float(v.mean()), "std": float(v.std(ddof=1)), "min": float(v.min()), "max": float(v.max())}
+        first = recs[ens[0]]
+        gold = {"what": "BASELINE config 2 (dt = 1e-3, t in [0, 50]), float64 pair sums on the GPU, ensemble over the "
+                        "partition of every sum into partial sums: the spread is what equally exact evaluations differ by",
+                "generated_by": "tools/cfg2_stats.py --golden (MI355X)", "runs": ens, "n_runs": len(ens),
+                "period_steps": first["period_steps"], "steps": first["steps"], "first_lev_step": first["first_lev_step"],
+                "tev": first["tev"], "max_abs_LESP": max(recs[k]["max_abs_LESP"] for k in ens),
+                "kelvin_residual_max": max(recs[k]["kelvin_residual_max"] for k in ens), "ensemble": stats,
+                "per_run": {k: recs[k] for k in ens}}
+        with open(a.golden, "w") as f:
+            json.dump(gold, f, indent=1)
+        np.savez_compressed(os.path.splitext(a.golden)[0] + "_first1000.npz", loads=series[ens[0]][:, :1001],
+                            shed=sheds[ens[0]][:1001])
     if a.series:
         np.savez_compressed(a.series, **{k.replace(":", "_"): series[k].astype(np.float32) for k in kinds})

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""One simulation shared by the ranks of a torch.distributed group, checked against the same simulation on one GPU.
+Launch with torchrun (one process per GPU; backend nccl = RCCL), or with LUDVM_DIST_BACKEND=gloo to rehearse with
+several ranks sharing one card:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29551 \
+        tools/dist_class_check.py
+
+Every rank builds LUDVM(..., distributed=True) with the symmetric threshold and the sharding threshold lowered so that
+the README-size case runs sharded roll-ups (tile blocks + one integer all-reduce per step), and compares with a
+single-GPU run of its own: loads, circulations and the final wake must agree BIT FOR BIT (integer sums commute), the
+sharded flow field too (row blocks), the sharded induced_velocity to fp32 rounding.  Prints DIST_OK <backend> <world>."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ludvm_amd import LUDVM, Engine  # noqa: E402
+from ludvm_amd.distributed import ShardGroup  # noqa: E402
+
+backend = os.environ.get("LUDVM_DIST_BACKEND", "nccl")
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+if backend == "nccl":
+    dist.init_process_group(backend="nccl", device_id=dev)
+else:
+    dist.init_process_group(backend=backend)
+assert dist.get_world_size() == world
+kw = dict(t0=0, tf=8, dt=5e-2, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2, Naca="0012")
+ok = True
+for march in (True, False):
+    for prec in ("f32", "f32x2"):
+        eng = Engine(local)
+        eng.set_symmetric(8)                       # symmetric (and overlapped) steps from 8 vortices on
+        sg = ShardGroup(min_targets=1000, min_wake=64)
+        sh = LUDVM(**kw, verbose=False, engine=eng, precision=prec, history="sparse", march=march, distributed=sg)
+        one = LUDVM(**kw, verbose=False, engine=eng, precision=prec, history="sparse", march=march)
+        same = all(np.array_equal(getattr(sh, n), getattr(one, n)) for n in ("Cl", "Cd", "Cm", "LESP", "LEV_shed")) and \
+            np.array_equal(sh.path["TEV"][sh.nt - 1], one.path["TEV"][one.nt - 1]) and \
+            np.array_equal(sh.circulation["TEV"], one.circulation["TEV"])
+        print(f"rank {rank} march={march} {prec}: sharded time_loop == single-GPU bit for bit: {same}", flush=True)
+        ok &= bool(same)
+        if march and prec == "f32":
+            args = dict(xmin=-6.0, xmax=1.0, zmin=-1.5, zmax=1.5, dr=0.05, tsteps=[0, 80, 159])
+            sg2 = ShardGroup(min_targets=1000, min_wake=64)
+            shf = LUDVM(**kw, verbose=False, engine=eng, precision=prec, history="sparse", distributed=sg2,
+                        snapshot_steps=LUDVM.flowfield_rows_needed(args["tsteps"]))
+            onef = LUDVM(**kw, verbose=False, engine=eng, precision=prec, history="sparse",
+                         snapshot_steps=LUDVM.flowfield_rows_needed(args["tsteps"]))
+            shf.flowfield(**args)
+            onef.flowfield(**args)
+            ff = all(np.array_equal(getattr(shf, n), getattr(onef, n)) for n in ("u_ff", "w_ff", "ome_ff"))
+            print(f"rank {rank}: sharded flowfield == single-GPU bit for bit: {ff}", flush=True)
+            rng = np.random.default_rng(1)
+            xw, zw, g = rng.uniform(-5, 0, 3000), rng.uniform(-1, 1, 3000), rng.standard_normal(3000) / 50
+            xp, zp = rng.uniform(-5, 0, 5001), rng.uniform(-1, 1, 5001)
+            u, w = shf.induced_velocity(g, xw, zw, xp, zp)
+            ur, wr = onef.induced_velocity(g, xw, zw, xp, zp)
+            iv = max(np.abs(u - ur).max(), np.abs(w - wr).max()) <= 1e-5 * max(np.abs(ur).max(), np.abs(wr).max())
+            print(f"rank {rank}: sharded induced_velocity within fp32 rounding: {iv}", flush=True)
+            ok &= bool(ff) and bool(iv)
+        eng.close()
+t = torch.tensor([1 if ok else 0], device=dev if backend == "nccl" else "cpu")
+dist.all_reduce(t, op=dist.ReduceOp.MIN)
+dist.barrier()
+dist.destroy_process_group()
+if int(t.item()) != 1:
+    sys.exit("sharded run differs from the single-GPU run")
+if rank == 0:
+    print("DIST_OK", backend, world)
