@@ -1,4 +1,7 @@
 R=$GRAFT_REPO_ROOT
-LUDVM_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29571 $R/tools/dist_class_check.py > $R/gpurun_out/r02_dist_check.log 2>&1
-tail -40 $R/gpurun_out/r02_dist_check.log
-python -m pytest $R/tests/test_gpu_kernel.py -m gpu -q -k "far_wake or patch" 2>&1 | tail -5
+O=$R/gpurun_out
+: > $O/r02_fuzz_march_seeds_1_to_7.txt
+for seed in 1 2 3 4 5 6 7; do python $R/tools/fuzz_march.py --cases 24 --seed $seed >> $O/r02_fuzz_march_seeds_1_to_7.txt 2>/dev/null; echo "seed $seed rc $?" >> $O/r02_fuzz_march_seeds_1_to_7.txt; done
+grep -E "failures|rc" $O/r02_fuzz_march_seeds_1_to_7.txt
+echo SWEEP; python $R/tools/sweep_rollup.py 11264 16384 24576 32768 40960 49152 65536 98304 131072 262144 > $O/r02_sweep_rollup.txt 2>/dev/null; cat $O/r02_sweep_rollup.txt
+python $R/tools/sweep_n.py 16384 65536 262144 1048576 > $O/r02_sweep_n.txt 2>/dev/null; cat $O/r02_sweep_n.txt

@@ -57,7 +57,7 @@ def cfg5(args):
     ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float), xt, zt, 0.065)
     u, w = du.cpu().numpy()[sel], dw.cpu().numpy()[sel]
     err = max(np.abs(u - ur).max(), np.abs(w - wr).max()) / max(np.abs(ur).max(), np.abs(wr).max())
-    print(json.dumps({"config": f"cfg5 flowfield {nx}x{nz} grid over N={n}", "kernel": "generic tpl=%d" % args.tpl if args.tpl else "grid-row (shared dx)", "s_per_call": el, "pairs_per_s": pairs / el,
+    print(json.dumps({"config": f"cfg5 flowfield {nx}x{nz} grid over N={n}", "kernel": "generic tpl=%d" % args.tpl if args.tpl else ("grid row of 4 (shared dx)" if os.environ.get("LUDVM_GRID_KERNEL", "")[:1] in ("r", "1") else "grid patch 2 x 4 (shared dx, dz)"), "s_per_call": el, "pairs_per_s": pairs / el,
                       "pair_kernel_ms": kms, "pct_fp32_peak": 13 * pairs / (kms * 1e-3) / 157.3e12 * 100,
                       "sampled_rel_err_vs_oracle": err, "omega_finite": bool(torch.isfinite(dome).all().item())}))
 
