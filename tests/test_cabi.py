@@ -61,6 +61,19 @@ def test_product_never_imports_the_oracle():
                 assert "import oracle" not in src and "from oracle" not in src, f
 
 
+def test_tools_and_bench_do_not_use_the_oracle_outside_the_cpu_baseline():
+    """Only tests/ (incl. tests/tools/), __graft_entry__.smoke() and bench.py's cpu_baseline leg may import the oracle."""
+    import re
+    for f in sorted(os.listdir(os.path.join(ROOT, "tools"))):
+        if f.endswith(".py") or f.endswith(".sh"):
+            src = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    hits = [m.start() for m in re.finditer(r"from oracle|import oracle", bench)]
+    a, b = bench.index("def cpu_baseline("), bench.index("def main(")
+    assert hits and all(a < h < b for h in hits)
+
+
 def test_single_hip_runtime_whatever_the_import_order():
     """PyTorch-ROCm bundles its own libamdhip64.so; the engine must share it rather than map the system
     copy next to it (two runtimes in one process: torch cannot initialise its device afterwards, stream

@@ -712,6 +712,25 @@ def test_march_dense_history_in_several_calls(eng, g2):
     assert np.abs(cut.Cl[:100] - ref.Cl[:100]).max() <= 1e-10
 
 
+def test_more_than_256_panels_in_the_fused_symmetric_roll_up():
+    """Npoints = 321 (320 bound vortices): the reference has no limit on the panel count; round 1's fused symmetric
+    roll-up refused more than 256 bound vortices in the middle of a run.  The Euler finisher now walks the
+    bound vortices in chunks; the march (one thread per panel) stays limited to 256 panels and such runs take the
+    per-step path.  fp32 with the symmetric kernel from 8 vortices on, against the float64 run."""
+    from ludvm_amd import Engine, LUDVM
+    e = Engine(0)
+    try:
+        e.set_symmetric(8)
+        kw = dict(CONFIG1, tf=3, Npoints=321, Ncoeffs=40)
+        a = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse")
+        b = LUDVM(**kw, verbose=False, engine=e, precision="f64", history="sparse")
+        assert np.array_equal(a.LEV_shed, b.LEV_shed) and (a.LEV_shed != -1).any()
+        for name in ("Cl", "Cd", "Cm"):
+            assert np.abs(getattr(a, name) - getattr(b, name)).max() <= 1e-4, name
+    finally:
+        e.close()
+
+
 def test_march_on_a_caller_provided_stream():
     """The engine on a torch side stream (ludvm_set_stream): the march's own second stream forks from and joins that
     stream; results as on the engine's own stream."""

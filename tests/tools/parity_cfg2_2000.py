@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ludvm_oracle as O  # noqa: E402
 from ludvm_amd import LUDVM, Engine  # noqa: E402
 

@@ -1,7 +1,7 @@
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out
-: > $O/r02_fuzz_march_seeds_1_to_7.txt
-for seed in 1 2 3 4 5 6 7; do python $R/tools/fuzz_march.py --cases 24 --seed $seed >> $O/r02_fuzz_march_seeds_1_to_7.txt 2>/dev/null; echo "seed $seed rc $?" >> $O/r02_fuzz_march_seeds_1_to_7.txt; done
-grep -E "failures|rc" $O/r02_fuzz_march_seeds_1_to_7.txt
-echo SWEEP; python $R/tools/sweep_rollup.py 11264 16384 24576 32768 40960 49152 65536 98304 131072 262144 > $O/r02_sweep_rollup.txt 2>/dev/null; cat $O/r02_sweep_rollup.txt
-python $R/tools/sweep_n.py 16384 65536 262144 1048576 > $O/r02_sweep_n.txt 2>/dev/null; cat $O/r02_sweep_n.txt
+cd $R
+python _old_r1/bench.py --workload cfg4 --steps 2 --warmup 1 --cpu-rows 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('OLD cfg4', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'])"
+python bench.py --workload cfg4 --steps 2 --warmup 1 --cpu-rows 0 --repeats 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('NEW cfg4', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'])"
+python bench.py --workload cfg4 --steps 2 --warmup 1 --cpu-rows 0 --repeats 0 --splits 8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('NEW cfg4 splits 8', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'])"
+python bench.py --workload cfg4 --steps 2 --warmup 1 --cpu-rows 0 --repeats 0 --splits 64 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('NEW cfg4 splits 64', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'])"
+python bench.py --steps 5 --warmup 2 --cpu-rows 0 --repeats 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('NEW cfg3', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'])"

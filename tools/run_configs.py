@@ -19,7 +19,6 @@ sys.path.insert(0, ROOT)
 def cfg5(args):
     import torch
     from ludvm_amd import Engine
-    from oracle import c_oracle
     n, nx, nz = args.vortices, args.grid, args.grid
     rng = np.random.default_rng(20260101)
     x = rng.uniform(-10, 0, n).astype(np.float32)
@@ -50,13 +49,8 @@ def cfg5(args):
     el = (time.perf_counter() - t0) / args.reps
     kms, _ = eng.kernel_time_ms(True)
     pairs = float(nx) * nz * n
-    # parity on sampled grid points against the C oracle
-    sel = rng.choice(nx * nz, 512, replace=False)
-    xt = xmin + (sel // nz) * dr
-    zt = zmin + (sel % nz) * dr
-    ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float), xt, zt, 0.065)
-    u, w = du.cpu().numpy()[sel], dw.cpu().numpy()[sel]
-    err = max(np.abs(u - ur).max(), np.abs(w - wr).max()) / max(np.abs(ur).max(), np.abs(wr).max())
+    # (parity of this case on sampled grid points against the C oracle: tests/test_gpu_kernel.py::test_full_size_config5_flowfield)
+    err = None
     print(json.dumps({"config": f"cfg5 flowfield {nx}x{nz} grid over N={n}", "kernel": "generic tpl=%d" % args.tpl if args.tpl else ("grid row of 4 (shared dx)" if os.environ.get("LUDVM_GRID_KERNEL", "")[:1] in ("r", "1") else "grid patch 2 x 4 (shared dx, dz)"), "s_per_call": el, "pairs_per_s": pairs / el,
                       "pair_kernel_ms": kms, "pct_fp32_peak": 13 * pairs / (kms * 1e-3) / 157.3e12 * 100,
                       "sampled_rel_err_vs_oracle": err, "omega_finite": bool(torch.isfinite(dome).all().item())}))
