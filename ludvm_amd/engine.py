@@ -54,12 +54,18 @@ class Engine:
     def _check(self, rc):
         if rc != _ffi.OK:
             msg = self._lib.ludvm_last_error(self._ctx)
-            raise LudvmHipError(rc, msg.decode() if msg else "")
+            err = LudvmHipError(rc, msg.decode() if msg else "")
+            cause = getattr(self, "_hook_error", None)      # an exception raised inside the all-reduce hook (set_shard)
+            if cause is not None:
+                self._hook_error = None
+                raise err from cause
+            raise err
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
             self._lib.ludvm_destroy(self._ctx)
             self._ctx = c_void_p()
+            self._hook_c = None
 
     def __del__(self):
         try:

@@ -456,209 +456,211 @@ class LUDVM:
         dense_march = can_march and full
         march_chunk = int(getattr(self, '_march_chunk', 512 if dense_march else 32768))   # steps per ludvm_march_run call
 
-        i = first_step
-        while i < nt:
-            if can_march and (dense_march or not self._record_row(i)):
-                j = i
-                while j < nt and (dense_march or not self._record_row(j)) and j - i < march_chunk:
-                    j += 1
-                    if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
-                        break
-                if j - i >= 2:
-                    if have_next:
-                        place = [sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1]]
-                    else:
-                        te, le = foil[i, :, -1], foil[i, :, 0]
-                        tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
-                        lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
-                        place = [tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]]
-                    (itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev) = self._march_stretch(
-                        i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed, tev_slot,
-                        lev_slot, prec_code, record=dense_march)
-                    have_next = False
-                    if self.verbose == True:  # noqa: E712
-                        for q in range(i, j):
-                            if q == 1 or q == nt - 1 or q / print_dt == int(q / print_dt):
-                                print('Step {} out of {}. Elapsed time {}'.format(q, nt - 1,
-                                                                                   timeit.default_timer() - self.start_time))
-                    if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0 and j - 1 < nt - 1:
-                        self._write_checkpoint(j, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
-                                               tev_slot, lev_slot)
-                    i = j
-                    continue
-            if (i == 1 or i == nt - 1 or i / print_dt == int(i / print_dt)) and self.verbose == True:  # noqa: E712
-                print('Step {} out of {}. Elapsed time {}'.format(i, nt - 1, timeit.default_timer() - self.start_time))
-            xg, zg = gpts[i, 0, :], gpts[i, 1, :]
-            te, le = foil[i, :, -1], foil[i, :, 0]
+        try:
+            i = first_step
+            while i < nt:
+                if can_march and (dense_march or not self._record_row(i)):
+                    j = i
+                    while j < nt and (dense_march or not self._record_row(j)) and j - i < march_chunk:
+                        j += 1
+                        if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
+                            break
+                    if j - i >= 2:
+                        if have_next:
+                            place = [sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1]]
+                        else:
+                            te, le = foil[i, :, -1], foil[i, :, 0]
+                            tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
+                            lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
+                            place = [tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]]
+                        (itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev) = self._march_stretch(
+                            i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed, tev_slot,
+                            lev_slot, prec_code, record=dense_march)
+                        have_next = False
+                        if self.verbose == True:  # noqa: E712
+                            for q in range(i, j):
+                                if q == 1 or q == nt - 1 or q / print_dt == int(q / print_dt):
+                                    print('Step {} out of {}. Elapsed time {}'.format(q, nt - 1,
+                                                                                       timeit.default_timer() - self.start_time))
+                        if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0 and j - 1 < nt - 1:
+                            self._write_checkpoint(j, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
+                                                   tev_slot, lev_slot)
+                        i = j
+                        continue
+                if (i == 1 or i == nt - 1 or i / print_dt == int(i / print_dt)) and self.verbose == True:  # noqa: E712
+                    print('Step {} out of {}. Elapsed time {}'.format(i, nt - 1, timeit.default_timer() - self.start_time))
+                xg, zg = gpts[i, 0, :], gpts[i, 1, :]
+                te, le = foil[i, :, -1], foil[i, :, 0]
 
-            # new TEV: first one half a step behind the initial trailing edge, then 1/3 of the way
-            # from the trailing edge to the previous TEV (:672-681)
-            # candidate LEV position: only geometry and the previous LEV enter (:788-800), so it is known
-            # before the solve and its unit influence rides in the same device call as the TEV's
-            n_wake = nf + itev + ilev
-            if have_next:
-                # placed on the device right after the previous roll-up, sums already here
-                tev_xy = np.array([sb.unit[0, 0], sb.unit[1, 0]])
-                lev_xy = np.array([sb.unit[0, 1], sb.unit[1, 1]])
-            else:
-                tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
-                lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
-
-            # existing wake -> chord (T1), unit new TEV -> chord (T2), unit candidate LEV -> chord (T3):
-            # one round trip (:743-754, :924-934)
-            if have_next:
-                u1, w1, ut1, wt1, ul1, wl1 = sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1]
-            elif sb is not None:
-                sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1] = tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]
-                eng.wake_chord_sums_into(sb, n_wake, xg, zg, vc_f)
-                u1, w1, ut1, wt1, ul1, wl1 = sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1]
-            else:
-                u1, w1, uu, wu = eng.wake_chord_sums(0, n_wake, xg, zg, [tev_xy[0], lev_xy[0]], [tev_xy[1], lev_xy[1]], vc)
-                ut1, wt1, ul1, wl1 = uu[0], wu[0], uu[1], wu[1]
-            T1 = self._downwash_from(u1, w1, i)
-            ut, un = self._chord_frame(ut1, wt1, i)
-            T2 = detadx * ut - un
-            I1, I2 = T1 @ cm1, T2 @ cm1
-            kelvin = sum_tev + sum_lev + sum_free - C['IC']
-            if self.method == 'Ramesh':
-                g_tev = self._newton_tev(T1, T2, kelvin)                         # :683-739
-            elif self.method == 'Faure':
-                g_tev = -(I1 + kelvin) / (1 + I2)                                # :758-760
-            else:
-                raise ValueError("method must be 'Faure' or 'Ramesh'")
-            g_lev = 0.0
-            W = T1 + g_tev * T2
-            A = cproj @ (W / U)
-            C['bound'][itev] = I1 + g_tev * I2 if self.method == 'Faure' else U * c * pi * (A[0] + A[1] / 2)
-            self.fourier[i, 0, :] = A
-            self.fourier[i, 1, :] = (A - self.fourier[i - 1, 0, :]) / dt          # :772-773
-            self.LESP_prev[itev] = A[0]
-
-            shed = abs(A[0]) >= abs(lesp_crit)                                    # :781
-            if shed:
-                LEV_shed[i] = ilev
-                lesp_crit = -abs(lesp_crit) if A[0] < 0 else abs(lesp_crit)       # :802-805
-                ult, uln = self._chord_frame(ul1, wl1, i)
-                T3 = detadx * ult - uln
-                I3 = T3 @ cm1
-                J1, J2, J3 = (-1 / pi * (T @ wq) for T in (T1, T2, T3))
-                if self.method == 'Ramesh':
-                    g_tev, g_lev = self._newton_tev_lev(T1, T2, T3, kelvin, lesp_crit, g_tev)   # :807-914
+                # new TEV: first one half a step behind the initial trailing edge, then 1/3 of the way
+                # from the trailing edge to the previous TEV (:672-681)
+                # candidate LEV position: only geometry and the previous LEV enter (:788-800), so it is known
+                # before the solve and its unit influence rides in the same device call as the TEV's
+                n_wake = nf + itev + ilev
+                if have_next:
+                    # placed on the device right after the previous roll-up, sums already here
+                    tev_xy = np.array([sb.unit[0, 0], sb.unit[1, 0]])
+                    lev_xy = np.array([sb.unit[0, 1], sb.unit[1, 1]])
                 else:
-                    g_tev, g_lev = np.linalg.solve(np.array([[1 + I2, 1 + I3], [J2, J3]]),
-                                                   np.array([-(I1 + kelvin), lesp_crit - J1]))  # :944-954
-                W = T1 + g_tev * T2 + g_lev * T3
-                A = cproj @ (W / U)
-                if self.method == 'Faure':
-                    C['bound'][itev] = I1 + g_tev * I2 + g_lev * I3
-                    A[0] = J1 + g_tev * J2 + g_lev * J3                           # :959
-                else:
-                    C['bound'][itev] = U * c * pi * (A[0] + A[1] / 2)
-                self.fourier[i, 0, :] = A       # derivatives keep their pre-LEV values (:963-966)
-                C['LEV'][ilev] = g_lev
-            C['TEV'][itev] = g_tev
-            self.LESP[itev] = A[0]
+                    tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
+                    lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
 
-            # bound vorticity per panel (:987-1010)
-            A0, A1, A2 = A[0], A[1], A[2]
-            A0d, A1d, A2d, A3d = self.fourier[i, 1, :4]
-            gamma = 2 * U * (A0 * one_plus_cos_over_sin + A[1:] @ ssin)
-            dGamma = gamma * half_c_sin_dth
-            C['airfoil'][itev], C['gamma_airfoil'][itev] = dGamma, gamma
-            C['Gamma_airfoil'][itev] = np.cumsum(dGamma)
-
-            # loads (:1035-1090).  The tangential velocity on the chord from the full wake (incl. the
-            # new TEV/LEV with their solved circulations) follows by linearity from u1 and the unit
-            # influences already evaluated: no further pair sum.
-            uc1, wc1 = u1 + g_tev * ut1, w1 + g_tev * wt1
-            if shed:
-                uc1, wc1 = uc1 + g_lev * ul1, wc1 + g_lev * wl1
-            u, _ = self._chord_frame(uc1, wc1, i)
-            a, hd = self.alpha[i], self.h_dot[i]
-            Ueff = U * np.cos(a) + hd * np.sin(a)
-            self.Fn[i] = rho * pi * c * U * (Ueff * (A0 + 0.5 * A1) + c * (3 / 4 * A0d + 1 / 4 * A1d + 1 / 8 * A2d)) \
-                + rho * ((u * gamma) @ wx)
-            self.Fs[i] = rho * pi * c * U**2 * A0**2
-            self.L[i] = self.Fn[i] * np.cos(a) + self.Fs[i] * np.sin(a)
-            self.D[i] = self.Fn[i] * np.sin(a) - self.Fs[i] * np.cos(a)
-            self.T[i] = -self.D[i]
-            self.M[i] = self.piv * self.Fn[i] - rho * pi * c**2 * U * (
-                Ueff * (1 / 4 * A0 + 1 / 4 * A1 - 1 / 8 * A2)
-                + c * (7 / 16 * A0d + 3 / 16 * A1d + 1 / 16 * A2d - 1 / 64 * A3d)) \
-                - rho * ((u * gamma * x_gamma) @ wx)
-
-            # wake roll-up (:1095-1127): shed vortices join the resident wake, then one fused launch
-            # (wake + bound vortices -> every wake vortex, explicit Euler update on the device)
-            record = self._record_row(i)
-            new_x, new_z, new_g = [tev_xy[0]], [tev_xy[1]], [g_tev]
-            tev_slot[itev] = n_wake
-            if shed:
-                lev_slot[ilev] = n_wake + 1
-                new_x.append(lev_xy[0]); new_z.append(lev_xy[1]); new_g.append(g_lev)
-            elif record:
-                # the reference also convects LEV slot `ilev` (zero strength, at the origin) on a
-                # non-shedding step and stores it in path['LEV'][i]; reproduce that row entry
-                new_x.append(0.0); new_z.append(0.0); new_g.append(0.0)
-            n_after = n_wake + len(new_x)
-            one_trip = (not record) and sb is not None and i < nt - 1 and hasattr(eng, 'wake_step_into')
-            if not one_trip:
-                eng.wake_append(new_x, new_z, new_g)
-
-            if record:
-                have_next = False
-                eng.wake_advect(dt, xg, zg, dGamma, vc, precision=self.precision)
-                xs, zs = eng.wake_read(0, n_after)
-                row_t = np.stack([xs[tev_slot[:itev + 1]], zs[tev_slot[:itev + 1]]])
-                lslots = lev_slot[:ilev + 1] if shed else np.append(lev_slot[:ilev], n_after - 1)
-                row_l = np.stack([xs[lslots], zs[lslots]])
-                row_f = np.stack([xs[:nf], zs[:nf]])
-                if full:
-                    P['TEV'][i, :, :itev + 1] = row_t
-                    P['LEV'][i, :, :ilev + 1] = row_l
-                    P['FREE'][i] = row_f
-                else:
-                    P['TEV'].store(i, row_t)
-                    P['LEV'].store(i, row_l)
-                    P['FREE'].store(i, row_f)
-                last_tev = row_t[:, -1].copy()
-                if shed:
-                    last_lev = row_l[:, -1].copy()
-                elif len(new_x) == 2:
-                    eng.wake_truncate(n_after - 1)   # drop the phantom LEV slot
-            else:
-                # only the newest TEV / LEV come back: they place the next ones (:680-681, :797-798)
-                k = 2 if shed else 1
-                have_next = False
-                if one_trip:
-                    # append of the shed vortices + roll-up of this step + placement and chord sums of the
-                    # next one: one packed upload, one download
-                    eng.wake_step_into(sb, np.array(new_x), np.array(new_z), np.array(new_g, dtype=float), dt_f, xg, zg,
-                                       dGamma, vc_f, prec_code, np.ascontiguousarray(foil[i + 1, :, -1]),
-                                       np.ascontiguousarray(foil[i + 1, :, 0]), shed, k, gpts[i + 1, 0, :],
-                                       gpts[i + 1, 1, :])
-                    xs, zs = sb.tail[0], sb.tail[1]
-                    have_next = True
+                # existing wake -> chord (T1), unit new TEV -> chord (T2), unit candidate LEV -> chord (T3):
+                # one round trip (:743-754, :924-934)
+                if have_next:
+                    u1, w1, ut1, wt1, ul1, wl1 = sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1]
                 elif sb is not None:
-                    eng.wake_advect_tail_into(sb, dt_f, xg, zg, dGamma, vc_f, k, prec_code)
-                    xs, zs = sb.tail[0], sb.tail[1]
+                    sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1] = tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]
+                    eng.wake_chord_sums_into(sb, n_wake, xg, zg, vc_f)
+                    u1, w1, ut1, wt1, ul1, wl1 = sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1]
                 else:
-                    xs, zs = eng.wake_advect_tail(dt, xg, zg, dGamma, vc, k, precision=self.precision)
-                last_tev = np.array([xs[0], zs[0]])
-                if shed:
-                    last_lev = np.array([xs[1], zs[1]])
+                    u1, w1, uu, wu = eng.wake_chord_sums(0, n_wake, xg, zg, [tev_xy[0], lev_xy[0]], [tev_xy[1], lev_xy[1]], vc)
+                    ut1, wt1, ul1, wl1 = uu[0], wu[0], uu[1], wu[1]
+                T1 = self._downwash_from(u1, w1, i)
+                ut, un = self._chord_frame(ut1, wt1, i)
+                T2 = detadx * ut - un
+                I1, I2 = T1 @ cm1, T2 @ cm1
+                kelvin = sum_tev + sum_lev + sum_free - C['IC']
+                if self.method == 'Ramesh':
+                    g_tev = self._newton_tev(T1, T2, kelvin)                         # :683-739
+                elif self.method == 'Faure':
+                    g_tev = -(I1 + kelvin) / (1 + I2)                                # :758-760
+                else:
+                    raise ValueError("method must be 'Faure' or 'Ramesh'")
+                g_lev = 0.0
+                W = T1 + g_tev * T2
+                A = cproj @ (W / U)
+                C['bound'][itev] = I1 + g_tev * I2 if self.method == 'Faure' else U * c * pi * (A[0] + A[1] / 2)
+                self.fourier[i, 0, :] = A
+                self.fourier[i, 1, :] = (A - self.fourier[i - 1, 0, :]) / dt          # :772-773
+                self.LESP_prev[itev] = A[0]
 
-            sum_tev += g_tev
-            self.ilev, self.itev, self.LEV_shed = ilev, itev, LEV_shed
-            if shed:
-                sum_lev += g_lev
-                ilev += 1
-            itev += 1
-            if self.checkpoint_every and i % self.checkpoint_every == 0 and i < nt - 1:
-                self._write_checkpoint(i + 1, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
-                                       tev_slot, lev_slot)
-            i += 1
-        if self._shard is not None:
-            self._shard.detach(eng)
+                shed = abs(A[0]) >= abs(lesp_crit)                                    # :781
+                if shed:
+                    LEV_shed[i] = ilev
+                    lesp_crit = -abs(lesp_crit) if A[0] < 0 else abs(lesp_crit)       # :802-805
+                    ult, uln = self._chord_frame(ul1, wl1, i)
+                    T3 = detadx * ult - uln
+                    I3 = T3 @ cm1
+                    J1, J2, J3 = (-1 / pi * (T @ wq) for T in (T1, T2, T3))
+                    if self.method == 'Ramesh':
+                        g_tev, g_lev = self._newton_tev_lev(T1, T2, T3, kelvin, lesp_crit, g_tev)   # :807-914
+                    else:
+                        g_tev, g_lev = np.linalg.solve(np.array([[1 + I2, 1 + I3], [J2, J3]]),
+                                                       np.array([-(I1 + kelvin), lesp_crit - J1]))  # :944-954
+                    W = T1 + g_tev * T2 + g_lev * T3
+                    A = cproj @ (W / U)
+                    if self.method == 'Faure':
+                        C['bound'][itev] = I1 + g_tev * I2 + g_lev * I3
+                        A[0] = J1 + g_tev * J2 + g_lev * J3                           # :959
+                    else:
+                        C['bound'][itev] = U * c * pi * (A[0] + A[1] / 2)
+                    self.fourier[i, 0, :] = A       # derivatives keep their pre-LEV values (:963-966)
+                    C['LEV'][ilev] = g_lev
+                C['TEV'][itev] = g_tev
+                self.LESP[itev] = A[0]
+
+                # bound vorticity per panel (:987-1010)
+                A0, A1, A2 = A[0], A[1], A[2]
+                A0d, A1d, A2d, A3d = self.fourier[i, 1, :4]
+                gamma = 2 * U * (A0 * one_plus_cos_over_sin + A[1:] @ ssin)
+                dGamma = gamma * half_c_sin_dth
+                C['airfoil'][itev], C['gamma_airfoil'][itev] = dGamma, gamma
+                C['Gamma_airfoil'][itev] = np.cumsum(dGamma)
+
+                # loads (:1035-1090).  The tangential velocity on the chord from the full wake (incl. the
+                # new TEV/LEV with their solved circulations) follows by linearity from u1 and the unit
+                # influences already evaluated: no further pair sum.
+                uc1, wc1 = u1 + g_tev * ut1, w1 + g_tev * wt1
+                if shed:
+                    uc1, wc1 = uc1 + g_lev * ul1, wc1 + g_lev * wl1
+                u, _ = self._chord_frame(uc1, wc1, i)
+                a, hd = self.alpha[i], self.h_dot[i]
+                Ueff = U * np.cos(a) + hd * np.sin(a)
+                self.Fn[i] = rho * pi * c * U * (Ueff * (A0 + 0.5 * A1) + c * (3 / 4 * A0d + 1 / 4 * A1d + 1 / 8 * A2d)) \
+                    + rho * ((u * gamma) @ wx)
+                self.Fs[i] = rho * pi * c * U**2 * A0**2
+                self.L[i] = self.Fn[i] * np.cos(a) + self.Fs[i] * np.sin(a)
+                self.D[i] = self.Fn[i] * np.sin(a) - self.Fs[i] * np.cos(a)
+                self.T[i] = -self.D[i]
+                self.M[i] = self.piv * self.Fn[i] - rho * pi * c**2 * U * (
+                    Ueff * (1 / 4 * A0 + 1 / 4 * A1 - 1 / 8 * A2)
+                    + c * (7 / 16 * A0d + 3 / 16 * A1d + 1 / 16 * A2d - 1 / 64 * A3d)) \
+                    - rho * ((u * gamma * x_gamma) @ wx)
+
+                # wake roll-up (:1095-1127): shed vortices join the resident wake, then one fused launch
+                # (wake + bound vortices -> every wake vortex, explicit Euler update on the device)
+                record = self._record_row(i)
+                new_x, new_z, new_g = [tev_xy[0]], [tev_xy[1]], [g_tev]
+                tev_slot[itev] = n_wake
+                if shed:
+                    lev_slot[ilev] = n_wake + 1
+                    new_x.append(lev_xy[0]); new_z.append(lev_xy[1]); new_g.append(g_lev)
+                elif record:
+                    # the reference also convects LEV slot `ilev` (zero strength, at the origin) on a
+                    # non-shedding step and stores it in path['LEV'][i]; reproduce that row entry
+                    new_x.append(0.0); new_z.append(0.0); new_g.append(0.0)
+                n_after = n_wake + len(new_x)
+                one_trip = (not record) and sb is not None and i < nt - 1 and hasattr(eng, 'wake_step_into')
+                if not one_trip:
+                    eng.wake_append(new_x, new_z, new_g)
+
+                if record:
+                    have_next = False
+                    eng.wake_advect(dt, xg, zg, dGamma, vc, precision=self.precision)
+                    xs, zs = eng.wake_read(0, n_after)
+                    row_t = np.stack([xs[tev_slot[:itev + 1]], zs[tev_slot[:itev + 1]]])
+                    lslots = lev_slot[:ilev + 1] if shed else np.append(lev_slot[:ilev], n_after - 1)
+                    row_l = np.stack([xs[lslots], zs[lslots]])
+                    row_f = np.stack([xs[:nf], zs[:nf]])
+                    if full:
+                        P['TEV'][i, :, :itev + 1] = row_t
+                        P['LEV'][i, :, :ilev + 1] = row_l
+                        P['FREE'][i] = row_f
+                    else:
+                        P['TEV'].store(i, row_t)
+                        P['LEV'].store(i, row_l)
+                        P['FREE'].store(i, row_f)
+                    last_tev = row_t[:, -1].copy()
+                    if shed:
+                        last_lev = row_l[:, -1].copy()
+                    elif len(new_x) == 2:
+                        eng.wake_truncate(n_after - 1)   # drop the phantom LEV slot
+                else:
+                    # only the newest TEV / LEV come back: they place the next ones (:680-681, :797-798)
+                    k = 2 if shed else 1
+                    have_next = False
+                    if one_trip:
+                        # append of the shed vortices + roll-up of this step + placement and chord sums of the
+                        # next one: one packed upload, one download
+                        eng.wake_step_into(sb, np.array(new_x), np.array(new_z), np.array(new_g, dtype=float), dt_f, xg, zg,
+                                           dGamma, vc_f, prec_code, np.ascontiguousarray(foil[i + 1, :, -1]),
+                                           np.ascontiguousarray(foil[i + 1, :, 0]), shed, k, gpts[i + 1, 0, :],
+                                           gpts[i + 1, 1, :])
+                        xs, zs = sb.tail[0], sb.tail[1]
+                        have_next = True
+                    elif sb is not None:
+                        eng.wake_advect_tail_into(sb, dt_f, xg, zg, dGamma, vc_f, k, prec_code)
+                        xs, zs = sb.tail[0], sb.tail[1]
+                    else:
+                        xs, zs = eng.wake_advect_tail(dt, xg, zg, dGamma, vc, k, precision=self.precision)
+                    last_tev = np.array([xs[0], zs[0]])
+                    if shed:
+                        last_lev = np.array([xs[1], zs[1]])
+
+                sum_tev += g_tev
+                self.ilev, self.itev, self.LEV_shed = ilev, itev, LEV_shed
+                if shed:
+                    sum_lev += g_lev
+                    ilev += 1
+                itev += 1
+                if self.checkpoint_every and i % self.checkpoint_every == 0 and i < nt - 1:
+                    self._write_checkpoint(i + 1, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
+                                           tev_slot, lev_slot)
+                i += 1
+        finally:
+            if self._shard is not None:
+                self._shard.detach(eng)
         return None
 
     def _march_stretch(self, i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
