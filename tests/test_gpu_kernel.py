@@ -266,6 +266,43 @@ def test_grid_patch_kernel_equals_the_row_kernel_bit_for_bit():
         assert (a[2] is None and b[2] is None) or np.array_equal(a[2], b[2])
 
 
+def test_flowfield_row_blocks_are_bitwise_the_full_grid(eng):
+    """ludvm_flowfield_rows_f32: any block of rows -- one row, ragged blocks, the grid's own edges -- is bit for bit what
+    the whole-grid call returns for those rows, velocity and vorticity (halo rows are evaluated internally; the grid's
+    first and last row keep the reference's one-sided differences, LUDVM.py:1233-1248)."""
+    rng = np.random.default_rng(23)
+    ns, nx, nz = 4000, 37, 44
+    xs, zs, g = rng.uniform(-10, 0, ns) - 15.0, rng.uniform(-2, 2, ns), rng.standard_normal(ns) / 50
+    args = (-25.0, -2.0, 0.07, nx, nz)
+    u, w, ome = eng.flowfield_rows(*args, 0, nx, g, xs, zs, 0.065)
+    uf, wf, of = eng.flowfield_vorticity(*args, g, xs, zs, 0.065)
+    assert np.array_equal(u, uf) and np.array_equal(w, wf) and np.array_equal(ome, of)
+    for first, count in ((0, 1), (0, 5), (5, 1), (6, 13), (19, 17), (36, 1), (30, 7), (12, 0)):
+        ub, wb, ob = eng.flowfield_rows(*args, first, count, g, xs, zs, 0.065)
+        assert ub.shape == (count, nz)
+        assert np.array_equal(ub, u[first:first + count]) and np.array_equal(wb, w[first:first + count])
+        assert np.array_equal(ob, ome[first:first + count]), (first, count)
+    ub, wb, ob = eng.flowfield_rows(*args, 3, 4, g, xs, zs, 0.065, vorticity=False)
+    assert ob is None and np.array_equal(ub, u[3:7])
+    with pytest.raises(Exception):
+        eng.flowfield_rows(*args, 30, 8, g, xs, zs, 0.065)        # rows outside the grid
+
+
+def test_self_interaction_calls_small_and_large_through_the_host_entry(eng):
+    """LUDVM.induced_velocity called with the same arrays as sources and targets (what the reference's roll-up passes,
+    LUDVM.py:1105): uploaded once; small calls take the packed path, large ones the symmetric kernel; every precision
+    against the oracle, and repeated calls return the same bits."""
+    rng = np.random.default_rng(29)
+    for n, tol32 in ((700, 1e-5), (30000, 1e-5)):
+        x, z, g = rng.uniform(-10, 0, n) - 30.0, rng.uniform(-2, 2, n), rng.standard_normal(n) / n
+        ur, wr = c_oracle.induced_velocity(g, x, z, x, z, 0.065)
+        for prec, tol in (("f32", tol32), ("f32x2", 1e-5), ("f64", 1e-12)):
+            u, w = eng.induce(g, x, z, x, z, 0.065, precision=prec)
+            assert _rel(u, w, ur, wr) < tol, (n, prec)
+            u2, w2 = eng.induce(g, x, z, x, z, 0.065, precision=prec)
+            assert np.array_equal(u, u2) and np.array_equal(w, w2), (n, prec)
+
+
 def test_flowfield_over_a_far_wake_keeps_1e5(eng):
     """The reference evaluates flowfield in float64 (LUDVM.py:1206, :1216-1217).  Over a config-2 wake -- |x| ~ 50,
     vortices 1e-3 apart, v_core = 1.3e-3 -- plain fp32 coordinates lose three digits; the host entry

@@ -183,6 +183,39 @@ def test_wake_advect_late_time_wake_keeps_1e5_in_fp32(eng, layout):
         eng.set_symmetric(1)
 
 
+def test_wake_write_keeps_the_local_origin_mirrors_consistent(eng):
+    """ludvm_wake_write moves vortices under the roll-up's feet (positions of an arbitrary range, circulations of
+    another): the fp32 mirrors of every origin block it touches are rebuilt -- the next roll-up in 'f32' (offsets from
+    block origins) and 'f32x2' equals the oracle on the edited wake, symmetric and direct kernel."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(44)
+    n = 20000
+    x = -40.0 + np.sort(rng.uniform(0, 20, n))
+    z = 0.2 * np.sin(x) + 1e-3 * rng.standard_normal(n)
+    g = rng.standard_normal(n) * 1e-3
+    x2, z2, g2 = x.copy(), z.copy(), g.copy()
+    x2[700:1300] += 0.37                      # a range that starts and ends inside origin blocks
+    z2[700:1300] -= 0.11
+    g2[5000:5003] = [0.5, -0.25, 0.125]
+    x2[128] = -12.0                           # the middle vortex of block 0: its origin moves with it
+    ur, wr = c_oracle.induced_velocity(g2, x2, z2, x2, z2, 1.3e-3)
+    scale = max(np.abs(ur).max(), np.abs(wr).max())
+    try:
+        for mode in (1, 0):
+            eng.set_symmetric(mode)
+            for prec, tol in (("f32", 2e-5), ("f32x2", 2e-6)):
+                eng.wake_clear()
+                eng.wake_append(x, z, g)
+                eng.wake_write(700, x=x2[700:1300], z=z2[700:1300])
+                eng.wake_write(5000, gamma=g2[5000:5003])
+                eng.wake_write(128, x=[x2[128]])
+                u, w = eng.wake_advect(1e-3, [], [], [], 1.3e-3, precision=prec, return_velocity=True)
+                err = max(np.abs(u - ur).max(), np.abs(w - wr).max()) / scale
+                assert err < tol, (mode, prec, err)
+    finally:
+        eng.set_symmetric(1)
+
+
 def test_resident_wake_roll_up_repeats_bit_for_bit(eng):
     """Two roll-up steps from the same state give the same bits in every precision and with either kernel: the direct
     kernel sums its partial slabs in a fixed order, the symmetric kernel accumulates in 64-bit fixed point (integer
