@@ -15,6 +15,9 @@ Fixture groups:
   G4 flowfield        -- coarse grid at three time steps (LUDVM.py:1186-1298).
   G5 variants         -- method='Ramesh', user free vortices, alpha_m != 0.
   G6 generators       -- the deterministic free-vortex cloud builders (LUDVM.py:53-96).
+  G7 config-2 regime  -- BASELINE config 2's parameters (dt = 1e-3, v_core = 1.3e-3) run by the reference itself for the
+                         first 1500 steps (the full 50 000 do not fit its dense history): loads, circulations, LESP, the
+                         onset of LEV shedding (step 1335) and three wake rows.
 G2-G5 run the unmodified reference class with oracle/airfoils_standin on sys.path (zero camber,
 valid for the symmetric NACA0012 all BASELINE configs use).
 """
@@ -222,10 +225,33 @@ def g6_generators():
     print("G6: single", xy1.shape, "lattice", xy2.shape)
 
 
+def g7_config2_regime():
+    """The reference at config 2's parameters over the first 1500 steps (LUDVM.py:597-1171 at dt = 1e-3)."""
+    import time
+    kw = dict(CONFIG1, dt=1e-3, tf=1.5)
+    t0 = time.time()
+    sim = run_reference(kw)
+    shed = sim.LEV_shed != -1
+    d = dict(nt=sim.nt, itev=sim.itev, ilev=sim.ilev, v_core=sim.v_core, Cl=sim.Cl, Cd=sim.Cd, Cm=sim.Cm, LESP=sim.LESP,
+             LEV_shed=sim.LEV_shed, circ_TEV=sim.circulation["TEV"], circ_LEV=sim.circulation["LEV"],
+             circ_bound=sim.circulation["bound"], circ_IC=float(sim.circulation["IC"]), fourier4=sim.fourier[:, :, :4],
+             first_lev_step=int(np.argmax(shed)) if shed.any() else -1)
+    for s_ in (300, 1000, 1500):
+        d[f"TEV_{s_}"] = sim.path["TEV"][s_][:, :s_ + 1]
+        d[f"LEV_{s_}"] = sim.path["LEV"][s_][:, :max(1, sim.ilev + 1)]
+    np.savez_compressed(os.path.join(OUT, "g7_config2_first1500.npz"), **d)
+    print("G7: nt", sim.nt, "itev", sim.itev, "ilev", sim.ilev, "first LEV at step", d["first_lev_step"],
+          "reference wall %.0f s" % (time.time() - t0))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":
+        g7_config2_regime()
+        sys.exit(0)
     g1_kernel_kats()
     g2_g3_g4_config1()
     g5_variants()
     g6_generators()
+    g7_config2_regime()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("total fixture bytes:", tot)
