@@ -530,6 +530,48 @@ def test_symmetric_tile_ring_partition(eng, ranks, n):
         eng.set_stream(None)
 
 
+@pytest.mark.parametrize("gscale", [1e-18, 1.0, 1e9])
+def test_symmetric_kernel_fixed_point_scale_follows_the_circulations(eng, gscale):
+    """The fixed-point scale is derived from sum|Gamma| / v_core per launch, so circulations of any magnitude -- and a
+    mix of one dominant vortex with many weak ones -- keep fp32 accuracy: 1e-5 of max|u| against the oracle, and the weak
+    vortices' own contribution (the field with the dominant one removed) is still resolved to 1e-3 of ITS maximum
+    wherever fp32 itself can resolve it."""
+    import torch
+    n = 40000
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-10, 0, n).astype(np.float32)
+    z = rng.uniform(-2, 2, n).astype(np.float32)
+    g = (rng.standard_normal(n) / n * gscale).astype(np.float32)
+    big = g.copy()
+    big[123] = np.float32(1e4 * np.abs(g).max())           # one vortex 10^4 times stronger than any other
+    dev = torch.device("cuda", 0)
+    dx, dz = torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev)
+    du, dw = torch.empty_like(dx), torch.empty_like(dx)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    sel = np.r_[0:200, rng.choice(n, 300, replace=False)]
+    try:
+        out = {}
+        for name, gam in (("plain", g), ("dominant", big)):
+            dg = torch.from_numpy(gam).to(dev)
+            eng.induce_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, dx.data_ptr(), dz.data_ptr(), n, 0.065,
+                           du.data_ptr(), dw.data_ptr())
+            torch.cuda.synchronize()
+            u, w = du.cpu().numpy().astype(np.float64), dw.cpu().numpy().astype(np.float64)
+            ur, wr = c_oracle.induced_velocity(gam.astype(float), x.astype(float), z.astype(float), x[sel].astype(float),
+                                               z[sel].astype(float), 0.065)
+            assert np.isfinite(u).all() and _rel(u[sel], w[sel], ur, wr) < 1e-5, name
+            out[name] = (u[sel], w[sel], ur, wr)
+        # what the weak vortices contribute, recovered from the two fields by linearity
+        g1 = np.zeros(n); g1[123] = float(big[123]) - float(g[123])
+        u1, w1 = c_oracle.induced_velocity(g1, x.astype(float), z.astype(float), x[sel].astype(float), z[sel].astype(float), 0.065)
+        weak_u = out["dominant"][0] - u1
+        scale = np.abs(out["plain"][2]).max()
+        far = np.abs(u1) < 50 * scale              # targets where fp32 itself can still resolve the weak part
+        assert far.sum() > 50 and np.abs(weak_u[far] - out["plain"][2][far]).max() < 1e-3 * scale
+    finally:
+        eng.set_stream(None)
+
+
 def test_symmetric_kernel_propagates_nan_like_the_reference(eng):
     """A NaN source position poisons the sum at every target in the reference (LUDVM.py:565-569); the fixed-point
     accumulators cannot hold a NaN, so the launch counts non-finite partial sums and the finisher returns NaN."""

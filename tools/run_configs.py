@@ -59,6 +59,8 @@ def cfg5(args):
 def cfg2(args):
     from ludvm_amd import LUDVM, Engine
     eng = Engine(0)
+    if args.sym_threshold:
+        eng.set_symmetric(args.sym_threshold)
     eng.kernel_timing(not args.no_timing)    # per-launch events (two per pair-kernel launch)
     t0 = time.perf_counter()
     sim = LUDVM(t0=0, tf=args.tf, dt=args.dt, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2,
@@ -93,6 +95,7 @@ if __name__ == "__main__":
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--no-march", action="store_true", help="cfg2: one device round trip per time step")
+    ap.add_argument("--sym-threshold", type=int, default=0, help="cfg2: smallest wake that takes the symmetric kernel (0 = library default)")
     ap.add_argument("--no-timing", action="store_true", help="cfg2: no per-launch timing events (kernel_ms_total reads 0)")
     a = ap.parse_args()
     {"cfg5": cfg5, "cfg2": cfg2}[a.which](a)
