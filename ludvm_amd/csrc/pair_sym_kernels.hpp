@@ -113,6 +113,41 @@ __device__ __forceinline__ float dpp_rol1(float v) {
 }
 __device__ __forceinline__ f32x2 dpp_rol1(f32x2 v) { return (f32x2){dpp_rol1(v.x), dpp_rol1(v.y)}; }
 
+// Packed targets.  A v_pk_* instruction pairs two SOURCES against one target, so the target operand is the same number
+// in both halves.  Instead of keeping every target twice ({x, x}: what hipcc does with a splat, re-made with v_mov
+// where registers run short), a register pair holds TWO different targets and op_sel / op_sel_hi broadcast the wanted
+// half: the same instruction, half the target registers.  The 512-vortex tile drops from 246 to 158 VGPRs (3 waves per
+// SIMD instead of 2); the instruction count and the speed at the headline size are unchanged, 65-100 k vortices gain
+// ~2 % (profiles/r02_packed_targets_ab.txt).  hipcc does not select these forms itself; tools/ubench/opsel_check.hip
+// pins their semantics on the hardware.
+// LUDVM_SYM_PACK=0 builds the splat form (same bits), LUDVM_SYM_OCC8 is the occupancy the T = 8 kernel is compiled for.
+#ifndef LUDVM_SYM_PACK
+#define LUDVM_SYM_PACK 1
+#endif
+#ifndef LUDVM_SYM_OCC8
+#define LUDVM_SYM_OCC8 3
+#endif
+constexpr bool kPackTargets = LUDVM_SYM_PACK != 0;
+// {p[half], p[half]} - s
+__device__ __forceinline__ f32x2 pk_sub_sel(f32x2 p, f32x2 s, int half) {
+  if (!kPackTargets) return (half ? (f32x2){p.y, p.y} : (f32x2){p.x, p.x}) - s;
+  f32x2 d;
+  if (half) asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(p), "v"(s));
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(p), "v"(s));
+  return d;
+}
+// s * {p[half], p[half]}.  `s` is the result of two v_rsq_f32: on gfx950 a VALU instruction may not read a
+// transcendental result in the very next issue slot, and the compiler's hazard pass does not look inside inline
+// assembly.  `after` must therefore be a value that ordinary code computed FROM s (the j-side strength s * gj): naming it
+// as an operand puts at least that instruction between the v_rsq and this one.
+__device__ __forceinline__ f32x2 pk_mul_sel(f32x2 s, f32x2 p, int half, f32x2 after) {
+  if (!kPackTargets) return s * (half ? (f32x2){p.y, p.y} : (f32x2){p.x, p.x});
+  f32x2 d;
+  if (half) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(s), "v"(p), "v"(after));
+  else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(s), "v"(p), "v"(after));
+  return d;
+}
+
 // Slab helpers: a wave's LDS slab holds T floats per home lane and component, as T/4 planes of
 // [64 home lanes][4 floats]: every ds_read_b128 / ds_write_b128 of a wave then covers 64 consecutive
 // 16-byte slots (conflict-free); `home4` is 4 * home lane.
@@ -149,7 +184,7 @@ __device__ __forceinline__ void slab_load(const float* l, int home4, f32x2 (&out
 // RED = false (the 512-vortex tile, whose register budget has no room for it, and R = 1): every wave adds its own
 // partial sums to the accumulators.
 template <int T, bool HILO = false, int R = 1, bool RED = (R > 1 && T == 4)>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T == 8 ? LUDVM_SYM_OCC8 : (R == 1 && !HILO ? 6 : 4))))
 pair_sym_f32(SymArgs a) {
   static_assert(T == 4 || T == 8, "T vortices per lane, read as T/4 ds_read_b128 per component");
   static_assert(R == 1 || R == 2 || R == 4, "waves per item");
@@ -206,8 +241,9 @@ pair_sym_f32(SymArgs a) {
   // origins a 512-vortex tile (T = 8) spans NS = 2 origin blocks: the targets are then kept once per origin block
   // of the partner tile (xq / zq[s]: referred to the origin of J's s-th block), selected by the source's block.
   constexpr int NS = T / 4;
-  f32x2 xp[T], zp[T], gp[T], au[T], aw[T], xpl[T], zpl[T];
-  f32x2 xq[NS][T], zq[NS][T];
+  // (targets 2 h and 2 h + 1 share register pair h: see kPackTargets)
+  f32x2 xp[H], zp[H], gp[H], au[T], aw[T], xpl[H], zpl[H];
+  f32x2 xq[NS][H], zq[NS][H];
   float x0[T], z0[T], g0[T], xl0[T], zl0[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -215,9 +251,13 @@ pair_sym_f32(SymArgs a) {
     const bool ok = active && i < a.n;
     x0[t] = ok ? a.x[i] : kPadPosF; z0[t] = ok ? a.z[i] : kPadPosF; g0[t] = ok ? a.g[i] : 0.0f;
     xl0[t] = (HILO && ok) ? a.xl[i] : 0.0f; zl0[t] = (HILO && ok) ? a.zl[i] : 0.0f;
-    xp[t] = (f32x2){x0[t], x0[t]}; zp[t] = (f32x2){z0[t], z0[t]}; gp[t] = (f32x2){g0[t], g0[t]};
-    xpl[t] = (f32x2){xl0[t], xl0[t]}; zpl[t] = (f32x2){zl0[t], zl0[t]};
     au[t] = (f32x2){0.f, 0.f}; aw[t] = (f32x2){0.f, 0.f};
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    xp[h] = (f32x2){x0[2 * h], x0[2 * h + 1]}; zp[h] = (f32x2){z0[2 * h], z0[2 * h + 1]};
+    gp[h] = (f32x2){g0[2 * h], g0[2 * h + 1]};
+    xpl[h] = (f32x2){xl0[2 * h], xl0[2 * h + 1]}; zpl[h] = (f32x2){zl0[2 * h], zl0[2 * h + 1]};
   }
   const f32x2 vc4 = {a.vc4, a.vc4};
   const float fxs = a.scale->scale;
@@ -235,8 +275,8 @@ pair_sym_f32(SymArgs a) {
     for (int t = 0; t < T; ++t) {
       // diagonal tile: block t / 4 of I against block q of I
       const float ddx = oix[t / 4] - oix[q], ddz = oiz[t / 4] - oiz[q];
-      xq[q][t] = (f32x2){x0[t] + ddx, x0[t] + ddx};
-      zq[q][t] = (f32x2){z0[t] + ddz, z0[t] + ddz};
+      if (t & 1) { xq[q][t / 2].y = x0[t] + ddx; zq[q][t / 2].y = z0[t] + ddz; }
+      else { xq[q][t / 2].x = x0[t] + ddx; zq[q][t / 2].x = z0[t] + ddz; }
     }
   float chk = 0.0f;   // sum of everything this lane hands to the accumulators: not finite <=> some partial is not
 
@@ -256,9 +296,9 @@ pair_sym_f32(SymArgs a) {
       for (int m = 0; m < H; ++m) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          f32x2 dx = (HILO ? xp[t] : xq[m / 2][t]) - xj[m];
-          f32x2 dz = (HILO ? zp[t] : zq[m / 2][t]) - zj[m];
-          if (HILO) { dx = dx + (xpl[t] - xjl[m]); dz = dz + (zpl[t] - zjl[m]); }
+          f32x2 dx = pk_sub_sel(HILO ? xp[t / 2] : xq[m / 2][t / 2], xj[m], t & 1);
+          f32x2 dz = pk_sub_sel(HILO ? zp[t / 2] : zq[m / 2][t / 2], zj[m], t & 1);
+          if (HILO) { dx = dx + pk_sub_sel(xpl[t / 2], xjl[m], t & 1); dz = dz + pk_sub_sel(zpl[t / 2], zjl[m], t & 1); }
           f32x2 r2 = dx * dx;
           r2 = __builtin_elementwise_fma(dz, dz, r2);
           const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
@@ -298,7 +338,8 @@ pair_sym_f32(SymArgs a) {
           for (int q = 0; q < NS; ++q) {
             const long long jb = ((J * W) >> kOriginShift) + q;
             const float xx = xi + (oix[t / 4] - a.cx[jb]), zz = zi + (oiz[t / 4] - a.cz[jb]);
-            xq[q][t] = (f32x2){xx, xx}; zq[q][t] = (f32x2){zz, zz};
+            if (t & 1) { xq[q][t / 2].y = xx; zq[q][t / 2].y = zz; }
+            else { xq[q][t / 2].x = xx; zq[q][t / 2].x = zz; }
           }
         }
       }
@@ -330,15 +371,15 @@ pair_sym_f32(SymArgs a) {
         for (int m = 0; m < H; ++m) {
 #pragma unroll
           for (int t = 0; t < T; ++t) {
-            f32x2 dx = (HILO ? xp[t] : xq[m / 2][t]) - xj[m];
-            f32x2 dz = (HILO ? zp[t] : zq[m / 2][t]) - zj[m];
-            if (HILO) { dx = dx + (xpl[t] - xjl[m]); dz = dz + (zpl[t] - zjl[m]); }
+            f32x2 dx = pk_sub_sel(HILO ? xp[t / 2] : xq[m / 2][t / 2], xj[m], t & 1);
+            f32x2 dz = pk_sub_sel(HILO ? zp[t / 2] : zq[m / 2][t / 2], zj[m], t & 1);
+            if (HILO) { dx = dx + pk_sub_sel(xpl[t / 2], xjl[m], t & 1); dz = dz + pk_sub_sel(zpl[t / 2], zjl[m], t & 1); }
             f32x2 r2 = dx * dx;
             r2 = __builtin_elementwise_fma(dz, dz, r2);
             const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
             const f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
             const f32x2 sj = s * gj[m];      // strength of j acting on i
-            const f32x2 si = s * gp[t];      // strength of i acting on j
+            const f32x2 si = pk_mul_sel(s, gp[t / 2], t & 1, sj);  // strength of i acting on j
             au[t] = __builtin_elementwise_fma(dz, sj, au[t]);
             aw[t] = __builtin_elementwise_fma(dx, sj, aw[t]);
             bu[m] = __builtin_elementwise_fma(dz, si, bu[m]);
@@ -378,9 +419,8 @@ pair_sym_f32(SymArgs a) {
       __syncthreads();
       if (valid) {
         // the R waves of the item share the 2 T components; each adds the R partials in wave order
-#pragma unroll
-        for (int c = 0; c < 2 * T; ++c) {
-          if (c % R != r) continue;
+#pragma unroll 1
+        for (int c = r; c < 2 * T; c += R) {
           float v = 0.0f;
 #pragma unroll
           for (int q = 0; q < R; ++q) v += rb[w0 + q][c][lane];
@@ -408,9 +448,8 @@ pair_sym_f32(SymArgs a) {
     for (int t = 0; t < T; ++t) { rb[wv][2 * t][lane] = au[t].x + au[t].y; rb[wv][2 * t + 1][lane] = aw[t].x + aw[t].y; }
     __syncthreads();
     if (active) {
-#pragma unroll
-      for (int c = 0; c < 2 * T; ++c) {
-        if (c % R != r) continue;
+#pragma unroll 1
+      for (int c = r; c < 2 * T; c += R) {
         float v = 0.0f;
 #pragma unroll
         for (int q = 0; q < R; ++q) v += rb[w0 + q][c][lane];

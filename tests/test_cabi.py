@@ -113,3 +113,27 @@ def test_every_entry_point_rejects_a_null_context():
         assert rc == _ffi.E_ARG, (name, rc)
     assert lib.ludvm_last_error(None) == b"null context"
     assert lib.ludvm_create(0, None) != _ffi.OK          # null output pointer
+
+
+def test_inline_asm_keeps_clear_of_the_transcendental_hazard(tmp_path):
+    """The symmetric kernel's packed-target multiply is inline assembly (v_pk_mul_f32 with op_sel) that reads the result
+    of v_rsq_f32.  gfx950 needs one issue slot between a transcendental instruction and a VALU read of its result, and
+    the compiler's hazard pass does not look inside inline assembly (pair_sym_kernels.hpp, pk_mul_sel): check the ISA."""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "ludvm_amd", "csrc", "ludvm_hip.hip")
+    out = tmp_path / "ludvm.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
+                    "--cuda-device-only", "-S", "-o", str(out), src], check=True, capture_output=True)
+    code = [l.strip() for l in open(out) if l.strip() and not l.strip().startswith((";", "."))]
+    asm_muls = 0
+    for i, l in enumerate(code):
+        if not (l.startswith(("v_pk_mul_f32", "v_pk_add_f32")) and "op_sel" in l):
+            continue
+        asm_muls += l.startswith("v_pk_mul_f32")
+        read = set()
+        for m in re.finditer(r"v\[(\d+):(\d+)\]", l.split(",", 1)[1]):
+            read.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        prev = re.match(r"v_(rsq|rcp|sqrt|exp|log|sin|cos)_f\d+\w* v(\d+),", code[i - 1])
+        assert not (prev and int(prev.group(2)) in read), (code[i - 1], l)
+    assert asm_muls >= 100          # the check looked at the kernels it is meant for
