@@ -1,4 +1,6 @@
-"""One-off fuzz: symmetric vs direct self-interaction over random sizes (run on the GPU box)."""
+"""Fuzz: symmetric vs direct self-interaction over random sizes, for the heuristic launch geometry and for every
+(tile, waves per tile pair) instantiation of pair_sym_f32 (run on the GPU box).
+    python tools/fuzz_sym.py"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,21 +11,34 @@ rng = np.random.default_rng(12345)
 worst = 0.0
 sizes = ([16384, 16385, 16639, 16640, 40959, 40960, 40961, 41471, 41472, 98303, 98304, 98305, 98815, 98816, 99328]
          + [int(v) for v in rng.integers(16384, 100000, 40)] + [int(v) for v in rng.integers(100000, 400000, 20)])
-for n in sizes:
+variants = [(0, 0), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4)]
+worst_by = {v: 0.0 for v in variants}
+for k, n in enumerate(sizes):
     x = torch.from_numpy(rng.uniform(-10, 0, n).astype(np.float32)).to(dev)
     z = torch.from_numpy(rng.uniform(-2, 2, n).astype(np.float32)).to(dev)
     g = torch.from_numpy((rng.standard_normal(n) / n).astype(np.float32)).to(dev)
-    out = {}
-    for mode in (0, 1):
+
+    def run(mode):
         eng.set_symmetric(mode)
         u = torch.full((n,), float("nan"), device=dev); w = torch.full((n,), float("nan"), device=dev)
         eng.induce_dev(x.data_ptr(), z.data_ptr(), g.data_ptr(), n, x.data_ptr(), z.data_ptr(), n, 0.065, u.data_ptr(), w.data_ptr())
         torch.cuda.synchronize()
-        out[mode] = (u, w)
-    scale = max(float(out[0][0].abs().max()), float(out[0][1].abs().max()))
-    err = max(float((out[0][0] - out[1][0]).abs().max()), float((out[0][1] - out[1][1]).abs().max())) / scale
-    assert torch.isfinite(out[1][0]).all() and torch.isfinite(out[1][1]).all(), n
-    worst = max(worst, err)
-    if err > 1e-5:
-        print("MISMATCH", n, err)
-print("sizes", len(sizes), "worst rel diff", worst)
+        return u, w
+    eng.set_sym_tuning(0, 0)
+    ref = run(0)
+    scale = max(float(ref[0].abs().max()), float(ref[1].abs().max()))
+    # every instantiation on the boundary sizes and on every fourth random size; the heuristic one everywhere
+    for v in (variants if (k < 15 or k % 4 == 0) else variants[:1]):
+        eng.set_sym_tuning(*v)
+        a = run(1)
+        b = run(1)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), ("not reproducible", n, v)
+        err = max(float((ref[0] - a[0]).abs().max()), float((ref[1] - a[1]).abs().max())) / scale
+        assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all(), (n, v)
+        worst_by[v] = max(worst_by[v], err)
+        if err > 1e-5:
+            print("MISMATCH", n, v, err)
+    eng.set_sym_tuning(0, 0)
+worst = max(worst_by.values())
+print("sizes", len(sizes), "worst rel diff to the direct kernel", worst, {f"T{t}R{r}": f"{e:.2e}" for (t, r), e in worst_by.items()})
+sys.exit(0 if worst <= 1e-5 else 1)
