@@ -87,7 +87,12 @@ __host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_spl
   if (ys < 1) ys = 1;
   long long rs = 1;
   if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) rs = tune_rsplit;
-  else while (rs < kSymMaxRsplit && nt1 * ys * rs < kSymMinItems) rs *= 2;
+  else {
+    // the 512-vortex tile has no LDS reduction: each sharing wave issues its own 2 T atomics per lane and tile pair, and
+    // four of them cost more than the finer granularity brings (40 960 vortices: 255 us with 4, 235 us with 2)
+    const long long max_rs = T == 8 ? 2 : kSymMaxRsplit;
+    while (rs < max_rs && nt1 * ys * rs < kSymMinItems) rs *= 2;
+  }
   g.ysplit = (int)ys;
   g.rsplit = (int)rs;
   return g;
