@@ -87,12 +87,7 @@ __host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_spl
   if (ys < 1) ys = 1;
   long long rs = 1;
   if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) rs = tune_rsplit;
-  else {
-    // the 512-vortex tile has no LDS reduction: each sharing wave issues its own 2 T atomics per lane and tile pair, and
-    // four of them cost more than the finer granularity brings (40 960 vortices: 255 us with 4, 235 us with 2)
-    const long long max_rs = T == 8 ? 2 : kSymMaxRsplit;
-    while (rs < max_rs && nt1 * ys * rs < kSymMinItems) rs *= 2;
-  }
+  else while (rs < kSymMaxRsplit && nt1 * ys * rs < kSymMinItems) rs *= 2;
   g.ysplit = (int)ys;
   g.rsplit = (int)rs;
   return g;
@@ -184,12 +179,14 @@ __device__ __forceinline__ void slab_load(const float* l, int home4, f32x2 (&out
 // WORKGROUP (a workgroup holds 4 / R items).  Their partial sums -- R sets of 2 T values per lane for the J side of
 // every tile pair, and for the I side at the end -- are added through LDS in a fixed order before they go to the
 // accumulators: the atomics, whose 64-B requests at the memory side are what limits mid sizes [MI355X], are issued
-// once per item instead of once per wave.  Every wave of a workgroup runs the same number of tile-pair rounds
-// (`per`), valid or not, so the workgroup barriers inside are uniform.
-// RED = false (the 512-vortex tile, whose register budget has no room for it, and R = 1): every wave adds its own
-// partial sums to the accumulators.
-template <int T, bool HILO = false, int R = 1, bool RED = (R > 1 && T == 4)>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T == 8 ? LUDVM_SYM_OCC8 : (R == 1 && !HILO ? 6 : 4))))
+// once per item instead of once per wave.  The partial sums travel in the waves' own slabs, which are dead between two
+// tile pairs (a separate 32 KB buffer limited the 512-vortex tile to two workgroups per CU, and the compiler then
+// scheduled its rotation loop into ~300 registers: profiles/r02_packed_targets_ab.txt), at the price of a second
+// workgroup barrier per round.  Every wave of a workgroup runs the same number of tile-pair rounds (`per`), valid or
+// not, so the barriers are uniform.
+// RED = false (R = 1; hi+lo positions never use the 512-vortex tile): every wave adds its own partial sums.
+template <int T, bool HILO = false, int R = 1, bool RED = (R > 1)>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T == 8 || HILO ? LUDVM_SYM_OCC8 : (R == 1 ? 6 : 4))))
 pair_sym_f32(SymArgs a) {
   static_assert(T == 4 || T == 8, "T vortices per lane, read as T/4 ds_read_b128 per component");
   static_assert(R == 1 || R == 2 || R == 4, "waves per item");
@@ -212,8 +209,9 @@ pair_sym_f32(SymArgs a) {
   constexpr int kWaves = kBlock / 64;
   constexpr int kComp = HILO ? 5 : 3;
   __shared__ __attribute__((aligned(16))) float slab[kWaves][kComp][64 * T];
-  // partial sums of the R waves of an item (double-buffered by round)
-  __shared__ float red[RED ? 2 : 1][RED ? kWaves : 1][RED ? 2 * T : 1][RED ? 64 : 1];
+  // RED: between two tile pairs a wave's slab also carries its 2 T x 64 partial sums to the reducing waves (it is dead
+  // then; 2 T <= kComp T), component c of wave w at slab[w][0][c * 64 + lane]
+  static_assert(2 * T * 64 <= kComp * 64 * T, "partial sums fit the slab");
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: tile indices stay scalar
@@ -413,12 +411,11 @@ pair_sym_f32(SymArgs a) {
         }
       }
     } else {
-      auto& rb = red[dd & 1];
       if (valid) {
 #pragma unroll
         for (int m = 0; m < H; ++m) {
-          rb[wv][4 * m + 0][home] = bu[m].x; rb[wv][4 * m + 1][home] = bu[m].y;
-          rb[wv][4 * m + 2][home] = bw[m].x; rb[wv][4 * m + 3][home] = bw[m].y;
+          lx[(4 * m + 0) * 64 + home] = bu[m].x; lx[(4 * m + 1) * 64 + home] = bu[m].y;
+          lx[(4 * m + 2) * 64 + home] = bw[m].x; lx[(4 * m + 3) * 64 + home] = bw[m].y;
         }
       }
       __syncthreads();
@@ -428,11 +425,12 @@ pair_sym_f32(SymArgs a) {
         for (int c = r; c < 2 * T; c += R) {
           float v = 0.0f;
 #pragma unroll
-          for (int q = 0; q < R; ++q) v += rb[w0 + q][c][lane];
+          for (int q = 0; q < R; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
           const long long j = J * W + lane + 64LL * (2 * (c / 4) + (c & 1));
           if (j < a.n) { fx_add((c & 2) ? &a.acc_w[j] : &a.acc_u[j], -v, fxs); chk += v; }
         }
       }
+      __syncthreads();     // the slabs are rewritten by the next tile pair
     }
   }
 
@@ -448,16 +446,15 @@ pair_sym_f32(SymArgs a) {
       }
     }
   } else {
-    auto& rb = red[per & 1];
 #pragma unroll
-    for (int t = 0; t < T; ++t) { rb[wv][2 * t][lane] = au[t].x + au[t].y; rb[wv][2 * t + 1][lane] = aw[t].x + aw[t].y; }
+    for (int t = 0; t < T; ++t) { lx[(2 * t) * 64 + lane] = au[t].x + au[t].y; lx[(2 * t + 1) * 64 + lane] = aw[t].x + aw[t].y; }
     __syncthreads();
     if (active) {
 #pragma unroll 1
       for (int c = r; c < 2 * T; c += R) {
         float v = 0.0f;
 #pragma unroll
-        for (int q = 0; q < R; ++q) v += rb[w0 + q][c][lane];
+        for (int q = 0; q < R; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
         const long long i = I * W + lane + 64LL * (c / 2);
         if (i < a.n) { fx_add((c & 1) ? &a.acc_w[i] : &a.acc_u[i], v, fxs); chk += v; }
       }
