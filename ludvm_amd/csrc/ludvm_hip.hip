@@ -382,10 +382,10 @@ int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, i
 }
 
 constexpr long long kSymMinN = 16384;   // below this the direct kernel's launch is as fast
-// Vortices per lane of the symmetric kernel: 8 (tile 512, 2 waves/SIMD) from ~4e4 vortices up, where halving
-// the rotation / LDS-read cost per pair wins 2-7 % (with the rotation steps of a tile pair shared by two waves
-// below ~8e4); 4 (tile 256, 5 waves/SIMD) below, where more and smaller tiles balance better, and for hi+lo
-// positions (8 would not fit the register file).
+// Vortices per lane of the symmetric kernel: 8 (tile 512, 158-162 VGPRs: 3 waves/SIMD) from ~4e4 vortices up, where
+// halving the rotation / LDS-read cost per pair wins 2-7 % (with the rotation steps of a tile pair shared by two or four
+// waves below ~8e4); 4 (tile 256, 70-90 VGPRs) below, where more and smaller tiles balance better, and for hi+lo
+// positions (not instantiated for the 512-vortex tile: hi+lo is instruction-bound either way).
 constexpr long long kSymT8MinN = 40960;
 static_assert(64 * 8 == LUDVM_SYM_TILE, "the multi-GPU entry points always use the 512-vortex tile");
 
@@ -405,7 +405,7 @@ bool use_symmetric(const ludvm_ctx* c, long long n, double vc4, bool march = fal
 
 int sym_tile_t(const ludvm_ctx* c, long long n, bool hilo, bool local = false) {
   (void)local;                        // local origins fit both tiles (a 512-vortex tile keeps its targets twice)
-  if (hilo) return 4;                 // hi+lo positions: register file
+  if (hilo) return 4;                 // hi+lo positions: 256-vortex tile only
   if (c->tune_sym_t == 4 || c->tune_sym_t == 8) return c->tune_sym_t;
   return n >= kSymT8MinN ? 8 : 4;
 }
@@ -571,9 +571,15 @@ int wake_grow(ludvm_ctx* c, size_t capacity) {
   const size_t nblk = cap / kOriginBlock + 1;
   double* d64[3] = {nullptr, nullptr, nullptr};
   float* f32[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  for (auto& q : d64) HIPCHK(c, hipMalloc(&q, cap * sizeof(double)));
-  for (int k = 0; k < 7; ++k) HIPCHK(c, hipMalloc(&f32[k], cap * sizeof(float)));
-  for (int k = 7; k < 9; ++k) HIPCHK(c, hipMalloc(&f32[k], nblk * sizeof(float)));
+  hipError_t me = hipSuccess;
+  for (auto& q : d64) if (me == hipSuccess) me = hipMalloc(&q, cap * sizeof(double));
+  for (int k = 0; k < 7; ++k) if (me == hipSuccess) me = hipMalloc(&f32[k], cap * sizeof(float));
+  for (int k = 7; k < 9; ++k) if (me == hipSuccess) me = hipMalloc(&f32[k], nblk * sizeof(float));
+  if (me != hipSuccess) {      // the wake keeps its old arrays; what was obtained so far goes back
+    for (double* q : d64) if (q) (void)hipFree(q);
+    for (float* q : f32) if (q) (void)hipFree(q);
+    return fail_hip(c, "hipMalloc (wake arrays)", me);
+  }
   const size_t n = c->wake_n;
   double* o64[3] = {c->x64, c->z64, c->g64};
   float* o32[9] = {c->xh, c->xl, c->zh, c->zl, c->g32, c->xr, c->zr, c->cx, c->cz};
