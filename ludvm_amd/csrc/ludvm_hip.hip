@@ -386,7 +386,7 @@ constexpr long long kSymMinN = 16384;   // below this the direct kernel's launch
 // halving the rotation / LDS-read cost per pair wins 2-7 % (with the rotation steps of a tile pair shared by two or four
 // waves below ~8e4); 4 (tile 256, 70-90 VGPRs) below, where more and smaller tiles balance better, and for hi+lo
 // positions (not instantiated for the 512-vortex tile: hi+lo is instruction-bound either way).
-constexpr long long kSymT8MinN = 40960;
+constexpr long long kSymT8MinN = 34816;
 static_assert(64 * 8 == LUDVM_SYM_TILE, "the multi-GPU entry points always use the 512-vortex tile");
 
 // The symmetric kernel accumulates in fixed point, which needs the bound sum|Gamma| / (sqrt(2) v_core) on the raw

@@ -72,7 +72,7 @@ struct SymArgs {
 constexpr long long kSymTargetWaves = 8 * 65536;   // (I, d-chunk) work items aimed for over the whole ring
 constexpr long long kSymMaxSplit = 64;
 constexpr long long kSymMaxRsplit = 4;
-constexpr long long kSymMinItems = 9000;           // measured (profiles/r01_sym_kernel_rotation_split.txt)
+constexpr long long kSymMinItems = 10500;          // measured (profiles/r02_atomics_cost_and_lds_reduction.txt, table 4)
 struct SymGeom { long long ntiles, dmax, dtot; int ysplit, rsplit; };
 __host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_split, int tune_rsplit) {
   SymGeom g;
