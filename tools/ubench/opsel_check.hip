@@ -42,10 +42,11 @@ int main() {
   f32x2 *hp = new f32x2[n], *hs = new f32x2[n], *ho = new f32x2[4 * n];
   for (int i = 0; i < n; ++i) { hp[i] = (f32x2){(float)drand48() - 0.5f, (float)drand48() * 3.f}; hs[i] = (f32x2){(float)drand48(), -(float)drand48()}; }
   f32x2 *dp, *ds, *dout;
-  hipMalloc(&dp, n * 8); hipMalloc(&ds, n * 8); hipMalloc(&dout, 4 * n * 8);
-  hipMemcpy(dp, hp, n * 8, hipMemcpyHostToDevice); hipMemcpy(ds, hs, n * 8, hipMemcpyHostToDevice);
+  auto ok = [](hipError_t e) { if (e != hipSuccess) { printf("HIP error: %s\n", hipGetErrorString(e)); exit(2); } };
+  ok(hipMalloc(&dp, n * 8)); ok(hipMalloc(&ds, n * 8)); ok(hipMalloc(&dout, 4 * n * 8));
+  ok(hipMemcpy(dp, hp, n * 8, hipMemcpyHostToDevice)); ok(hipMemcpy(ds, hs, n * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dp, ds, dout);
-  hipMemcpy(ho, dout, 4 * n * 8, hipMemcpyDeviceToHost);
+  ok(hipMemcpy(ho, dout, 4 * n * 8, hipMemcpyDeviceToHost));
   int bad = 0;
   for (int i = 0; i < n; ++i) {
     const f32x2 p = hp[i], s = hs[i];
