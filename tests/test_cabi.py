@@ -137,3 +137,35 @@ def test_inline_asm_keeps_clear_of_the_transcendental_hazard(tmp_path):
         prev = re.match(r"v_(rsq|rcp|sqrt|exp|log|sin|cos)_f\d+\w* v(\d+),", code[i - 1])
         assert not (prev and int(prev.group(2)) in read), (code[i - 1], l)
     assert asm_muls >= 100          # the check looked at the kernels it is meant for
+
+
+def test_hot_kernels_do_not_spill():
+    """Register budget of the pair kernels as hipcc compiles them for gfx950 (no GPU needed): no scratch, and the
+    512-vortex symmetric tile within three waves per SIMD.  (A reduction buffer in LDS once pushed that kernel to ~300
+    registers with spills inside its rotation loop: profiles/r02_packed_targets_ab.txt.)"""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "ludvm_amd", "csrc", "ludvm_hip.hip")
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
+                          "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", src, "-o", os.devnull],
+                         check=True, capture_output=True, text=True).stderr
+    kernels, cur = {}, None
+    for line in out.splitlines():
+        m = re.search(r"remark:\s+(.*?) \[-Rpass", line)
+        if not m:
+            continue
+        t = m.group(1).strip()
+        if t.startswith("Function Name:"):
+            cur = t.split(":", 1)[1].strip()
+            kernels[cur] = {}
+        elif cur and ":" in t:
+            k, v = t.split(":", 1)
+            kernels[cur][k.strip()] = v.strip()
+    pair = {k: v for k, v in kernels.items() if "pair_f32" in k or "pair_sym_f32" in k or "pair_f64" in k}
+    assert len(pair) >= 30, sorted(kernels)
+    for name, r in pair.items():
+        assert int(r["ScratchSize [bytes/lane]"]) == 0 and int(r["VGPRs Spill"]) == 0 and int(r["AGPRs"]) == 0, (name, r)
+    t8 = {k: v for k, v in pair.items() if "pair_sym_f32ILi8" in k}
+    assert len(t8) == 3
+    for name, r in t8.items():
+        assert int(r["VGPRs"]) <= 168 and int(r["Occupancy [waves/SIMD]"]) >= 3, (name, r)
