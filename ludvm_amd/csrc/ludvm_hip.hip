@@ -1782,6 +1782,15 @@ int ludvm_vorticity_f32(ludvm_ctx* c, const float* u, const float* w, size_t nx,
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 
+#ifdef LUDVM_WAVE_TRACE
+int ludvm_debug_set_wave_trace(ludvm_ctx* c, unsigned long long* d_trace) {
+  if (!c) return LUDVM_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(ludvm::g_wave_trace), &d_trace, sizeof(d_trace)));
+  return LUDVM_OK;
+}
+#endif
+
 int ludvm_kernel_timing(ludvm_ctx* c, int enable) {
   if (!c) return LUDVM_E_ARG;
   c->timing = enable != 0;

@@ -185,6 +185,10 @@ __device__ __forceinline__ void slab_load(const float* l, int home4, f32x2 (&out
 // workgroup barrier per round.  Every wave of a workgroup runs the same number of tile-pair rounds (`per`), valid or
 // not, so the barriers are uniform.
 // RED = false (R = 1; hi+lo positions never use the 512-vortex tile): every wave adds its own partial sums.
+#ifdef LUDVM_WAVE_TRACE
+// measurement build only (tools/sym_wave_trace.py): every wave stores its start and end time (100 MHz clock)
+__device__ unsigned long long* g_wave_trace = nullptr;
+#endif
 template <int T, bool HILO = false, int R = 1, bool RED = (R > 1)>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T == 8 || HILO ? LUDVM_SYM_OCC8 : (R == 1 ? 6 : 4))))
 pair_sym_f32(SymArgs a) {
@@ -205,6 +209,9 @@ pair_sym_f32(SymArgs a) {
     }
     a.ysplit = gm.ysplit;
   }
+#ifdef LUDVM_WAVE_TRACE
+  const unsigned long long trace_t0 = wall_clock64();
+#endif
   constexpr int H = T / 2;
   constexpr int kWaves = kBlock / 64;
   constexpr int kComp = HILO ? 5 : 3;
@@ -461,6 +468,13 @@ pair_sym_f32(SymArgs a) {
     }
   }
   if (!(__builtin_fabsf(chk) < __builtin_inff())) atomicAdd(reinterpret_cast<unsigned long long*>(a.bad), 1ULL);
+#ifdef LUDVM_WAVE_TRACE
+  if (g_wave_trace && (threadIdx.x & 63) == 0) {
+    const long long wid = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    g_wave_trace[2 * wid] = trace_t0;
+    g_wave_trace[2 * wid + 1] = wall_clock64();
+  }
+#endif
 }
 
 // One workgroup: the fixed-point scale of a launch from sum |Gamma| (summed in a fixed order -> the same bits every

@@ -14,6 +14,8 @@ from ludvm_amd import Engine  # noqa: E402
 eng = Engine(0)
 if os.environ.get("SYM_T"):
     eng.set_sym_tuning(int(os.environ["SYM_T"]), int(os.environ.get("SYM_R", "0")))
+if os.environ.get("SYM_YS"):
+    eng.set_tuning(0, int(os.environ["SYM_YS"]))       # d-chunks per tile of the symmetric kernel (and source splits of the direct one)
 rng = np.random.default_rng(1)
 sizes = [int(a) for a in sys.argv[1:]] or [8192, 11264, 12288, 14336, 16384, 20480, 24576, 32768, 40960, 49152, 65536]
 fx, fz, fg = np.linspace(-30.9, -30.0, 80), np.zeros(80), rng.standard_normal(80) / 100
