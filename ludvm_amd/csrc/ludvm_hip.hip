@@ -6,6 +6,8 @@
 #include "pair_sym_kernels.hpp"
 #include "march_kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -1523,6 +1525,8 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   long long p_step = first_step - 1, p_n = n0;   // a finished step and the wake size after it
   long long n_before = n0;          // upper bound of the wake size before the current step's solve
   bool overlapped = false;          // the accumulators have been zeroed for the overlapped steps
+  bool fork_signalled = false;      // the previous step's finisher already signals ev_fork
+  static const bool ext_fork = [] { const char* e = std::getenv("LUDVM_MARCH_EXT_EVENTS"); return !(e && e[0] == '0'); }();
   // LUDVM_MARCH_OVERLAP=0 keeps every step serial (A/B measurements; results agree to fp32 rounding)
   const char* ov_env = std::getenv("LUDVM_MARCH_OVERLAP");
   const bool overlap_ok = !(ov_env && ov_env[0] == '0');
@@ -1586,7 +1590,8 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
         HIPCHK(c, hipMemsetAsync(acc - 2, 0, all, c->stream));
         overlapped = true;
       }
-      HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+      // (an overlapped step's finisher carries the fork event as its completion signal: no packet of its own)
+      if (!fork_signalled) HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
       HIPCHK(c, hipStreamWaitEvent(c->stream_b, c->ev_fork, 0));
       c->stream = c->stream_b;
       int rc = march_chord_launch(c, n_before);
@@ -1617,11 +1622,20 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
       CHK(launch_sym_tiles(c, T, o, nb, first, cnt, vc4, &S->n_old[s & 1], n_lo, sharded));
       if (sharded) CHK(reduce_accumulators(c, acc, nt_pad));
       HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
-      hipLaunchKernelGGL(march_finish_sym, dim3(fin_blocks(n_ub)), dim3(kFinBlock), 0, c->stream, acc, acc + nt_pad,
-                         &S->sc[s & 1], S, &S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->mir(), c->g32, td,
-                         bad_step, bad_next);
+      if (ext_fork) {
+        hipExtLaunchKernelGGL(march_finish_sym, dim3(fin_blocks(n_ub)), dim3(kFinBlock), 0, c->stream, nullptr, c->ev_fork, 0,
+                              acc, acc + nt_pad, (const SymScale*)&S->sc[s & 1], S,
+                              (const long long*)&S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->mir(), c->g32, td,
+                              bad_step, bad_next);
+        fork_signalled = true;
+      } else {
+        hipLaunchKernelGGL(march_finish_sym, dim3(fin_blocks(n_ub)), dim3(kFinBlock), 0, c->stream, acc, acc + nt_pad,
+                           &S->sc[s & 1], S, &S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->mir(), c->g32, td,
+                           bad_step, bad_next);
+      }
       HIPCHK(c, hipGetLastError());
     }
+    if (!fork) fork_signalled = false;
     n_before = n_ub;
   }
   // results: per-step rows, final state, the two newest wake vortices
