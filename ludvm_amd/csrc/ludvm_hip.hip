@@ -43,7 +43,8 @@ struct ludvm_ctx {
   int tune_split = 0;
   int sym_mode = 1;
   int tune_sym_t = 0, tune_sym_rsplit = 0;   // ludvm_set_sym_tuning (0 = heuristics)
-  int grid_kernel = 2;                       // flow-field grids: 2 = 2 x 4 patch per lane, 1 = 4 points of a row (LUDVM_GRID_KERNEL)
+  int grid_kernel = 2;                       // flow-field grids (LUDVM_GRID_KERNEL): 1 = 4 points of a row per lane; 2 = patch,
+                                             // 4 x 4 from 2^20 grid points and 2 x 4 below; 3 / 4 = always the 2 x 4 / 4 x 4 patch
   long long small_tile_max = 14000;          // direct fp32 launches with at most this many sources use 256-source tiles
   long long small_tile_max_f64 = 12000;      // fp64 launches with at most this many sources use 128-source tiles
                                              // (roll-up step 52 -> 26 us at 2400 vortices, 87 -> 72 at 8192 [MI355X])
@@ -265,13 +266,23 @@ int drain_timing(ludvm_ctx* c) {
   return LUDVM_OK;
 }
 
-// workgroups of a flow-field grid launch: 256 lanes of 4 row points, or of 2 x 4 patches
-long long grid_kernel_blocks(const ludvm_ctx* c, const PairArgs& a) {
-  if (c->grid_kernel == 2) {
-    const long long nrows = a.nt / a.grid_nz, patches = ((nrows + 1) / 2) * (a.grid_nz / 4);
+// workgroups of a flow-field grid launch: 256 lanes of 4 row points (patch_rows = 0), or of patch_rows x 4 patches
+long long grid_kernel_blocks(const PairArgs& a, int patch_rows) {
+  if (patch_rows > 0) {
+    const long long nrows = a.nt / a.grid_nz, patches = ((nrows + patch_rows - 1) / patch_rows) * (a.grid_nz / 4);
     return (patches + kBlock - 1) / kBlock;
   }
   return (a.nt + (long long)kBlock * 4 - 1) / ((long long)kBlock * 4);
+}
+
+// rows of the patch of grid points a lane owns (4 columns), 0 = the row kernel.  Every variant performs the same
+// operations on the same operands for a given grid point, so the choice never changes a result bit.
+constexpr long long kPatch4MinTargets = 1LL << 20;
+int grid_patch_rows(const ludvm_ctx* c, const PairArgs& a, const Plan& p) {
+  if (c->grid_kernel == 1) return 0;
+  if (c->grid_kernel == 3 || p.tile == kTileF32Small) return 2;       // (the 4 x 4 patch exists for 1024-source tiles)
+  if (c->grid_kernel == 4) return 4;
+  return a.nt >= kPatch4MinTargets ? 4 : 2;
 }
 
 // Launch the main pair kernel described by `a` (sources, targets and vc4 filled in by the caller)
@@ -307,8 +318,11 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
     // local-origin fp32 (LUDVM_PREC_F32 wherever the library lays the positions out itself)
     if (a.grid_nz > 0 && a.grid_nz % 4 == 0 && c->tune_tpl == 0) {
       // flow-field grid: a 2 x 4 patch (or 4 points of a row) per lane; the plan's grid is recomputed for it
-      grid = dim3((unsigned)grid_kernel_blocks(c, a), grid.y, 1);
-      if (c->grid_kernel == 2) {
+      const int prows = grid_patch_rows(c, a, p);
+      grid = dim3((unsigned)grid_kernel_blocks(a, prows), grid.y, 1);
+      if (prows == 4) {
+        hipLaunchKernelGGL((pair_f32<16, kTileF32, false, 2, true>), grid, dim3(kBlock), 0, c->stream, a);
+      } else if (prows == 2) {
         if (p.tile == kTileF32Small) hipLaunchKernelGGL((pair_f32<8, kTileF32Small, false, 2, true>), grid, dim3(kBlock), 0, c->stream, a);
         else hipLaunchKernelGGL((pair_f32<8, kTileF32, false, 2, true>), grid, dim3(kBlock), 0, c->stream, a);
       } else {
@@ -337,8 +351,11 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
     }
   } else if (a.grid_nz > 0 && a.grid_nz % 4 == 0 && c->tune_tpl == 0) {
     // flow-field grid: a 2 x 4 patch (or 4 points of a row) per lane; the plan's grid is recomputed for it
-    grid = dim3((unsigned)grid_kernel_blocks(c, a), grid.y, 1);
-    if (c->grid_kernel == 2) {
+    const int prows = grid_patch_rows(c, a, p);
+    grid = dim3((unsigned)grid_kernel_blocks(a, prows), grid.y, 1);
+    if (prows == 4) {
+      hipLaunchKernelGGL((pair_f32<16, kTileF32, false, 2>), grid, dim3(kBlock), 0, c->stream, a);
+    } else if (prows == 2) {
       if (p.tile == kTileF32Small) hipLaunchKernelGGL((pair_f32<8, kTileF32Small, false, 2>), grid, dim3(kBlock), 0, c->stream, a);
       else hipLaunchKernelGGL((pair_f32<8, kTileF32, false, 2>), grid, dim3(kBlock), 0, c->stream, a);
     } else {
@@ -645,7 +662,10 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
     return LUDVM_E_HIP;
   }
   c->stream = c->own_stream;
-  if (const char* gk = std::getenv("LUDVM_GRID_KERNEL")) c->grid_kernel = (gk[0] == 'r' || gk[0] == '1') ? 1 : 2;
+  if (const char* gk = std::getenv("LUDVM_GRID_KERNEL")) {      // row | patch | patch2 | patch4
+    const std::string k(gk);
+    c->grid_kernel = k == "row" || k == "1" ? 1 : (k == "patch2" ? 3 : (k == "patch4" ? 4 : 2));
+  }
   if (small_env) { c->small_tile_max = std::atoll(small_env); c->small_tile_max_f64 = std::min<long long>(c->small_tile_max, 12000); }
   const char* small64_env = std::getenv("LUDVM_SMALL_TILE_MAX_F64");
   if (small64_env) c->small_tile_max_f64 = std::atoll(small64_env);

@@ -106,12 +106,12 @@ __device__ __forceinline__ void grid_point(const PairArgs& a, long long p, doubl
 //               |x| ~ 50 against a vortex spacing of ~1e-3).
 // ---------------------------------------------------------------------------------------------
 // GRID = 1 (flow-field grids with nz % TPL == 0): a lane owns TPL CONSECUTIVE grid points of one
-//               row (same x, z stepping by dr), so dx and dx^2 are computed once per source pair and
-//               shared by the lane's targets: 6 + 2 / TPL instead of 8 packed ops per two pairs and target.
-// GRID = 2 (nz % (TPL / 2) == 0): a lane owns a PATCH of 2 rows x TPL / 2 columns, so dx, dx^2 are shared along each
-//               row and dz along each column: 5 + 8 / TPL packed ops (TPL = 8: 6 instead of 6.5 -> issue bound 20
-//               instead of 21 cycles per pair); the same operations on the same operands as GRID = 1, so the
-//               results are bit for bit the same.
+//               row (same x, z stepping by dr), so dx, dx^2 and Gamma dx are computed once per source pair and
+//               shared by the lane's targets.
+// GRID = 2 (nz % 4 == 0): a lane owns a PATCH of kRows x 4 grid points (TPL = 8: 2 rows, TPL = 16: 4 rows), so dx, dx^2
+//               and Gamma dx are shared along each row and dz, Gamma dz along each column: 4 + (3 kRows + 8) / TPL
+//               packed ops per two pairs and target (5.25 at 4 x 4, 5.75 at 2 x 4; 6.5 for GRID = 1, 8 for GRID = 0).
+//               The same operations on the same operands as GRID = 1, so the results are bit for bit the same.
 // LOCAL = true: positions are offsets from block origins (see kOriginShift); the targets are re-referred to the
 //               origin of each 256-source segment of the LDS tile (TPL adds per 256 sources).
 template <int TPL, int TILE, bool HILO, int GRID = 0, bool LOCAL = false>
@@ -139,19 +139,20 @@ pair_f32(PairArgs a) {
   // a launch sized from an upper bound of the target count (march): blocks without targets leave at once
   // (uniform over the block, before any barrier)
   // targets of this lane: tid, tid + 256, ... of the block's slab (GRID = 0); TPL consecutive points of a grid row
-  // (GRID = 1); or a patch of 2 rows x TPL / 2 columns (GRID = 2: patches are numbered along the row pairs)
-  constexpr int kCols = GRID == 2 ? TPL / 2 : 1;
+  // (GRID = 1); or a patch of kRows rows x 4 columns (GRID = 2: patches are numbered along the row groups)
+  constexpr int kRows = GRID == 2 ? (TPL >= 16 ? 4 : 2) : 1;
+  constexpr int kCols = GRID == 2 ? TPL / kRows : 1;
   const long long lane_id = (long long)blockIdx.x * kBlock + tid;
   const long long nzq = GRID == 2 ? a.grid_nz / kCols : 1;                   // patches per row pair
   const long long prow = GRID == 2 ? lane_id / nzq : 0, pcol = GRID == 2 ? lane_id - prow * nzq : 0;
   auto tindex = [&](int t) -> long long {
-    if (GRID == 2) return (2 * prow + t / kCols) * a.grid_nz + pcol * kCols + t % kCols;   // beyond the grid: >= nt
+    if (GRID == 2) return (kRows * prow + t / kCols) * a.grid_nz + pcol * kCols + t % kCols;   // beyond the grid: >= nt
     if (GRID == 1) return lane_id * TPL + t;
     return (long long)blockIdx.x * kBlock * TPL + tid + (long long)t * kBlock;
   };
   if (GRID == 2) {
     const long long nrows = sz.nt / a.grid_nz;
-    if ((long long)blockIdx.x * kBlock >= ((nrows + 1) / 2) * nzq) return;
+    if ((long long)blockIdx.x * kBlock >= ((nrows + kRows - 1) / kRows) * nzq) return;
   } else if ((long long)blockIdx.x * kBlock * TPL >= sz.nt) {
     return;
   }
@@ -159,7 +160,8 @@ pair_f32(PairArgs a) {
   long long s_end = s_begin + a.chunk;
   if (s_end > sz.ns) s_end = sz.ns;
 
-  f32x2 xp[TPL], zp[TPL], xpl[TPL], zpl[TPL], au[TPL], aw[TPL];
+  f32x2 xp[TPL], zp[TPL], xpl[TPL], zpl[TPL];
+  float au[TPL], aw[TPL];      // running totals (the two packed halves of a tile's sums are added when the tile is folded in)
   // LOCAL: what the targets are re-referred from -- exact grid coordinates, or offsets + origins
   double gxd[LOCAL ? TPL : 1], gzd[LOCAL ? TPL : 1];
   float tox[LOCAL ? TPL : 1], toz[LOCAL ? TPL : 1], tlx[LOCAL ? TPL : 1], tlz[LOCAL ? TPL : 1];
@@ -192,8 +194,8 @@ pair_f32(PairArgs a) {
     zp[t] = (f32x2){z, z};
     xpl[t] = (f32x2){xl, xl};
     zpl[t] = (f32x2){zl, zl};
-    au[t] = (f32x2){0.0f, 0.0f};
-    aw[t] = (f32x2){0.0f, 0.0f};
+    au[t] = 0.0f;
+    aw[t] = 0.0f;
   }
   const float vc4s = (float)a.vc4;
   const f32x2 vc4 = {vc4s, vc4s};
@@ -270,37 +272,39 @@ pair_f32(PairArgs a) {
           xl2 = h ? (f32x2){XL.z, XL.w} : (f32x2){XL.x, XL.y};
           zl2 = h ? (f32x2){ZL.z, ZL.w} : (f32x2){ZL.x, ZL.y};
         }
+        // The grid kernels weight the DIFFERENCES with the source strengths (u += (g dz) s, w += (g dx) s) instead of the
+        // kernel value (s g): g dx is shared along a row and g dz along a column, like dx, dx^2 and dz themselves.
         if (GRID == 1) {
           const f32x2 dx = xp[0] - xs2;      // every target of the lane sits in the same grid row
           const f32x2 dxx = dx * dx;
+          const f32x2 gdx = gs2 * dx;
 #pragma unroll
           for (int t = 0; t < TPL; ++t) {
             const f32x2 dz = zp[t] - zs2;
+            const f32x2 gdz = gs2 * dz;
             const f32x2 r2 = __builtin_elementwise_fma(dz, dz, dxx);
             const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
-            f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
-            s = s * gs2;
-            tu[t] = __builtin_elementwise_fma(dz, s, tu[t]);
-            tw[t] = __builtin_elementwise_fma(dx, s, tw[t]);
+            const f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+            tu[t] = __builtin_elementwise_fma(gdz, s, tu[t]);
+            tw[t] = __builtin_elementwise_fma(gdx, s, tw[t]);
           }
           continue;
         }
         if (GRID == 2) {
-          // two rows share each column's dz, kCols columns share each row's dx and dx^2
-          f32x2 dxr[2], dxxr[2], dzc[kCols];
+          // kRows rows share each column's dz and g dz, kCols columns share each row's dx, dx^2 and g dx
+          f32x2 gdxr[kRows], dxxr[kRows], dzc[kCols], gdzc[kCols];
 #pragma unroll
-          for (int r = 0; r < 2; ++r) { dxr[r] = xp[r * kCols] - xs2; dxxr[r] = dxr[r] * dxr[r]; }
+          for (int r = 0; r < kRows; ++r) { const f32x2 d = xp[r * kCols] - xs2; dxxr[r] = d * d; gdxr[r] = gs2 * d; }
 #pragma unroll
-          for (int cc = 0; cc < kCols; ++cc) dzc[cc] = zp[cc] - zs2;
+          for (int cc = 0; cc < kCols; ++cc) { dzc[cc] = zp[cc] - zs2; gdzc[cc] = gs2 * dzc[cc]; }
 #pragma unroll
           for (int t = 0; t < TPL; ++t) {
             const int r = t / kCols, cc = t % kCols;
             const f32x2 r2 = __builtin_elementwise_fma(dzc[cc], dzc[cc], dxxr[r]);
             const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
-            f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
-            s = s * gs2;
-            tu[t] = __builtin_elementwise_fma(dzc[cc], s, tu[t]);
-            tw[t] = __builtin_elementwise_fma(dxr[r], s, tw[t]);
+            const f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+            tu[t] = __builtin_elementwise_fma(gdzc[cc], s, tu[t]);
+            tw[t] = __builtin_elementwise_fma(gdxr[r], s, tw[t]);
           }
           continue;
         }
@@ -324,7 +328,7 @@ pair_f32(PairArgs a) {
     }
     }
 #pragma unroll
-    for (int t = 0; t < TPL; ++t) { au[t] = au[t] + tu[t]; aw[t] = aw[t] + tw[t]; }
+    for (int t = 0; t < TPL; ++t) { au[t] += tu[t].x + tu[t].y; aw[t] += tw[t].x + tw[t].y; }
   }
 
   const float scale = (float)kInv2PiD;
@@ -332,8 +336,8 @@ pair_f32(PairArgs a) {
   for (int t = 0; t < TPL; ++t) {
     const long long ti = tindex(t);
     if (ti < sz.nt) {
-      const float uu = (au[t].x + au[t].y) * scale;
-      const float ww = -(aw[t].x + aw[t].y) * scale;
+      const float uu = au[t] * scale;
+      const float ww = -aw[t] * scale;
       if (gridDim.y == 1) {
         static_cast<float*>(a.u)[ti] = uu;
         static_cast<float*>(a.w)[ti] = ww;

@@ -236,16 +236,16 @@ def test_flowfield_grid_and_vorticity(eng):
         eng.vorticity(u[:1], w[:1], dr)
 
 
-def test_grid_patch_kernel_equals_the_row_kernel_bit_for_bit():
-    """Flow-field grids run with a 2 x 4 patch of grid points per lane (dx, dx^2 shared along each row, dz along each
-    column: 6 instead of 6.5 packed operations per two pairs and target); LUDVM_GRID_KERNEL=row selects the previous
-    kernel (4 points of one row per lane).  Same operations on the same operands in the same order -> the same bits,
-    for even and odd row counts, one and several source splits, plain and local-origin sources."""
+def test_grid_patch_kernels_equal_the_row_kernel_bit_for_bit():
+    """Flow-field grids run with a patch of grid points per lane -- 4 x 4 from 2^20 grid points, 2 x 4 below (dx, dx^2
+    and Gamma dx shared along each row, dz and Gamma dz along each column: 5.25 / 5.75 instead of 6.5 packed operations
+    per two pairs and target); LUDVM_GRID_KERNEL = row | patch2 | patch4 forces one form (row: 4 points of one row per
+    lane).  Same operations on the same operands in the same order -> the same bits, for row counts that are and are not
+    multiples of the patch, one and several source splits, small- and large-tile source sets, local-origin sources."""
     import os
     from ludvm_amd import Engine
-    rng = np.random.default_rng(17)
     res = {}
-    for kind in ("patch", "row"):
+    for kind in ("row", "patch2", "patch4", "patch"):
         os.environ["LUDVM_GRID_KERNEL"] = kind
         try:
             e = Engine(0)
@@ -254,16 +254,17 @@ def test_grid_patch_kernel_equals_the_row_kernel_bit_for_bit():
         try:
             out = []
             r = np.random.default_rng(17)
-            for ns, nx, nz in ((700, 37, 48), (20000, 64, 36), (3000, 1, 8), (5000, 301, 260)):
+            for ns, nx, nz in ((700, 37, 48), (20000, 64, 36), (3000, 1, 8), (5000, 301, 260), (20000, 1027, 1024)):
                 xs, zs, g = r.uniform(-10, 0, ns) - 20.0, r.uniform(-2, 2, ns), r.standard_normal(ns) / 50
                 u, w, ome = e.flowfield_rows(-30.0, -2.0, 0.0173, nx, nz, 0, nx, g, xs, zs, 0.065, vorticity=nx > 1)
                 out.append((u, w, ome))
             res[kind] = out
         finally:
             e.close()
-    for a, b in zip(res["patch"], res["row"]):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-        assert (a[2] is None and b[2] is None) or np.array_equal(a[2], b[2])
+    for kind in ("patch2", "patch4", "patch"):
+        for a, b in zip(res[kind], res["row"]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), kind
+            assert (a[2] is None and b[2] is None) or np.array_equal(a[2], b[2]), kind
 
 
 def test_flowfield_row_blocks_are_bitwise_the_full_grid(eng):

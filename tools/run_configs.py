@@ -51,7 +51,7 @@ def cfg5(args):
     pairs = float(nx) * nz * n
     # (parity of this case on sampled grid points against the C oracle: tests/test_gpu_kernel.py::test_full_size_config5_flowfield)
     err = None
-    print(json.dumps({"config": f"cfg5 flowfield {nx}x{nz} grid over N={n}", "kernel": "generic tpl=%d" % args.tpl if args.tpl else ("grid row of 4 (shared dx)" if os.environ.get("LUDVM_GRID_KERNEL", "")[:1] in ("r", "1") else "grid patch 2 x 4 (shared dx, dz)"), "s_per_call": el, "pairs_per_s": pairs / el,
+    print(json.dumps({"config": f"cfg5 flowfield {nx}x{nz} grid over N={n}", "kernel": "generic tpl=%d" % args.tpl if args.tpl else {"row": "grid row of 4 (shared dx)", "1": "grid row of 4 (shared dx)", "patch2": "grid patch 2 x 4 (shared dx, dz, G dx, G dz)"}.get(os.environ.get("LUDVM_GRID_KERNEL", ""), "grid patch 4 x 4 (shared dx, dz, G dx, G dz)"), "s_per_call": el, "pairs_per_s": pairs / el,
                       "pair_kernel_ms": kms, "pct_fp32_peak": 13 * pairs / (kms * 1e-3) / 157.3e12 * 100,
                       "sampled_rel_err_vs_oracle": err, "omega_finite": bool(torch.isfinite(dome).all().item())}))
 
