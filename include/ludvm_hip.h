@@ -286,8 +286,9 @@ int ludvm_flowfield_vorticity_f32(ludvm_ctx* ctx, double xmin, double zmin, doub
                                   const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
                                   float* u, float* w, float* ome);
 /* Rows [row_first, row_first + row_count) of that nx x nz grid only -- the same numbers, bit for bit, that the
- * whole-grid call returns for them (the grid coordinates are generated from the global row index; with ome wanted,
- * one halo row per interior side is evaluated internally).  Outputs are row_count * nz each.  This is the unit a
+ * whole-grid call returns for them (the grid coordinates are generated from the global row index and the split of the
+ * sources into partial sums is planned from the whole grid, not from the block; with ome wanted, one halo row per
+ * interior side is evaluated internally).  Outputs are row_count * nz each.  This is the unit a
  * multi-GPU flow field shards by: each GPU evaluates a block of rows, nothing is exchanged. */
 int ludvm_flowfield_rows_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz, size_t row_first,
                              size_t row_count, const double* xs, const double* zs, const double* gs, size_t ns,

@@ -205,8 +205,12 @@ constexpr long long kTargetBlocks = 16384;  // total workgroups aimed for (2048 
 constexpr int kMaxSplit = 2048;
 
 // small_ok = false: the launch has no 256-source-tile kernel (generic flow-field grids), keep the chunk a multiple of 1024
-Plan make_plan(const ludvm_ctx* c, long long nt, long long ns, int precision, bool small_ok = true) {
+// plan_nt: the target count that DECIDES the plan -- tile size, targets per lane and the split of the sources into
+// partial sums, i.e. everything the rounding of a result depends on -- when the launch itself covers only a part of a
+// larger target set (a block of rows of a flow-field grid: the block then carries the whole grid's bits); 0 = nt.
+Plan make_plan(const ludvm_ctx* c, long long nt_launch, long long ns, int precision, bool small_ok = true, long long plan_nt = 0) {
   Plan p{};
+  const long long nt = plan_nt > 0 ? plan_nt : nt_launch;
   const bool f64 = precision == LUDVM_PREC_F64;
   p.tile = f64 ? ((nt <= kFewTargets || ns <= c->small_tile_max_f64) ? kTileF64Few : kTileF64) : kTileF32;
   if (!f64 && small_ok && ns <= c->small_tile_max) p.tile = kTileF32Small;
@@ -227,8 +231,9 @@ Plan make_plan(const ludvm_ctx* c, long long nt, long long ns, int precision, bo
   chunk = (chunk + p.tile - 1) / p.tile * p.tile;
   p.chunk = chunk;
   p.nsplit = (int)std::max<long long>(1, (ns + chunk - 1) / chunk);
-  p.nt_pad = (nt + 63) / 64 * 64;
-  p.grid = dim3((unsigned)ttiles, (unsigned)p.nsplit, 1);
+  p.nt_pad = (nt_launch + 63) / 64 * 64;
+  const long long tiles_launch = std::max<long long>(1, (nt_launch + (long long)kBlock * p.tpl - 1) / ((long long)kBlock * p.tpl));
+  p.grid = dim3((unsigned)tiles_launch, (unsigned)p.nsplit, 1);
   return p;
 }
 
@@ -375,7 +380,8 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
 }
 
 // pair kernel + split reduction into (u, w) device arrays of the precision's type
-int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, int precision, void* u, void* w) {
+int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, int precision, void* u, void* w,
+                  long long plan_nt = 0) {
   if (nt == 0) return LUDVM_OK;
   const size_t elt = precision == LUDVM_PREC_F64 ? sizeof(double) : sizeof(float);
   if (ns == 0) {
@@ -384,7 +390,7 @@ int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, i
     return LUDVM_OK;
   }
   const bool grid_generic = a.grid_nz > 0 && !(a.grid_nz % 4 == 0 && c->tune_tpl == 0);
-  Plan p = make_plan(c, nt, ns, precision, !grid_generic);
+  Plan p = make_plan(c, nt, ns, precision, !grid_generic, plan_nt);
   CHK(launch_pair(c, a, p, precision, u, w));
   if (p.nsplit > 1) {
     if (precision == LUDVM_PREC_F64)
@@ -1771,7 +1777,8 @@ int ludvm_flowfield_rows_f32(ludvm_ctx* c, double xmin, double zmin, double dr, 
     a.xmin = xmin; a.zmin = zmin; a.dr = dr;
     const double v2 = vcore * vcore;
     a.vc4 = v2 * v2;
-    CHK(induce_device(c, a, a.nt, a.ns, LUDVM_PREC_F32, du, dw));
+    // (planned for the whole grid: a block of rows is then bit for bit what the whole-grid call computes for them)
+    CHK(induce_device(c, a, a.nt, a.ns, LUDVM_PREC_F32, du, dw, (long long)(nx * nz)));
   }
   // velocity and vorticity leave the device together: the stencil (LUDVM.py:1224-1292) runs on the fields where they are
   if (ome) CHK(ludvm_vorticity_dev_f32(c, du, dw, rows, nz, (float)dr, dome));
