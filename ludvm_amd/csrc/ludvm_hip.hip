@@ -473,13 +473,12 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   a.bad = o.bad;
   a.vc4 = (float)vc4;
   // workgroups: 4 / rsplit items (tile, d-chunk) each
-  auto blocks_of = [](long long items, int rs) { const long long ipb = 4 / rs; return (items + ipb - 1) / ipb; };
-  long long blocks = blocks_of(i_count * gm.ysplit, gm.rsplit);
+  long long blocks = sym_blocks(i_count, gm.ysplit, gm.rsplit);
   if (n_dev) {
     const long long W = 64LL * T;
     for (long long nt = std::max<long long>(1, (std::max<long long>(n_lo, 1) + W - 1) / W); nt <= gm.ntiles; ++nt) {
       const SymGeom q = sym_geometry(nt * W, T, a.tune_split, gm.rsplit);    // rsplit fixed by the bound: it picks the kernel
-      blocks = std::max(blocks, blocks_of(q.ntiles * q.ysplit, gm.rsplit));
+      blocks = std::max(blocks, sym_blocks(q.ntiles, q.ysplit, gm.rsplit));
     }
   }
   if (!n_dev && i_count == 0) return LUDVM_OK;     // an owner without tiles (fewer tiles than owners)

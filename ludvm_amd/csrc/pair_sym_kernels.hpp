@@ -71,9 +71,16 @@ struct SymArgs {
 // march step sized from an upper bound, for one GPU and for G GPUs that own I-tile blocks of the same ring.
 constexpr long long kSymTargetWaves = 8 * 65536;   // (I, d-chunk) work items aimed for over the whole ring
 constexpr long long kSymMaxSplit = 64;
+constexpr long long kXcds = 8;                        // XCDs of an MI355X: workgroup b is dispatched to XCD b % 8
 constexpr long long kSymMaxRsplit = 4;
 constexpr long long kSymMinItems = 10500;          // measured (profiles/r02_atomics_cost_and_lds_reduction.txt, table 4)
 struct SymGeom { long long ntiles, dmax, dtot; int ysplit, rsplit; };
+// workgroups of a launch over i_count I tiles: the same number for each XCD, sized for the largest eighth
+__host__ __device__ inline long long sym_blocks(long long i_count, long long ysplit, int rsplit) {
+  const long long ipb = 4 / rsplit, per_xcd = (i_count + kXcds - 1) / kXcds;
+  return kXcds * ((per_xcd * ysplit + ipb - 1) / ipb);
+}
+
 __host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_split, int tune_rsplit) {
   SymGeom g;
   const long long W = 64LL * T;
@@ -224,8 +231,17 @@ pair_sym_f32(SymArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: tile indices stay scalar
   const int r = wv % R;                    // this wave's share of the rotation steps
   const int w0 = wv - r;                   // first wave of the item in the workgroup
-  const long long item = (long long)blockIdx.x * (kWaves / R) + wv / R;
-  const bool active = item < a.i_count * a.ysplit;
+  // XCD-aware placement.  Workgroups are dispatched to the 8 XCDs round-robin (workgroup b runs on XCD b % 8, each with its
+  // own L2): XCD x takes the x-th eighth of the launch's I tiles, for every d-chunk y, and works through its items
+  // (y-major: the diagonal-tile items first) in the order of its workgroups.  Waves that run on an XCD at the same time
+  // then hold neighbouring I tiles with the same offsets d, i.e. overlapping partner tiles J, and the L2 serves them:
+  // memory-side fetches of an N = 2^20 launch 2.04 GB -> 0.03 GB at unchanged speed (the kernel is ALU-bound;
+  // profiles/r02_xcd_aware_mapping.txt).  The items, and with them the partial sums, are the same whatever the placement.
+  const long long xcd = blockIdx.x % kXcds, qb = blockIdx.x / kXcds;
+  const long long x_lo = a.i_count * xcd / kXcds, x_n = a.i_count * (xcd + 1) / kXcds - x_lo;   // this XCD's I tiles
+  const long long q = qb * (kWaves / R) + wv / R;                                               // item within the XCD
+  const bool active = q < x_n * a.ysplit;
+  const long long item = active ? (q / x_n) * a.i_count + x_lo + q % x_n : 0;
   if (!RED && !active) return;             // no barriers on this path: whole waves leave
   const long long I = a.i_first + (active ? item % a.i_count : 0);
   const int y = active ? (int)(item / a.i_count) : 0;
