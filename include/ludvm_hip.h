@@ -306,6 +306,12 @@ int ludvm_vorticity_dev_f32(ludvm_ctx* ctx, const float* d_u, const float* d_w, 
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 
+/* Probe of the symmetric kernel's fixed-point accumulation (the order-independent sums behind the roll-up of
+ * LUDVM.py:1095-1127): units[i] = the 64-bit integer the kernel adds to an accumulator for the fp32 partial sum
+ * values[i] at scale 2^scale_log2, i.e. trunc(values[i] * 2^scale_log2) -- exact for every |values[i] * 2^scale_log2|
+ * < 2^63.  Host arrays; the conversion runs on the device with the kernel's own code. */
+int ludvm_fixed_point_probe(ludvm_ctx* ctx, const float* values, size_t n, int scale_log2, long long* units);
+
 /* Average device time (ms) of the pair kernel launches (main kernel only -- direct or symmetric --
  * not the split reduction / finisher) issued since the last call with reset != 0, measured with HIP events on the stream the
  * kernel is launched on; *launches = number of launches averaged.  Timing is off until

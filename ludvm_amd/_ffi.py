@@ -71,6 +71,7 @@ SIGNATURES = {
                                 c_void_p, c_size_t, c_float, c_void_p, c_void_p],
     "ludvm_vorticity_f32": [c_void_p, _pf, _pf, c_size_t, c_size_t, c_double, _pf],
     "ludvm_vorticity_dev_f32": [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_void_p],
+    "ludvm_fixed_point_probe": [c_void_p, _pf, c_size_t, c_int, POINTER(c_longlong)],
     "ludvm_kernel_timing": [c_void_p, c_int],
     "ludvm_kernel_time_ms": [c_void_p, c_int, POINTER(c_double), POINTER(c_longlong)],
 }

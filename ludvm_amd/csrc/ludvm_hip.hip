@@ -449,6 +449,7 @@ struct SymOperands {
 // [n_lo, n], and the grid is sized for the largest wave count any such n needs.
 int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, long long i_first, long long i_count, double vc4,
                      const long long* n_dev = nullptr, long long n_lo = 0, bool sharded = false) {
+  if (n >= (1LL << 31)) return fail(c, LUDVM_E_ARG, "the symmetric kernel indexes vortices with 32 bits: n < 2^31");
   SymArgs a{};
   a.x = o.x; a.z = o.z; a.g = o.g; a.n = n;
   a.n_dev = n_dev;
@@ -592,13 +593,16 @@ int wake_grow(ludvm_ctx* c, size_t capacity) {
   cap = (cap + kOriginBlock - 1) / kOriginBlock * kOriginBlock;      // whole origin blocks
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->stream_b) HIPCHK(c, hipStreamSynchronize(c->stream_b));
-  const size_t nblk = cap / kOriginBlock + 1;
+  const size_t nblk = (size_t)origin_slots((long long)cap);      // origin records: two per 256-vortex block
   double* d64[3] = {nullptr, nullptr, nullptr};
   float* f32[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipError_t me = hipSuccess;
   for (auto& q : d64) if (me == hipSuccess) me = hipMalloc(&q, cap * sizeof(double));
   for (int k = 0; k < 7; ++k) if (me == hipSuccess) me = hipMalloc(&f32[k], cap * sizeof(float));
   for (int k = 7; k < 9; ++k) if (me == hipSuccess) me = hipMalloc(&f32[k], nblk * sizeof(float));
+  // (records of blocks that hold no vortex yet are never used for a stored vortex, but tiles that straddle the end of
+  // the wake read them: they must be numbers)
+  for (int k = 7; k < 9; ++k) if (me == hipSuccess) me = hipMemsetAsync(f32[k], 0, nblk * sizeof(float), c->stream);
   if (me != hipSuccess) {      // the wake keeps its old arrays; what was obtained so far goes back
     for (double* q : d64) if (q) (void)hipFree(q);
     for (float* q : f32) if (q) (void)hipFree(q);
@@ -610,7 +614,7 @@ int wake_grow(ludvm_ctx* c, size_t capacity) {
   if (n) {
     for (int k = 0; k < 3; ++k) HIPCHK(c, hipMemcpyAsync(d64[k], o64[k], n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     for (int k = 0; k < 7; ++k) HIPCHK(c, hipMemcpyAsync(f32[k], o32[k], n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    const size_t ob = (n + kOriginBlock - 1) / kOriginBlock;
+    const size_t ob = 2 * ((n + kOriginBlock - 1) / kOriginBlock);
     for (int k = 7; k < 9; ++k) HIPCHK(c, hipMemcpyAsync(f32[k], o32[k], ob * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
@@ -801,7 +805,7 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
   // One packed block in = xs | zs | gs | xt | zt.  Small calls (every call of a README-size run) go through the pinned
   // ring: one upload, one conversion launch, the pair launch, one back-conversion, one pinned download.
   const bool small = in_doubles * 8 <= kPinBytes / 4 && out_doubles * 8 <= kPinOutBytes;
-  const size_t nsb = ns / kOriginBlock + 1, ntb = nt / kOriginBlock + 1;
+  const size_t nsb = (size_t)origin_slots((long long)ns), ntb = (size_t)origin_slots((long long)nt);
   size_t bytes = Arena::need(in_doubles, 8) + Arena::need(out_doubles, 8);
   if (!f64) bytes += 5 * Arena::need(ns, 4) + 6 * Arena::need(nt, 4) + 2 * Arena::need(nsb, 4) + 2 * Arena::need(ntb, 4);
   CHK(ensure(c, c->arena, bytes));
@@ -1710,7 +1714,7 @@ int ludvm_flowfield_dev_f32(ludvm_ctx* c, double xmin, double zmin, double dr, s
 // vortices 1e-3 apart keeps the precision it has near the origin (LUDVM.py:1206, :1216-1217 evaluate in float64).
 static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, const double* zs, const double* gs, size_t ns,
                                   PairArgs& a) {
-  const size_t nsb = ns / kOriginBlock + 1;
+  const size_t nsb = (size_t)origin_slots((long long)ns);
   double* dxs = ar.take<double>(ns);
   double* dzs = ar.take<double>(ns);
   double* dgs = ar.take<double>(ns);
@@ -1732,7 +1736,7 @@ static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, con
   return LUDVM_OK;
 }
 static size_t flowfield_upload_bytes(size_t ns) {
-  return 3 * Arena::need(ns, 8) + 3 * Arena::need(ns, 4) + 2 * Arena::need(ns / kOriginBlock + 1, 4);
+  return 3 * Arena::need(ns, 8) + 3 * Arena::need(ns, 4) + 2 * Arena::need((size_t)origin_slots((long long)ns), 4);
 }
 
 int ludvm_flowfield_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, const double* xs,
@@ -1830,6 +1834,25 @@ int ludvm_debug_set_wave_trace(ludvm_ctx* c, unsigned long long* d_trace) {
   return LUDVM_OK;
 }
 #endif
+
+int ludvm_fixed_point_probe(ludvm_ctx* c, const float* values, size_t n, int scale_log2, long long* units) {
+  if (!c) return LUDVM_E_ARG;
+  if (n && (!values || !units)) return fail(c, LUDVM_E_ARG, "null array");
+  if (scale_log2 < -120 || scale_log2 > 120) return fail(c, LUDVM_E_ARG, "scale_log2 must lie in [-120, 120]");
+  if (n == 0) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(ensure(c, c->arena, Arena::need(n, 4) + Arena::need(n, 8)));
+  Arena ar(c->arena.p);
+  float* dv = ar.take<float>(n);
+  long long* du = ar.take<long long>(n);
+  HIPCHK(c, hipMemcpyAsync(dv, values, n * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(fx_probe, dim3(blocks_for((long long)n)), dim3(kBlock), 0, c->stream, dv, (long long)n,
+                     (float)std::ldexp(1.0, scale_log2), du);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(units, du, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LUDVM_OK;
+}
 
 int ludvm_kernel_timing(ludvm_ctx* c, int enable) {
   if (!c) return LUDVM_E_ARG;

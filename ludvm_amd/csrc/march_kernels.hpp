@@ -365,19 +365,21 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
   __syncthreads();                                   // all reads of S are done; it is rewritten below
 
   // Local-origin mirrors of the entries written now -- wake index n0 (TEV), n0 + 1 (LEV when shed), then the npan
-  // bound vortices: an origin block that starts among them takes its origin from the entry written there, the
-  // others keep the origin the last Euler finisher gave them.
+  // bound vortices: an origin class (256-vortex block x index parity) whose first member is among them takes its origin
+  // from the entry written there, the others keep the origin the last Euler finisher gave them.
   auto origin_of = [&](long long i, float& ox, float& oz) {
-    const long long b = i >> kOriginShift, bs = b << kOriginShift;
-    if (bs >= n0) {
+    const long long b = i >> kOriginShift, cs = (b << kOriginShift) + (i & 1), slot = origin_slot(i);
+    if (cs >= n0) {
       double bx, bz;
-      if (bs == n0) { bx = tev_x; bz = tev_z; }
-      else if (shed && bs == n0 + 1) { bx = lev_x; bz = lev_z; }
-      else { bx = xg[bs - n0 - k]; bz = zg[bs - n0 - k]; }
+      if (cs == n0) { bx = tev_x; bz = tev_z; }
+      else if (shed && cs == n0 + 1) { bx = lev_x; bz = lev_z; }
+      else { bx = xg[cs - n0 - k]; bz = zg[cs - n0 - k]; }
       ox = (float)bx; oz = (float)bz;
-      if (i == bs) { mir.cx[b] = ox; mir.cz[b] = oz; }
+      if (i == cs) { mir.cx[slot] = ox; mir.cz[slot] = oz; }
+      // a block opened by the very last entry written now: its still empty odd class gets a number too
+      if (i == cs && (i & 1) == 0 && i == n0 + k + npan - 1) { mir.cx[slot + 1] = ox; mir.cz[slot + 1] = oz; }
     } else {
-      ox = mir.cx[b]; oz = mir.cz[b];
+      ox = mir.cx[slot]; oz = mir.cz[slot];
     }
   };
 
@@ -466,7 +468,7 @@ march_finish_sym(long long* acc_u, long long* acc_w, const SymScale* sc, MarchSt
                  long long* bad_step = nullptr, long long* bad_next = nullptr) {
   // bad_step / bad_next (sharded roll-up): this step's count of non-finite partial sums, summed over all owners by
   // the all-reduce that also summed acc_u / acc_w, and the next step's counter, cleared here; S->sym_bad keeps it
-  __shared__ float org[2];
+  __shared__ float org[4];
   const bool bad = S->sym_bad != 0 || (bad_step && *bad_step != 0);
   const long long n = S->n, n_old = *n_old_p;
   const int k = (int)(n - n_old);
@@ -492,7 +494,7 @@ march_finish_sym(long long* acc_u, long long* acc_w, const SymScale* sc, MarchSt
     }
     xn = xo + dt * su;
     zn = zo + dt * sw;
-    if (i == origin_index(blockIdx.x, n)) { org[0] = (float)xn; org[1] = (float)zn; m.cx[blockIdx.x] = org[0]; m.cz[blockIdx.x] = org[1]; }
+    publish_origins(m, i, n, xn, zn, org);
   }
   __syncthreads();
   if (bad_step && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -502,7 +504,7 @@ march_finish_sym(long long* acc_u, long long* acc_w, const SymScale* sc, MarchSt
   if (!on) return;
   x64[i] = xn;
   z64[i] = zn;
-  store_mirrors(m, i, xn, zn, org[0], org[1]);
+  store_mirrors(m, i, xn, zn, org[i & 1], org[2 + (i & 1)]);
   tail_duty(td, i, n, xn, zn);
 }
 

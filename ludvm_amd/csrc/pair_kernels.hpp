@@ -28,18 +28,27 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts, one per SIMD
-// Local origins: fp32 positions are stored as offsets from the origin of their 256-vortex block
-// (block b = indices [256 b, 256 b + 256), origin = the fp32-rounded position of one of its vortices); a pair
-// difference is then (offset_p + (origin_p - origin_w)) - offset_w, with the origin difference added to the
-// targets once per block pair.  The wake is stored in shedding order, so a block is spatially compact: pairs
-// in nearby blocks keep (almost) full relative precision at any distance from the coordinate origin, far blocks
-// do not need it.  Costs nothing in the pair loop (unlike hi+lo positions: +4 packed ops per two pairs).
+// Local origins: fp32 positions are stored as offsets from the origin of their origin CLASS: the vortices
+// of one 256-vortex block (block b = indices [256 b, 256 b + 256)) that share an index parity -- class (b, p) holds
+// indices 256 b + p, 256 b + p + 2, ...; its origin is the fp32-rounded position of its middle member, stored at
+// cx / cz[2 b + p].  A pair difference is then (offset_p + (origin_p - origin_w)) - offset_w, with the origin
+// difference added to the targets once per class pair.  The wake is stored in shedding order: while only trailing-edge
+// vortices are shed a block is one compact stretch of the sheet, and while a leading-edge vortex is shed with every
+// trailing-edge one the two families alternate -- a chord apart -- and each takes one index parity, so a CLASS is
+// compact in both orders (round 2 kept one origin per block: 8e-6 of max|u| on a single sheet but 2-4e-5 on the
+// alternating order, which is most of BASELINE config 2).  Pairs in nearby classes keep (almost) full relative
+// precision at any distance from the coordinate origin, far ones do not need it.  Costs nothing in the pair loop
+// (unlike hi+lo positions: +4 packed ops per two pairs): the two sources of a packed instruction have the two
+// parities, so the packed target operand simply holds the target referred to one origin in each half.
 // Measured [MI355X] on a wake at |x| ~ 50 with vortices 1e-3 apart (v_core = 1.3e-3): 1.4e-3 of max|u| with plain
 // fp32 coordinates, 1.7e-5 with 512-vortex blocks whose origin is their first vortex, < 1e-5 with 256-vortex
-// blocks whose origin is their middle vortex (what is built here), 1e-6 with hi+lo positions.
+// blocks whose origin is their middle vortex, 1e-6 with hi+lo positions.
 constexpr int kOriginShift = 8;
 constexpr int kOriginBlock = 1 << kOriginShift;   // = the 256-vortex tile of pair_sym_f32<4>
 constexpr int kFinBlock = kOriginBlock;           // Euler finishers: one workgroup per origin block
+// number of origin records (2 per block) an array of n positions needs, with one spare block for tiles that straddle
+// the end
+inline __host__ __device__ long long origin_slots(long long n) { return 2 * (n / kOriginBlock + 2); }
 constexpr double kInv2PiD = 0.15915494309189533576888;
 // Padding for source slots past the end of the range: far enough that r^4 overflows to +inf, so
 // rsq() returns exactly 0 and the (zero-circulation) slot contributes exactly 0 even when vc = 0
@@ -71,10 +80,10 @@ struct PairArgs {
   // from the host's upper bound; surplus blocks find nothing to do.
   const long long* n_dev;
   int ns_dev, nt_dev;
-  // LOCAL kernels: xs / zs are offsets from the origin of their 256-source block, scx / scz the origins (block
-  // index = source index >> kOriginShift, the source arrays start on a block boundary).  Array targets are offsets too,
-  // their origins are tcx / tcz[(t_index0 + p) >> kOriginShift]; grid targets are generated in float64 and referred to
-  // the source block's origin directly.
+  // LOCAL kernels: xs / zs are offsets from the origin of their origin class (256-source block x index parity),
+  // scx / scz the origins (record 2 (source index >> kOriginShift) + (source index & 1); the source arrays start on a
+  // block boundary).  Array targets are offsets too, their origins are tcx / tcz[2 ((t_index0 + p) >> kOriginShift)
+  // + ((t_index0 + p) & 1)]; grid targets are generated in float64 and referred to the source classes' origins directly.
   const float* scx; const float* scz;
   const float* tcx; const float* tcz;
   long long t_index0;
@@ -128,7 +137,7 @@ pair_f32(PairArgs a) {
   __shared__ __attribute__((aligned(16))) float lxl[HILO ? TILE : 4];
   __shared__ __attribute__((aligned(16))) float lzl[HILO ? TILE : 4];
   constexpr int kSegs = LOCAL ? (TILE + kOriginBlock - 1) / kOriginBlock : 1;
-  __shared__ float lox[kSegs], loz[kSegs];      // LOCAL: origins of the tile's source blocks, staged with the tile
+  __shared__ float lox[2 * kSegs], loz[2 * kSegs];      // LOCAL: origins of the tile's source classes (block x parity), staged with the tile
 
   const float* __restrict__ xs = static_cast<const float*>(a.xs);
   const float* __restrict__ zs = static_cast<const float*>(a.zs);
@@ -179,7 +188,7 @@ pair_f32(PairArgs a) {
         if (HILO) { xl = (float)(xd - (double)x); zl = (float)(zd - (double)z); }
         if (LOCAL) { gxd[t] = xd; gzd[t] = zd; }
       } else if (LOCAL && GRID == 0) {
-        const long long tb = (a.t_index0 + ti) >> kOriginShift;
+        const long long tg = a.t_index0 + ti, tb = 2 * (tg >> kOriginShift) + (tg & 1);
         tlx[t] = static_cast<const float*>(a.xt)[ti];
         tlz[t] = static_cast<const float*>(a.zt)[ti];
         tox[t] = a.tcx[tb];
@@ -215,9 +224,9 @@ pair_f32(PairArgs a) {
         lzl[l] = ok ? a.zsl[si] : 0.0f;
       }
     }
-    if (LOCAL && tid < kSegs && base + (long long)tid * kOriginBlock < s_end) {
-      lox[tid] = a.scx[(base >> kOriginShift) + tid];
-      loz[tid] = a.scz[(base >> kOriginShift) + tid];
+    if (LOCAL && tid < 2 * kSegs && base + (long long)(tid >> 1) * kOriginBlock < s_end) {
+      lox[tid] = a.scx[2 * (base >> kOriginShift) + tid];
+      loz[tid] = a.scz[2 * (base >> kOriginShift) + tid];
     }
     __syncthreads();
 
@@ -231,25 +240,25 @@ pair_f32(PairArgs a) {
     constexpr int kSeg = LOCAL ? (TILE < kOriginBlock ? TILE : kOriginBlock) : TILE;
     for (int seg = 0; seg < TILE; seg += kSeg) {
     if (LOCAL) {
-      // the segment's sources share one origin: refer this lane's targets to it
+      // the segment's sources have two origins, one per index parity -- and a packed instruction pairs an even source
+      // with the odd one behind it: the packed target operand holds the target referred to the even sources' origin in
+      // its low half and to the odd sources' origin in its high half
       const long long sidx = base + seg;
       if (sidx >= s_end) break;
-      const float ox = lox[seg >> kOriginShift], oz = loz[seg >> kOriginShift];
+      const int so = 2 * (seg >> kOriginShift);
+      const float ox0 = lox[so], ox1 = lox[so + 1], oz0 = loz[so], oz1 = loz[so + 1];
 #pragma unroll
       for (int t = 0; t < TPL; ++t) {
         // (grid kernels read x of one target per row and z of one per column only)
-        if (GRID == 1 && t != 0) { const float z1 = (float)(gzd[t] - (double)oz); zp[t] = (f32x2){z1, z1}; continue; }
+        if (GRID == 1 && t != 0) { zp[t] = (f32x2){(float)(gzd[t] - (double)oz0), (float)(gzd[t] - (double)oz1)}; continue; }
         if (GRID == 2 && t >= kCols && t % kCols != 0) continue;
-        float x, z;
         if (GRID != 0 || a.grid_nz > 0) {
-          x = (float)(gxd[t] - (double)ox);
-          z = (float)(gzd[t] - (double)oz);
+          xp[t] = (f32x2){(float)(gxd[t] - (double)ox0), (float)(gxd[t] - (double)ox1)};
+          zp[t] = (f32x2){(float)(gzd[t] - (double)oz0), (float)(gzd[t] - (double)oz1)};
         } else {
-          x = tlx[t] + (tox[t] - ox);
-          z = tlz[t] + (toz[t] - oz);
+          xp[t] = (f32x2){tlx[t] + (tox[t] - ox0), tlx[t] + (tox[t] - ox1)};
+          zp[t] = (f32x2){tlz[t] + (toz[t] - oz0), tlz[t] + (toz[t] - oz1)};
         }
-        xp[t] = (f32x2){x, x};
-        zp[t] = (f32x2){z, z};
       }
     }
 #pragma unroll 2
@@ -498,20 +507,39 @@ __device__ __forceinline__ void split_hilo(double v, float& hi, float& lo) {
 }
 
 // The fp32 mirrors of the resident wake's float64 master positions: (xh, xl) / (zh, zl) hi+lo pairs for the
-// f32x2 kernels, (xr, zr) offsets from the block origins (cx, cz)[index >> 9] for the local-origin fp32 kernels.
-// Invariant: xr[i] = (float)(x64[i] - cx[i >> kOriginShift]) for every stored vortex; cx[b] is the fp32 position a
-// vortex of block b had when the block's offsets were last rewritten (the middle one, or the last one of a block
-// that is not yet half full).
+// f32x2 kernels, (xr, zr) offsets from the class origins (cx, cz)[2 (index >> 8) + (index & 1)] for the local-origin
+// fp32 kernels.  Invariant: xr[i] = (float)(x64[i] - cx[origin_slot(i)]) for every stored vortex; cx[2 b + p] is the fp32
+// position a vortex of class (b, p) had when the block's offsets were last rewritten (the middle one, or the newest one
+// of a class that is not yet half full).  Both records of a block that holds any vortex are finite numbers.
 struct Mirrors {
   float* xh; float* xl; float* zh; float* zl;
   float* xr; float* zr; float* cx; float* cz;
 };
 
-// Which vortex of origin block `b` lends the block its origin when n vortices are stored: the middle one, or the
-// newest while the block is less than half full.
-__device__ __forceinline__ long long origin_index(long long b, long long n) {
-  const long long mid = (b << kOriginShift) + kOriginBlock / 2;
-  return mid < n ? mid : n - 1;
+// origin record of vortex i
+__host__ __device__ __forceinline__ long long origin_slot(long long i) { return 2 * (i >> kOriginShift) + (i & 1); }
+
+// Which vortex lends origin class (block b, index parity p) its origin when n vortices are stored (n > 256 b): the
+// middle one of the class, or its newest while the class is less than half full; a class without a member yet (the
+// odd one of a block that holds a single vortex) borrows the block's first vortex, so that its record is a number.
+__host__ __device__ __forceinline__ long long origin_index(long long b, int p, long long n) {
+  const long long first = b << kOriginShift;
+  const long long mid = first + kOriginBlock / 2 + p;
+  if (mid < n) return mid;
+  const long long last = (n - 1) - (((n - 1) ^ p) & 1);       // the newest stored index of parity p
+  return last >= first ? last : first;
+}
+
+// Euler finishers (one workgroup per origin block): the threads that have just moved the two origin vortices of the
+// block publish the new origins -- org = [x even, x odd, z even, z odd] in LDS for the block's threads, and the records.
+__device__ __forceinline__ void publish_origins(const Mirrors& m, long long i, long long n, double xn, double zn, float* org) {
+  const long long b = blockIdx.x;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+    if (i == origin_index(b, p, n)) {
+      org[p] = (float)xn; org[2 + p] = (float)zn;
+      m.cx[2 * b + p] = org[p]; m.cz[2 * b + p] = org[2 + p];
+    }
 }
 
 __device__ __forceinline__ void store_mirrors(const Mirrors& m, long long i, double x, double z, float ox, float oz) {
@@ -581,7 +609,7 @@ template <typename T>
 __global__ void __launch_bounds__(kFinBlock)
 finish_wake_advect(const T* part, long long nt, long long nt_pad, int nsplit, double dt, double* x64, double* z64,
                    Mirrors m, double* u_out, double* w_out, const long long* n_dev = nullptr, TailDuty td = TailDuty{}) {
-  __shared__ float org[2];
+  __shared__ float org[4];
   const long long i = (long long)blockIdx.x * kFinBlock + threadIdx.x;
   if (n_dev) nt = *n_dev;          // device-resident march: the wake size lives on the device
   tail_duty_block0(td, nt);
@@ -593,18 +621,18 @@ finish_wake_advect(const T* part, long long nt, long long nt_pad, int nsplit, do
     if (u_out) { u_out[i] = (double)su; w_out[i] = (double)sw; }
     xn = x64[i] + dt * (double)su;
     zn = z64[i] + dt * (double)sw;
-    if (i == origin_index(blockIdx.x, nt)) { org[0] = (float)xn; org[1] = (float)zn; m.cx[blockIdx.x] = org[0]; m.cz[blockIdx.x] = org[1]; }
+    publish_origins(m, i, nt, xn, zn, org);
   }
   __syncthreads();
   if (!on) return;
   x64[i] = xn;
   z64[i] = zn;
-  store_mirrors(m, i, xn, zn, org[0], org[1]);
+  store_mirrors(m, i, xn, zn, org[i & 1], org[2 + (i & 1)]);
   tail_duty(td, i, nt, xn, zn);
 }
 
 // Rebuild the fp32 mirrors of every origin block that intersects [first, first + count) from the float64
-// masters (after a host write): the block's origin is re-taken (origin_index over the `stored` entries), so the
+// masters (after a host write): the block's two origins are re-taken (origin_index over the `stored` entries), so the
 // whole block is refreshed.  Entries of a touched block that lie beyond the stored range are computed from whatever
 // the master arrays hold there and are never read.  `limit` = allocated capacity.
 __global__ void __launch_bounds__(kBlock)
@@ -616,9 +644,10 @@ refresh_mirrors(long long first, long long count, long long stored, long long li
   if (hi > limit) hi = limit;
   if (i >= hi) return;
   const long long b = i >> kOriginShift;
-  const long long oi = origin_index(b, stored);
+  const int p = (int)(i & 1);
+  const long long oi = origin_index(b, p, stored);
   const float ox = (float)x64[oi], oz = (float)z64[oi];
-  if ((i & (kOriginBlock - 1)) == 0) { m.cx[b] = ox; m.cz[b] = oz; }
+  if ((i & (kOriginBlock - 1)) < 2) { m.cx[2 * b + p] = ox; m.cz[2 * b + p] = oz; }      // the first thread of each class
   store_mirrors(m, i, x64[i], z64[i], ox, oz);
   g32[i] = (float)g64[i];
 }
@@ -640,16 +669,18 @@ cvt_f32_to_f64(const float* in, double* out, long long n) {
   if (i < n) out[i] = (double)in[i];
 }
 
-// float64 -> local-origin fp32 for the stateless host API: off[i] = (float)(in[i] - org[i >> kOriginShift]) with
-// org[b] = (float)in[origin_index(b, n)].
+// float64 -> local-origin fp32 for the stateless host API: off[i] = (float)(in[i] - org[origin_slot(i)]) with
+// org[2 b + p] = (float)in[origin_index(b, p, n)].  n is rounded up to whole blocks by the grid: the threads of a
+// class without a member still write its record (a number: the kernels read both records of every block they stage).
 __global__ void __launch_bounds__(kBlock)
 cvt_f64_to_local(const double* in, float* off, float* org, long long n) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
   const long long b = i >> kOriginShift;
-  const float o = (float)in[origin_index(b, n)];
-  if ((i & (kOriginBlock - 1)) == 0) org[b] = o;
-  off[i] = (float)(in[i] - (double)o);
+  if ((b << kOriginShift) >= n) return;
+  const int p = (int)(i & 1);
+  const float o = (float)in[origin_index(b, p, n)];
+  if ((i & (kOriginBlock - 1)) < 2) org[2 * b + p] = o;
+  if (i < n) off[i] = (float)(in[i] - (double)o);
 }
 
 // Small stateless calls: the five float64 input arrays arrive in one packed upload, in = xs[ns] | zs[ns] | gs[ns] |
@@ -669,8 +700,9 @@ cvt_packed_inputs(const double* in, long long ns, long long nt, float* xs, float
   else { zt[k - 3 * ns - nt] = h; ztl[k - 3 * ns - nt] = l; }
 }
 
-// The same packed block as local-origin fp32: offsets from the origin of each array's own 256-element blocks
-// (origin = fp32 value of the block's middle element).  nt = 0 when the targets are the sources themselves.
+// The same packed block as local-origin fp32: offsets from the origins of each array's own origin classes (256-element
+// block x index parity; origin = fp32 value of the class's middle element).  nt = 0 when the targets are the sources
+// themselves.
 __global__ void __launch_bounds__(kBlock)
 cvt_packed_inputs_local(const double* in, long long ns, long long nt, float* xs, float* zs, float* gs, float* sox, float* soz,
                         float* xt, float* zt, float* tox, float* toz) {
@@ -679,8 +711,11 @@ cvt_packed_inputs_local(const double* in, long long ns, long long nt, float* xs,
   const double v = in[k];
   auto local = [&](long long base, long long i, long long len, float* off, float* org) {
     const long long b = i >> kOriginShift;
-    const float o = (float)in[base + origin_index(b, len)];
-    if ((i & (kOriginBlock - 1)) == 0) org[b] = o;
+    const int p = (int)(i & 1);
+    const float o = (float)in[base + origin_index(b, p, len)];
+    if ((i & (kOriginBlock - 1)) < 2) org[2 * b + p] = o;
+    // (a block that holds a single element: its odd class has no member to write the record, which the kernels still read)
+    if ((i & (kOriginBlock - 1)) == 0 && i + 1 >= len) org[2 * b + 1] = o;
     off[i] = (float)(v - (double)o);
   };
   if (k < ns) local(0, k, ns, xs, sox);
@@ -717,7 +752,8 @@ unit_influence_f64(const double* xt, const double* zt, long long nt, const doubl
 // One kernel stages everything a time step uploads: `n_new` shed vortices appended at wake index n0 and
 // `n_foil` bound vortices behind them (sources of the roll-up only), from one packed host->device copy
 // pack = [new_x | new_z | new_g | foil_x | foil_z | foil_g]; float64 masters and fp32 mirrors are written.
-// An origin block that starts inside the staged range takes its origin from the vortex staged there.
+// An origin class (block x index parity) whose first member lies inside the staged range takes its origin from the
+// vortex staged there (the other classes keep the origin the last Euler finisher gave them).
 __global__ void __launch_bounds__(kBlock)
 stage_step_inputs(const double* pack, long long n0, int n_new, int n_foil, double* x64, double* z64, double* g64, Mirrors m,
                   float* g32) {
@@ -732,15 +768,17 @@ stage_step_inputs(const double* pack, long long n0, int n_new, int n_foil, doubl
   double x, z, g;
   staged(k, x, z, g);
   const long long i = n0 + k;
-  const long long b = i >> kOriginShift, bs = b << kOriginShift;
+  const long long b = i >> kOriginShift, cs = (b << kOriginShift) + (i & 1), slot = origin_slot(i);   // cs: first member of i's class
   float ox, oz;
-  if (bs >= n0) {
+  if (cs >= n0) {
     double bx, bz, bg;
-    staged((int)(bs - n0), bx, bz, bg);
+    staged((int)(cs - n0), bx, bz, bg);
     ox = (float)bx; oz = (float)bz;
-    if (i == bs) { m.cx[b] = ox; m.cz[b] = oz; }
+    if (i == cs) { m.cx[slot] = ox; m.cz[slot] = oz; }
+    // a block opened by the last staged entry: give its still empty odd class a number too
+    if (i == cs && (i & 1) == 0 && k + 1 == n_new + n_foil) { m.cx[slot + 1] = ox; m.cz[slot + 1] = oz; }
   } else {
-    ox = m.cx[b]; oz = m.cz[b];
+    ox = m.cx[slot]; oz = m.cz[slot];
   }
   x64[i] = x; z64[i] = z; g64[i] = g;
   store_mirrors(m, i, x, z, ox, oz);

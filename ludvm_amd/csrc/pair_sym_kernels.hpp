@@ -100,17 +100,32 @@ __host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_spl
   return g;
 }
 
-// acc += floor(v * scale): order-independent accumulation of an fp32 partial sum.  The 64-bit integer is put together
-// from two 32-bit conversions (6 VALU instructions; the compiler's float -> int64 sequence takes ~16, and there are
-// 4 T of these per tile pair): t = v * scale is exact (power-of-two scale), h = floor(t / 2^32) fits an int32 because
-// |t| < 2^63, and the remainder t - h 2^32 is an exact fp32 number in [0, 2^32).
-__device__ __forceinline__ void fx_add(long long* acc, float v, float scale) {
+// acc += trunc(v * scale): order-independent accumulation of an fp32 partial sum (rounded toward zero to a whole unit of
+// 1 / scale, i.e. 2^-61 of the bound on the sum: nine decimal digits below the fp32 rounding of the partial itself).
+// The 64-bit integer is put together from two 32-bit conversions of the MAGNITUDE and negated as an integer for
+// negative partials (11 VALU instructions; the compiler's float -> int64 sequence takes ~16, and there are 4 T of these
+// per tile pair).  Every step is exact: t = v * scale (power-of-two scale), a = |t| < 2^63, h = floor(a / 2^32) < 2^31,
+// and the remainder a - h 2^32 is an fp32 number in [0, 2^32) -- a multiple of ulp(a) below 2^32 has no more significant
+// bits than a -- whose conversion to u32 drops at most a fraction.  (Round 2 split the SIGNED t: for t in (-2^31, 0) the
+// remainder t + 2^32 is not an fp32 number and rounded by up to 128 units, up to 2^32 itself, whose conversion is
+// undefined in C++.)
+__device__ __forceinline__ unsigned long long fx_units(float v, float scale) {
   const float t = v * scale;
-  const float h = __builtin_floorf(t * 2.3283064365386963e-10f);            // 2^-32
-  const float r = __builtin_fmaf(-h, 4294967296.0f, t);
-  const unsigned lo = (unsigned)r;
-  const int hi = (int)h;
-  atomicAdd(reinterpret_cast<unsigned long long*>(acc), ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)lo);
+  const float a = __builtin_fabsf(t);
+  const float h = __builtin_floorf(a * 2.3283064365386963e-10f);            // 2^-32
+  const float r = __builtin_fmaf(-h, 4294967296.0f, a);
+  const unsigned long long m = ((unsigned long long)(unsigned)h << 32) | (unsigned long long)(unsigned)r;
+  const unsigned long long s = (unsigned long long)((long long)__builtin_bit_cast(int, t) >> 31);   // all ones for t < 0
+  return (m ^ s) - s;                                                        // two's complement of -m when t < 0
+}
+__device__ __forceinline__ void fx_add(long long* acc, float v, float scale) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(acc), fx_units(v, scale));
+}
+
+// measurement / test probe (ludvm_fixed_point_probe): out[i] = the integer fx_add would add for v[i]
+__global__ void __launch_bounds__(kBlock) fx_probe(const float* v, long long n, float scale, long long* out) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = (long long)fx_units(v[i], scale);
 }
 
 // lane l receives the value of lane l+1 (wrapping): data moves one lane down
@@ -155,6 +170,13 @@ __device__ __forceinline__ f32x2 pk_mul_sel(f32x2 s, f32x2 p, int half, f32x2 af
   return d;
 }
 
+// p[i] for i < n, `pad` beyond: the load itself is unconditional (index clamped into the array), so the tile loads are
+// straight-line code instead of one branch per element.  The array holds at least one element.
+__device__ __forceinline__ float load_or(const float* p, unsigned i, unsigned n, float pad) {
+  const float v = p[i < n ? i : 0u];
+  return i < n ? v : pad;
+}
+
 // Slab helpers: a wave's LDS slab holds T floats per home lane and component, as T/4 planes of
 // [64 home lanes][4 floats]: every ds_read_b128 / ds_write_b128 of a wave then covers 64 consecutive
 // 16-byte slots (conflict-free); `home4` is 4 * home lane.
@@ -197,7 +219,7 @@ __device__ __forceinline__ void slab_load(const float* l, int home4, f32x2 (&out
 __device__ unsigned long long* g_wave_trace = nullptr;
 #endif
 template <int T, bool HILO = false, int R = 1, bool RED = (R > 1)>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T == 8 || HILO ? LUDVM_SYM_OCC8 : (R == 1 ? 6 : 4))))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T == 8 || HILO ? LUDVM_SYM_OCC8 : 4)))
 pair_sym_f32(SymArgs a) {
   static_assert(T == 4 || T == 8, "T vortices per lane, read as T/4 ds_read_b128 per component");
   static_assert(R == 1 || R == 2 || R == 4, "waves per item");
@@ -243,140 +265,133 @@ pair_sym_f32(SymArgs a) {
   const bool active = q < x_n * a.ysplit;
   const long long item = active ? (q / x_n) * a.i_count + x_lo + q % x_n : 0;
   if (!RED && !active) return;             // no barriers on this path: whole waves leave
-  const long long I = a.i_first + (active ? item % a.i_count : 0);
+  // (vortex and tile indices are 32-bit from here on -- the launcher refuses n >= 2^31 -- so that per-lane addresses are
+  // a scalar base plus a 32-bit offset register instead of 64-bit register pairs)
+  const unsigned n = (unsigned)a.n, ntiles = (unsigned)a.ntiles;
+  const unsigned I = (unsigned)(a.i_first + (active ? item % a.i_count : 0));
   const int y = active ? (int)(item / a.i_count) : 0;
   // This wave does rotation steps [k_lo, k_hi) of every tile pair.  A J accumulator set that starts in lane l at step
   // k_lo belongs to home lane (l + k_lo) and, one lane per step, sits in lane (home - k_hi) after the last step.
   const int k_lo = r * (64 / R);
   const int k_hi = k_lo + 64 / R;
-  const long long W = 64LL * T;
+  constexpr unsigned W = 64u * T;
   float* const lx = slab[wv][0];
   float* const lz = slab[wv][1];
   float* const lg = slab[wv][2];
   float* const lxl = slab[wv][HILO ? 3 : 0];
   float* const lzl = slab[wv][HILO ? 4 : 1];
 
-  const bool even = (a.ntiles % 2 == 0) && a.ntiles > 1;
-  const long long dtot = a.dmax + (even ? 1 : 0);
-  const long long per = (dtot + a.ysplit - 1) / a.ysplit;
-  const long long d_lo = 1 + (long long)y * per;
-  long long d_hi = d_lo + per;  // exclusive
+  const bool even = (ntiles % 2 == 0) && ntiles > 1;
+  const int dtot = (int)a.dmax + (even ? 1 : 0);
+  const int per = (dtot + a.ysplit - 1) / a.ysplit;
+  const int d_lo = 1 + y * per;
+  int d_hi = d_lo + per;  // exclusive
   if (d_hi > dtot + 1) d_hi = dtot + 1;
 
-  // my targets (duplicated into register pairs: the packed ops pair two SOURCES against one target).  With local
-  // origins a 512-vortex tile (T = 8) spans NS = 2 origin blocks: the targets are then kept once per origin block
-  // of the partner tile (xq / zq[s]: referred to the origin of J's s-th block), selected by the source's block.
+  // my targets.  The packed ops pair two SOURCES against one target; targets 2 h and 2 h + 1 share register pair h and
+  // op_sel broadcasts the wanted half (kPackTargets).
+  // Local origins: a vortex's offset is relative to the origin of its CLASS -- its 256-vortex block x its index parity
+  // (pair_kernels.hpp).  Lane l holds vortices I W + l + 64 t: their index parity is the lane's, their block is t / 4.
+  // A partner tile J is taken in NS = T / 4 passes, one per origin block q of J (plane q of the slab: 4 J vortices per
+  // home lane), and at rotation step k a lane meets the J vortices of home lane l + k, whose index parity is the
+  // lane's own when k is even and the other one when k is odd: the targets are therefore kept twice per pass,
+  // xq / zq[0] referred to the origin of J's class (q, own parity) and xq / zq[1] to (q, other parity), and the rotation
+  // loop alternates between them -- the same 11 packed ops + 2 rsq per two unordered pairs as plain fp32, and no more
+  // target registers than the one-origin-per-block layout of round 2 needed for a 512-vortex tile.
   constexpr int NS = T / 4;
-  // (targets 2 h and 2 h + 1 share register pair h: see kPackTargets)
   f32x2 xp[H], zp[H], gp[H], au[T], aw[T], xpl[H], zpl[H];
-  f32x2 xq[NS][H], zq[NS][H];
-  float x0[T], z0[T], g0[T], xl0[T], zl0[T];
+  f32x2 xq[2][H], zq[2][H];
+  {
+    float x0[T], z0[T], g0[T], xl0[T], zl0[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const long long i = I * W + lane + 64LL * t;
-    const bool ok = active && i < a.n;
-    x0[t] = ok ? a.x[i] : kPadPosF; z0[t] = ok ? a.z[i] : kPadPosF; g0[t] = ok ? a.g[i] : 0.0f;
-    xl0[t] = (HILO && ok) ? a.xl[i] : 0.0f; zl0[t] = (HILO && ok) ? a.zl[i] : 0.0f;
-    au[t] = (f32x2){0.f, 0.f}; aw[t] = (f32x2){0.f, 0.f};
-  }
+    for (int t = 0; t < T; ++t) {
+      const unsigned i = I * W + lane + 64u * t;
+      const unsigned nl = active ? n : 0u;         // (an idle wave of a reducing workgroup holds padding only)
+      x0[t] = load_or(a.x, i, nl, kPadPosF); z0[t] = load_or(a.z, i, nl, kPadPosF); g0[t] = load_or(a.g, i, nl, 0.0f);
+      xl0[t] = HILO ? load_or(a.xl, i, nl, 0.0f) : 0.0f; zl0[t] = HILO ? load_or(a.zl, i, nl, 0.0f) : 0.0f;
+      au[t] = (f32x2){0.f, 0.f}; aw[t] = (f32x2){0.f, 0.f};
+    }
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
-    xp[h] = (f32x2){x0[2 * h], x0[2 * h + 1]}; zp[h] = (f32x2){z0[2 * h], z0[2 * h + 1]};
-    gp[h] = (f32x2){g0[2 * h], g0[2 * h + 1]};
-    xpl[h] = (f32x2){xl0[2 * h], xl0[2 * h + 1]}; zpl[h] = (f32x2){zl0[2 * h], zl0[2 * h + 1]};
+    for (int h = 0; h < H; ++h) {
+      xp[h] = (f32x2){x0[2 * h], x0[2 * h + 1]}; zp[h] = (f32x2){z0[2 * h], z0[2 * h + 1]};
+      gp[h] = (f32x2){g0[2 * h], g0[2 * h + 1]};
+      xpl[h] = (f32x2){xl0[2 * h], xl0[2 * h + 1]}; zpl[h] = (f32x2){zl0[2 * h], zl0[2 * h + 1]};
+      xq[0][h] = xp[h]; xq[1][h] = xp[h]; zq[0][h] = zp[h]; zq[1][h] = zp[h];
+    }
   }
   const f32x2 vc4 = {a.vc4, a.vc4};
   const float fxs = a.scale->scale;
-  // local origins: the origins of this tile's NS origin blocks (vortex I*W + lane + 64 t lies in block t / 4)
+  // local origins: the origins of this lane's own classes (block I W / 256 + q, the lane's parity)
   const bool local = !HILO && a.cx != nullptr;
+  const int pl = lane & 1;
+  const unsigned blk_i = (I * W) >> kOriginShift;
   float oix[NS], oiz[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     oix[q] = 0.0f; oiz[q] = 0.0f;
-    if (local && active) { oix[q] = a.cx[((I * W) >> kOriginShift) + q]; oiz[q] = a.cz[((I * W) >> kOriginShift) + q]; }
+    // (a block past the last vortex has no origin record: its slots are padding, any finite number serves)
+    if (local && active && ((blk_i + q) << kOriginShift) < n) { oix[q] = a.cx[2 * (blk_i + q) + pl]; oiz[q] = a.cz[2 * (blk_i + q) + pl]; }
   }
+  // refer this lane's targets to the two origins of block q of tile Jt: [0] the class of the lane's own index parity,
+  // [1] the other.  One rounding of (origin_I - origin_J) + offset per target and class pair: neighbouring classes keep
+  // their relative precision, far ones do not need it.  (Offsets re-read rather than kept: 2 T loads per pass.)
+  auto refer_targets = [&](unsigned Jt, int q) {
+    // (the offsets are loaded anew for every pass: without this barrier the compiler keeps the 2 T values of one pass in
+    // registers for the next, through the whole rotation loop, and the 512-vortex tile no longer fits three waves per SIMD)
+    asm volatile("" ::: "memory");
+    const unsigned jb = ((Jt * W) >> kOriginShift) + q;
+    const bool has = (jb << kOriginShift) < n;
+    float ojx[2], ojz[2];
 #pragma unroll
-  for (int q = 0; q < NS; ++q)
+    for (int rr = 0; rr < 2; ++rr) {
+      ojx[rr] = has ? a.cx[2 * jb + (pl ^ rr)] : 0.0f;
+      ojz[rr] = has ? a.cz[2 * jb + (pl ^ rr)] : 0.0f;
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      // diagonal tile: block t / 4 of I against block q of I
-      const float ddx = oix[t / 4] - oix[q], ddz = oiz[t / 4] - oiz[q];
-      if (t & 1) { xq[q][t / 2].y = x0[t] + ddx; zq[q][t / 2].y = z0[t] + ddz; }
-      else { xq[q][t / 2].x = x0[t] + ddx; zq[q][t / 2].x = z0[t] + ddz; }
-    }
-  float chk = 0.0f;   // sum of everything this lane hands to the accumulators: not finite <=> some partial is not
-
-  // ---- diagonal tile: ordered evaluation, i-side only (contains the self pairs) ----------------
-  if (active && y == 0) {
-    slab_store<T>(lx, lane * 4, x0); slab_store<T>(lz, lane * 4, z0); slab_store<T>(lg, lane * 4, g0);
-    if (HILO) { slab_store<T>(lxl, lane * 4, xl0); slab_store<T>(lzl, lane * 4, zl0); }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int k = k_lo; k < k_hi; ++k) {
-      const int pos = ((lane + k) & 63) * 4;
-      f32x2 xj[H], zj[H], gj[H], xjl[H], zjl[H];
-      slab_load<T>(lx, pos, xj); slab_load<T>(lz, pos, zj); slab_load<T>(lg, pos, gj);
-      if (HILO) { slab_load<T>(lxl, pos, xjl); slab_load<T>(lzl, pos, zjl); }
+      const unsigned i = I * W + lane + 64u * t;
+      const float xi = load_or(a.x, i, n, kPadPosF), zi = load_or(a.z, i, n, kPadPosF);
 #pragma unroll
-      for (int m = 0; m < H; ++m) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          f32x2 dx = pk_sub_sel(HILO ? xp[t / 2] : xq[m / 2][t / 2], xj[m], t & 1);
-          f32x2 dz = pk_sub_sel(HILO ? zp[t / 2] : zq[m / 2][t / 2], zj[m], t & 1);
-          if (HILO) { dx = dx + pk_sub_sel(xpl[t / 2], xjl[m], t & 1); dz = dz + pk_sub_sel(zpl[t / 2], zjl[m], t & 1); }
-          f32x2 r2 = dx * dx;
-          r2 = __builtin_elementwise_fma(dz, dz, r2);
-          const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
-          f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
-          s = s * gj[m];
-          au[t] = __builtin_elementwise_fma(dz, s, au[t]);
-          aw[t] = __builtin_elementwise_fma(dx, s, aw[t]);
-        }
+      for (int rr = 0; rr < 2; ++rr) {
+        const float xx = xi + (oix[t / 4] - ojx[rr]), zz = zi + (oiz[t / 4] - ojz[rr]);
+        if (t & 1) { xq[rr][t / 2].y = xx; zq[rr][t / 2].y = zz; }
+        else { xq[rr][t / 2].x = xx; zq[rr][t / 2].x = zz; }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
+  };
+  // the 4 J vortices (two packed pairs) that plane q of the slab holds for the home lane at byte position pos4 / 4
+  auto load_plane = [&](const float* l, int q, int pos4, f32x2 (&out)[2]) {
+    const f32x4 V = *reinterpret_cast<const f32x4*>(&l[q * 256 + pos4]);
+    out[0] = (f32x2){V.x, V.y};
+    out[1] = (f32x2){V.z, V.w};
+  };
+  float chk = 0.0f;   // sum of everything this lane hands to the accumulators: not finite <=> some partial is not
 
-  // ---- off-diagonal tiles: each unordered pair once, both sides accumulated --------------------
-  // (`per` rounds for every wave of the workgroup; a round without a tile pair only takes part in the barrier)
-  for (long long dd = 0; dd < per; ++dd) {
-    const long long d = d_lo + dd;
-    const bool valid = active && d < d_hi && !(even && d == dtot && I >= a.ntiles / 2);  // the half-way offset pairs each tile twice
-    long long J = I + d;
-    if (J >= a.ntiles) J -= a.ntiles;
+  // ---- tile pairs: each unordered pair once, both sides accumulated ------------------------------------------------
+  // Round -1 (items of d-chunk 0 only) is the diagonal tile, J = I, which holds the self pairs: the same code, but over
+  // the 64 rotation steps every ordered pair (i, j) of the tile is met from i's lane AND from j's, so the i side alone
+  // is the complete ordered sum and the J-side accumulators are dropped.  (A separate ordered loop for it -- 8 instead
+  // of 11 packed ops per two pairs on 1 of ~NT/2 tile pairs -- made the compiler carry ~60 more live registers through
+  // the rotation loops.)  Rounds 0 .. per - 1 are the item's tile pairs; every wave of the workgroup runs all of them,
+  // valid or not, because the reducing variants meet at two workgroup barriers per round (none in round -1).
+  for (int dd = (active && y == 0) ? -1 : 0; dd < per; ++dd) {
+    const bool diag = dd < 0;
+    const int d = diag ? 0 : d_lo + dd;
+    const bool valid = diag || (active && d < d_hi && !(even && d == dtot && I >= ntiles / 2));  // the half-way offset pairs each tile twice
+    unsigned J = I + (unsigned)d;
+    if (J >= ntiles) J -= ntiles;
     if (!RED && !valid) continue;
     f32x2 bu[H], bw[H];
 #pragma unroll
     for (int m = 0; m < H; ++m) { bu[m] = (f32x2){0.f, 0.f}; bw[m] = (f32x2){0.f, 0.f}; }
     if (valid) {
-      if (local) {
-        // refer my targets to the origins of the partner tile's blocks: one rounding of (origin_I - origin_J) + offset
-        // per target and block pair; neighbouring blocks keep their relative precision, far ones do not need it
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          // (re-read rather than kept in registers: T loads per 64 * T * T pair evaluations)
-          const long long i = I * W + lane + 64LL * t;
-          const bool ok = i < a.n;
-          const float xi = ok ? a.x[i] : kPadPosF, zi = ok ? a.z[i] : kPadPosF;
-#pragma unroll
-          for (int q = 0; q < NS; ++q) {
-            const long long jb = ((J * W) >> kOriginShift) + q;
-            const float xx = xi + (oix[t / 4] - a.cx[jb]), zz = zi + (oiz[t / 4] - a.cz[jb]);
-            if (t & 1) { xq[q][t / 2].y = xx; zq[q][t / 2].y = zz; }
-            else { xq[q][t / 2].x = xx; zq[q][t / 2].x = zz; }
-          }
-        }
-      }
       {
         float x[T], z[T], g[T], xl[T], zl[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const long long j = J * W + lane + 64LL * t;
-          const bool ok = j < a.n;
-          x[t] = ok ? a.x[j] : kPadPosF; z[t] = ok ? a.z[j] : kPadPosF; g[t] = ok ? a.g[j] : 0.0f;
-          xl[t] = (HILO && ok) ? a.xl[j] : 0.0f; zl[t] = (HILO && ok) ? a.zl[j] : 0.0f;
+          const unsigned j = J * W + lane + 64u * t;
+          x[t] = load_or(a.x, j, n, kPadPosF); z[t] = load_or(a.z, j, n, kPadPosF); g[t] = load_or(a.g, j, n, 0.0f);
+          xl[t] = HILO ? load_or(a.xl, j, n, 0.0f) : 0.0f; zl[t] = HILO ? load_or(a.zl, j, n, 0.0f) : 0.0f;
         }
         slab_store<T>(lx, lane * 4, x); slab_store<T>(lz, lane * 4, z); slab_store<T>(lg, lane * 4, g);
         if (HILO) { slab_store<T>(lxl, lane * 4, xl); slab_store<T>(lzl, lane * 4, zl); }
@@ -385,36 +400,46 @@ pair_sym_f32(SymArgs a) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-      // (issuing the reads of step k+1 ahead of the arithmetic of step k measured no gain: with 4-5
-      // waves per SIMD the LDS latency is already covered)
-      for (int k = k_lo; k < k_hi; ++k) {
-        // at step k this lane holds the accumulators of the J vortices whose home lane is (lane + k) % 64
-        const int pos = ((lane + k) & 63) * 4;
-        f32x2 xj[H], zj[H], gj[H], xjl[H], zjl[H];
-        slab_load<T>(lx, pos, xj); slab_load<T>(lz, pos, zj); slab_load<T>(lg, pos, gj);
-        if (HILO) { slab_load<T>(lxl, pos, xjl); slab_load<T>(lzl, pos, zjl); }
+      // Pass q: my T targets against the 4 J vortices per home lane of J's origin block q (J accumulators bu / bw[2 q],
+      // [2 q + 1]); every pass walks the wave's rotation steps [k_lo, k_hi), so all J accumulators end up with the same
+      // home lane.  (Issuing the reads of step k+1 ahead of the arithmetic of step k measured no gain: with 3-5 waves
+      // per SIMD the LDS latency is already covered.)
 #pragma unroll
-        for (int m = 0; m < H; ++m) {
+      for (int q = 0; q < NS; ++q) {
+        if (local) refer_targets(J, q);
+        for (int k = k_lo; k < k_hi; k += 2) {
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
-            f32x2 dx = pk_sub_sel(HILO ? xp[t / 2] : xq[m / 2][t / 2], xj[m], t & 1);
-            f32x2 dz = pk_sub_sel(HILO ? zp[t / 2] : zq[m / 2][t / 2], zj[m], t & 1);
-            if (HILO) { dx = dx + pk_sub_sel(xpl[t / 2], xjl[m], t & 1); dz = dz + pk_sub_sel(zpl[t / 2], zjl[m], t & 1); }
-            f32x2 r2 = dx * dx;
-            r2 = __builtin_elementwise_fma(dz, dz, r2);
-            const f32x2 q = __builtin_elementwise_fma(r2, r2, vc4);
-            const f32x2 s = {__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
-            const f32x2 sj = s * gj[m];      // strength of j acting on i
-            const f32x2 si = pk_mul_sel(s, gp[t / 2], t & 1, sj);  // strength of i acting on j
-            au[t] = __builtin_elementwise_fma(dz, sj, au[t]);
-            aw[t] = __builtin_elementwise_fma(dx, sj, aw[t]);
-            bu[m] = __builtin_elementwise_fma(dz, si, bu[m]);
-            bw[m] = __builtin_elementwise_fma(dx, si, bw[m]);
+          for (int rr = 0; rr < 2; ++rr) {
+            // at step k this lane holds the accumulators of the J vortices whose home lane is (lane + k) % 64
+            const int pos = ((lane + k + rr) & 63) * 4;
+            f32x2 xj[2], zj[2], gj[2], xjl[2], zjl[2];
+            load_plane(lx, q, pos, xj); load_plane(lz, q, pos, zj); load_plane(lg, q, pos, gj);
+            if (HILO) { load_plane(lxl, q, pos, xjl); load_plane(lzl, q, pos, zjl); }
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+              const int m = 2 * q + mm;
+#pragma unroll
+              for (int t = 0; t < T; ++t) {
+                f32x2 dx = pk_sub_sel(HILO ? xp[t / 2] : xq[rr][t / 2], xj[mm], t & 1);
+                f32x2 dz = pk_sub_sel(HILO ? zp[t / 2] : zq[rr][t / 2], zj[mm], t & 1);
+                if (HILO) { dx = dx + pk_sub_sel(xpl[t / 2], xjl[mm], t & 1); dz = dz + pk_sub_sel(zpl[t / 2], zjl[mm], t & 1); }
+                f32x2 r2 = dx * dx;
+                r2 = __builtin_elementwise_fma(dz, dz, r2);
+                const f32x2 qq = __builtin_elementwise_fma(r2, r2, vc4);
+                const f32x2 sv = {__builtin_amdgcn_rsqf(qq.x), __builtin_amdgcn_rsqf(qq.y)};
+                const f32x2 sj = sv * gj[mm];      // strength of j acting on i
+                const f32x2 si = pk_mul_sel(sv, gp[t / 2], t & 1, sj);  // strength of i acting on j
+                au[t] = __builtin_elementwise_fma(dz, sj, au[t]);
+                aw[t] = __builtin_elementwise_fma(dx, sj, aw[t]);
+                bu[m] = __builtin_elementwise_fma(dz, si, bu[m]);
+                bw[m] = __builtin_elementwise_fma(dx, si, bw[m]);
+              }
+            }
+            // hand the pass's J accumulators to the lane that meets the same J vortices next step (lane - 1)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) { bu[2 * q + mm] = dpp_rol1(bu[2 * q + mm]); bw[2 * q + mm] = dpp_rol1(bw[2 * q + mm]); }
           }
         }
-        // hand the J accumulators to the lane that meets the same J vortices next step (lane - 1)
-#pragma unroll
-        for (int m = 0; m < H; ++m) { bu[m] = dpp_rol1(bu[m]); bw[m] = dpp_rol1(bw[m]); }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next tile
@@ -424,13 +449,14 @@ pair_sym_f32(SymArgs a) {
     // home lane h holds vortices J*W + h + 64*t as packed elements t = 0..T-1; component c = 4 m + {0: u of element
     // 2m, 1: u of 2m+1, 2: w of 2m, 3: w of 2m+1}
     const int home = (lane + k_hi) & 63;
+    if (diag) continue;        // (no barrier in this round)
     if constexpr (!RED) {
       if (valid) {
 #pragma unroll
         for (int m = 0; m < H; ++m) {
-          const long long j0 = J * W + home + 64LL * (2 * m), j1 = j0 + 64;
-          if (j0 < a.n) { fx_add(&a.acc_u[j0], -bu[m].x, fxs); fx_add(&a.acc_w[j0], -bw[m].x, fxs); chk += bu[m].x + bw[m].x; }
-          if (j1 < a.n) { fx_add(&a.acc_u[j1], -bu[m].y, fxs); fx_add(&a.acc_w[j1], -bw[m].y, fxs); chk += bu[m].y + bw[m].y; }
+          const unsigned j0 = J * W + home + 64u * (2 * m), j1 = j0 + 64;
+          if (j0 < n) { fx_add(&a.acc_u[j0], -bu[m].x, fxs); fx_add(&a.acc_w[j0], -bw[m].x, fxs); chk += bu[m].x + bw[m].x; }
+          if (j1 < n) { fx_add(&a.acc_u[j1], -bu[m].y, fxs); fx_add(&a.acc_w[j1], -bw[m].y, fxs); chk += bu[m].y + bw[m].y; }
         }
       }
     } else {
@@ -449,8 +475,8 @@ pair_sym_f32(SymArgs a) {
           float v = 0.0f;
 #pragma unroll
           for (int q = 0; q < R; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
-          const long long j = J * W + lane + 64LL * (2 * (c / 4) + (c & 1));
-          if (j < a.n) { fx_add((c & 2) ? &a.acc_w[j] : &a.acc_u[j], -v, fxs); chk += v; }
+          const unsigned j = J * W + lane + 64u * (2 * (c / 4) + (c & 1));
+          if (j < n) { fx_add((c & 2) ? &a.acc_w[j] : &a.acc_u[j], -v, fxs); chk += v; }
         }
       }
       __syncthreads();     // the slabs are rewritten by the next tile pair
@@ -461,8 +487,8 @@ pair_sym_f32(SymArgs a) {
   if constexpr (!RED) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const long long i = I * W + lane + 64LL * t;
-      if (i < a.n) {
+      const unsigned i = I * W + lane + 64u * t;
+      if (i < n) {
         const float su = au[t].x + au[t].y, sw = aw[t].x + aw[t].y;
         fx_add(&a.acc_u[i], su, fxs); fx_add(&a.acc_w[i], sw, fxs);
         chk += su + sw;
@@ -478,8 +504,8 @@ pair_sym_f32(SymArgs a) {
         float v = 0.0f;
 #pragma unroll
         for (int q = 0; q < R; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
-        const long long i = I * W + lane + 64LL * (c / 2);
-        if (i < a.n) { fx_add((c & 1) ? &a.acc_w[i] : &a.acc_u[i], v, fxs); chk += v; }
+        const unsigned i = I * W + lane + 64u * (c / 2);
+        if (i < n) { fx_add((c & 1) ? &a.acc_w[i] : &a.acc_u[i], v, fxs); chk += v; }
       }
     }
   }
@@ -641,7 +667,7 @@ __global__ void __launch_bounds__(kFinBlock)
 finish_wake_advect_sym(const long long* acc_u, const long long* acc_w, const SymScale* sc, const long long* bad, long long nt,
                        int nfoil, float vc4, double dt, double* x64, double* z64, Mirrors m, const float* g32, double* u_out,
                        double* w_out, const long long* n_dev = nullptr, TailDuty td = TailDuty{}) {
-  __shared__ float org[2];
+  __shared__ float org[4];
   if (n_dev) nt = *n_dev;          // device-resident march: the wake size lives on the device
   tail_duty_block0(td, nt);
   const long long i = (long long)blockIdx.x * kFinBlock + threadIdx.x;
@@ -656,13 +682,13 @@ finish_wake_advect_sym(const long long* acc_u, const long long* acc_w, const Sym
     if (u_out) { u_out[i] = (double)su; w_out[i] = (double)sw; }
     xn = xo + dt * (double)su;
     zn = zo + dt * (double)sw;
-    if (i == origin_index(blockIdx.x, nt)) { org[0] = (float)xn; org[1] = (float)zn; m.cx[blockIdx.x] = org[0]; m.cz[blockIdx.x] = org[1]; }
+    publish_origins(m, i, nt, xn, zn, org);
   }
   __syncthreads();
   if (!on) return;
   x64[i] = xn;
   z64[i] = zn;
-  store_mirrors(m, i, xn, zn, org[0], org[1]);
+  store_mirrors(m, i, xn, zn, org[i & 1], org[2 + (i & 1)]);
   tail_duty(td, i, nt, xn, zn);
 }
 

@@ -360,6 +360,15 @@ class Engine:
     def vorticity_dev(self, d_u, d_w, nx, nz, dr, d_ome):
         self._check(self._lib.ludvm_vorticity_dev_f32(self._ctx, d_u, d_w, int(nx), int(nz), float(dr), d_ome))
 
+    def fixed_point_probe(self, values, scale_log2):
+        """int64 units the symmetric kernel adds to an accumulator for fp32 partial sums `values` at scale
+        2**scale_log2 (ludvm_fixed_point_probe): trunc(value * scale), exact below 2**63."""
+        v = _f32(values)
+        out = np.empty(len(v), np.int64)
+        self._check(self._lib.ludvm_fixed_point_probe(self._ctx, _pf(v), len(v), int(scale_log2),
+                                                      out.ctypes.data_as(POINTER(c_longlong))))
+        return out
+
     # -- measurement -----------------------------------------------------------------------------
     def kernel_timing(self, enable=True):
         self._check(self._lib.ludvm_kernel_timing(self._ctx, 1 if enable else 0))

@@ -578,6 +578,27 @@ def test_symmetric_kernel_fixed_point_scale_follows_the_circulations(eng, gscale
         eng.set_stream(None)
 
 
+def test_fixed_point_conversion_is_exact(eng):
+    """fx_add's float -> 64-bit integer conversion through the kernel's own code (ludvm_fixed_point_probe): trunc(v * 2^k),
+    exactly, for every |v * 2^k| < 2^63 -- small negative partial sums included (round 2 split the signed product: for
+    t in (-2^31, 0) its remainder t + 2^32 is not an fp32 number and the result was off by up to 128 units)."""
+    import math
+    from fractions import Fraction
+    rng = np.random.default_rng(77)
+    special = [0.0, -0.0, 0.5, -0.5, 1.0, -1.0, -100.0, 100.25, -100.75, -2.0**31 + 128, 2.0**31 - 128, -2.0**31, 2.0**31,
+               -2.0**32, 2.0**32 - 256, -(2.0**32 - 256), 2.0**32 + 512, -(2.0**32 + 512), 2.0**62, -2.0**62,
+               float(np.float32(2.0**63 - 2.0**39)), -float(np.float32(2.0**63 - 2.0**39)), 1e-30, -1e-30, 3.0**20, -(3.0**20)]
+    rand = np.concatenate([rng.standard_normal(2000) * s for s in (1.0, 1e3, 2.0**31, 2.0**40, 2.0**61)])
+    v = np.concatenate([np.array(special), rand]).astype(np.float32)
+    for k in (0, 7, -9):
+        vals = v if k == 0 else (v * np.float32(2.0 ** -k)).astype(np.float32)
+        keep = np.abs(vals.astype(np.float64) * 2.0**k) < 2.0**63
+        vals = vals[keep]
+        got = eng.fixed_point_probe(vals, k)
+        want = np.array([math.trunc(Fraction(float(x)) * Fraction(2) ** k) for x in vals], dtype=object)
+        assert all(int(a) == int(b) for a, b in zip(got, want)), [(float(x), int(a), int(b)) for x, a, b in zip(vals, got, want) if int(a) != int(b)][:5]
+
+
 def test_symmetric_kernel_propagates_nan_like_the_reference(eng):
     """A NaN source position poisons the sum at every target in the reference (LUDVM.py:565-569); the fixed-point
     accumulators cannot hold a NaN, so the launch counts non-finite partial sums and the finisher returns NaN."""
