@@ -293,6 +293,13 @@ int ludvm_flowfield_vorticity_f32(ludvm_ctx* ctx, double xmin, double zmin, doub
 int ludvm_flowfield_rows_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz, size_t row_first,
                              size_t row_count, const double* xs, const double* zs, const double* gs, size_t ns,
                              double vcore, float* u, float* w, float* ome);
+/* The same rows in float64 throughout -- pair sums, grid coordinates and the vorticity stencil with the mesh differences
+ * taken from the mesh values, as the reference evaluates flowfield (LUDVM.py:1206, :1216-1217, :1224-1292): u, w and ome
+ * then equal the reference's to rounding (~1e-13 of their maxima).  Outputs are host float64 arrays of row_count * nz;
+ * the whole grid is row_first = 0, row_count = nx.  LUDVM.flowfield uses it when the run's precision is 'f64'. */
+int ludvm_flowfield_rows_f64(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz, size_t row_first,
+                             size_t row_count, const double* xs, const double* zs, const double* gs, size_t ns,
+                             double vcore, double* u, double* w, double* ome);
 /* Same as ludvm_flowfield_f32, device-resident fp32 sources and outputs (asynchronous). */
 int ludvm_flowfield_dev_f32(ludvm_ctx* ctx, double xmin, double zmin, double dr, size_t nx, size_t nz,
                             const float* d_xs, const float* d_zs, const float* d_gs, size_t ns, float vcore,

@@ -67,6 +67,8 @@ SIGNATURES = {
                                       c_double, _pf, _pf, _pf],
     "ludvm_flowfield_rows_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, c_size_t, c_size_t, _pd, _pd, _pd,
                                  c_size_t, c_double, _pf, _pf, _pf],
+    "ludvm_flowfield_rows_f64": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, c_size_t, c_size_t, _pd, _pd, _pd,
+                                 c_size_t, c_double, _pd, _pd, _pd],
     "ludvm_flowfield_dev_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_float, c_void_p, c_void_p],
     "ludvm_vorticity_f32": [c_void_p, _pf, _pf, c_size_t, c_size_t, c_double, _pf],

@@ -1749,9 +1749,15 @@ int ludvm_flowfield_vorticity_f32(ludvm_ctx* c, double xmin, double zmin, double
   return ludvm_flowfield_rows_f32(c, xmin, zmin, dr, nx, nz, 0, nx, xs, zs, gs, ns, vcore, u, w, ome);
 }
 
-int ludvm_flowfield_rows_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, size_t row_first,
-                             size_t row_count, const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
-                             float* u, float* w, float* ome) {
+}  // extern "C"
+
+// Rows [row_first, row_first + row_count) of the grid, in fp32 on local-origin sources (T = float) or in float64
+// throughout (T = double), with the vorticity stencil on the device.
+template <typename T>
+static int flowfield_rows(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, size_t row_first,
+                          size_t row_count, const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
+                          T* u, T* w, T* ome) {
+  constexpr bool f64 = sizeof(T) == 8;
   if (!c) return LUDVM_E_ARG;
   if (row_first + row_count > nx) return fail(c, LUDVM_E_ARG, "rows outside the grid");
   if (row_count == 0 || nz == 0) return LUDVM_OK;
@@ -1763,17 +1769,27 @@ int ludvm_flowfield_rows_f32(ludvm_ctx* c, double xmin, double zmin, double dr, 
   const size_t h0 = ome && row_first > 0 ? row_first - 1 : row_first;
   const size_t h1 = ome && row_first + row_count < nx ? row_first + row_count + 1 : row_first + row_count;
   const size_t rows = h1 - h0, nt = rows * nz;
-  CHK(ensure(c, c->arena, flowfield_upload_bytes(ns) + 3 * Arena::need(nt, 4)));
+  CHK(ensure(c, c->arena, (f64 ? 3 * Arena::need(ns, 8) : flowfield_upload_bytes(ns)) + 3 * Arena::need(nt, sizeof(T))));
   Arena ar(c->arena.p);
-  float* du = ar.take<float>(nt);
-  float* dw = ar.take<float>(nt);
-  float* dome = ar.take<float>(nt);
+  T* du = ar.take<T>(nt);
+  T* dw = ar.take<T>(nt);
+  T* dome = ar.take<T>(nt);
   if (ns == 0) {
-    HIPCHK(c, hipMemsetAsync(du, 0, nt * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(dw, 0, nt * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(du, 0, nt * sizeof(T), c->stream));
+    HIPCHK(c, hipMemsetAsync(dw, 0, nt * sizeof(T), c->stream));
   } else {
     PairArgs a{};
-    CHK(flowfield_upload_local(c, ar, xs, zs, gs, ns, a));
+    if (f64) {
+      double* dxs = ar.take<double>(ns);
+      double* dzs = ar.take<double>(ns);
+      double* dgs = ar.take<double>(ns);
+      HIPCHK(c, hipMemcpyAsync(dxs, xs, ns * 8, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(dzs, zs, ns * 8, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(dgs, gs, ns * 8, hipMemcpyHostToDevice, c->stream));
+      a.xs = dxs; a.zs = dzs; a.gs = dgs; a.ns = (long long)ns;
+    } else {
+      CHK(flowfield_upload_local(c, ar, xs, zs, gs, ns, a));
+    }
     a.nt = (long long)nt;
     a.grid_nz = (long long)nz;
     a.grid_row0 = (long long)h0;
@@ -1781,16 +1797,38 @@ int ludvm_flowfield_rows_f32(ludvm_ctx* c, double xmin, double zmin, double dr, 
     const double v2 = vcore * vcore;
     a.vc4 = v2 * v2;
     // (planned for the whole grid: a block of rows is then bit for bit what the whole-grid call computes for them)
-    CHK(induce_device(c, a, a.nt, a.ns, LUDVM_PREC_F32, du, dw, (long long)(nx * nz)));
+    CHK(induce_device(c, a, a.nt, a.ns, f64 ? LUDVM_PREC_F64 : LUDVM_PREC_F32, du, dw, (long long)(nx * nz)));
   }
   // velocity and vorticity leave the device together: the stencil (LUDVM.py:1224-1292) runs on the fields where they are
-  if (ome) CHK(ludvm_vorticity_dev_f32(c, du, dw, rows, nz, (float)dr, dome));
+  if (ome) {
+    if constexpr (f64) {
+      hipLaunchKernelGGL(vorticity_f64, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, du, dw, (long long)rows,
+                         (long long)nz, (long long)h0, xmin, zmin, dr, dome);
+      HIPCHK(c, hipGetLastError());
+    } else {
+      CHK(ludvm_vorticity_dev_f32(c, du, dw, rows, nz, (float)dr, dome));
+    }
+  }
   const size_t off = (row_first - h0) * nz, cnt = row_count * nz;
-  HIPCHK(c, hipMemcpyAsync(u, du + off, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(w, dw + off, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-  if (ome) HIPCHK(c, hipMemcpyAsync(ome, dome + off, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(u, du + off, cnt * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(w, dw + off, cnt * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+  if (ome) HIPCHK(c, hipMemcpyAsync(ome, dome + off, cnt * sizeof(T), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LUDVM_OK;
+}
+
+extern "C" {
+
+int ludvm_flowfield_rows_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, size_t row_first,
+                             size_t row_count, const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
+                             float* u, float* w, float* ome) {
+  return flowfield_rows<float>(c, xmin, zmin, dr, nx, nz, row_first, row_count, xs, zs, gs, ns, vcore, u, w, ome);
+}
+
+int ludvm_flowfield_rows_f64(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, size_t row_first,
+                             size_t row_count, const double* xs, const double* zs, const double* gs, size_t ns, double vcore,
+                             double* u, double* w, double* ome) {
+  return flowfield_rows<double>(c, xmin, zmin, dr, nx, nz, row_first, row_count, xs, zs, gs, ns, vcore, u, w, ome);
 }
 
 int ludvm_vorticity_dev_f32(ludvm_ctx* c, const float* d_u, const float* d_w, size_t nx, size_t nz, float dr,

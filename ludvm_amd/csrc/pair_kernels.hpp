@@ -866,4 +866,22 @@ vorticity_f32(const float* u, const float* w, long long nx, long long nz, float 
   ome[p] = dw / dxm - du / dzm;
 }
 
+// The same stencil in float64 on rows [row0, row0 + nx) of the grid, with the mesh differences taken from the mesh
+// values themselves as the reference does (x[i+1, j] - x[i-1, j] with x = xmin + i dr, LUDVM.py:1193, :1228-1229): the
+// float64 flow field then equals the reference's to rounding.
+__global__ void __launch_bounds__(kBlock)
+vorticity_f64(const double* u, const double* w, long long nx, long long nz, long long row0, double xmin, double zmin, double dr,
+              double* ome) {
+  const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= nx * nz) return;
+  const long long i = p / nz, j = p - i * nz;
+  const long long ip = i + 1 < nx ? i + 1 : i, im = i > 0 ? i - 1 : i;
+  const long long jp = j + 1 < nz ? j + 1 : j, jm = j > 0 ? j - 1 : j;
+  const double dxm = (xmin + (double)(row0 + ip) * dr) - (xmin + (double)(row0 + im) * dr);
+  const double dzm = (zmin + (double)jp * dr) - (zmin + (double)jm * dr);
+  const double dw = w[ip * nz + j] - w[im * nz + j];
+  const double du = u[i * nz + jp] - u[i * nz + jm];
+  ome[p] = dw / dxm - du / dzm;
+}
+
 }  // namespace ludvm

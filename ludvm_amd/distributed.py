@@ -59,6 +59,9 @@ class ShardGroup:
         dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
         return recv[:n].cpu().numpy().reshape((n,) + tuple(local.shape[1:]))
 
+    def barrier(self):
+        dist.barrier(group=self.group)
+
     # ---- sharded roll-up ---------------------------------------------------------------------------------------
     def attach(self, engine, capacity):
         """Shard the engine's symmetric roll-ups over the group: accumulators in a tensor this object owns, summed by
@@ -70,13 +73,27 @@ class ShardGroup:
         self._acc = torch.zeros([count], dtype=torch.int64, device=dev)
         engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 
-        def allreduce(n):
-            dist.all_reduce(self._acc[:n], op=dist.ReduceOp.SUM, group=self.group)
+        def allreduce(n, stream):
+            # on the stream the library launches on (the one it hands to the hook), whatever torch's current stream is at
+            # the moment of the call: the collective then sits between the symmetric kernel and the Euler finisher
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)) if self.backend == "nccl" else _null():
+                dist.all_reduce(self._acc[:n], op=dist.ReduceOp.SUM, group=self.group)
         engine.set_shard(self.rank, self.world, allreduce, self._acc.data_ptr(), count * 8, self.min_wake)
         return True
 
     def detach(self, engine):
         if self._acc is not None:
-            engine.synchronize()
+            try:
+                engine.synchronize()
+            except Exception:           # (a failed launch must not keep the engine sharded, nor hide the error that led here)
+                pass
             engine.set_shard(0, 1)
             self._acc = None
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False

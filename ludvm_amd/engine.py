@@ -112,12 +112,13 @@ class Engine:
 
     def set_shard(self, rank, world, allreduce=None, d_acc=0, acc_bytes=0, min_vortices=0):
         """Evaluate only tile block `rank` of `world` of every symmetric roll-up of at least `min_vortices` vortices;
-        `allreduce(count)` must enqueue an in-place sum all-reduce of the first `count` int64 of the accumulator buffer
-        at device address `d_acc` (ludvm_set_shard).  world = 1 undoes it."""
+        `allreduce(count, stream)` must enqueue, on the hipStream_t `stream` (an int handle; 0 = the default stream), an
+        in-place sum all-reduce of the first `count` int64 of the accumulator buffer at device address `d_acc`
+        (ludvm_set_shard).  world = 1 undoes it."""
         if world > 1:
-            def hook(_user, _buf, count, _stream):
+            def hook(_user, _buf, count, stream):
                 try:
-                    allreduce(int(count))
+                    allreduce(int(count), int(stream or 0))
                     return 0
                 except Exception as e:       # never let an exception cross the C frame
                     self._hook_error = e
@@ -324,25 +325,25 @@ class Engine:
                                                   _pd(xs), _pd(zs), _pd(g), len(xs), float(v_core), _pf(u), _pf(w)))
         return u.reshape(nx, nz), w.reshape(nx, nz)
 
-    def flowfield_vorticity(self, xmin, zmin, dr, nx, nz, circulation, xw, zw, v_core):
-        """(u, w, ome) float32 [nx, nz]: velocity field and its vorticity (LUDVM.py:1224-1292) in one device round
-        trip -- the stencil runs on the fields where they are."""
-        g, xs, zs = _f64(circulation), _f64(xw), _f64(zw)
-        u, w, ome = (np.empty(nx * nz, np.float32) for _ in range(3))
-        self._check(self._lib.ludvm_flowfield_vorticity_f32(self._ctx, float(xmin), float(zmin), float(dr), int(nx), int(nz),
-                                                            _pd(xs), _pd(zs), _pd(g), len(xs), float(v_core), _pf(u), _pf(w),
-                                                            _pf(ome)))
-        return u.reshape(nx, nz), w.reshape(nx, nz), ome.reshape(nx, nz)
+    def flowfield_vorticity(self, xmin, zmin, dr, nx, nz, circulation, xw, zw, v_core, precision="f32"):
+        """(u, w, ome) [nx, nz]: velocity field and its vorticity (LUDVM.py:1224-1292) in one device round trip -- the
+        stencil runs on the fields where they are.  float32 arrays from fp32 arithmetic on local-origin sources, or,
+        with precision='f64', float64 arrays from float64 arithmetic throughout (the reference's)."""
+        return self.flowfield_rows(xmin, zmin, dr, nx, nz, 0, nx, circulation, xw, zw, v_core, precision=precision)
 
-    def flowfield_rows(self, xmin, zmin, dr, nx, nz, row_first, row_count, circulation, xw, zw, v_core, vorticity=True):
-        """Rows [row_first, row_first + row_count) of the nx x nz grid: (u, w, ome) float32 [row_count, nz], bit for
-        bit what the whole-grid call returns for those rows -- the unit a multi-GPU flow field shards by."""
+    def flowfield_rows(self, xmin, zmin, dr, nx, nz, row_first, row_count, circulation, xw, zw, v_core, vorticity=True,
+                       precision="f32"):
+        """Rows [row_first, row_first + row_count) of the nx x nz grid: (u, w, ome) [row_count, nz], bit for bit what the
+        whole-grid call returns for those rows -- the unit a multi-GPU flow field shards by.  precision 'f32' (float32
+        arrays) or 'f64' (float64 arrays, float64 arithmetic throughout)."""
         g, xs, zs = _f64(circulation), _f64(xw), _f64(zw)
-        u, w = np.empty(row_count * nz, np.float32), np.empty(row_count * nz, np.float32)
-        ome = np.empty(row_count * nz, np.float32) if vorticity else None
-        self._check(self._lib.ludvm_flowfield_rows_f32(self._ctx, float(xmin), float(zmin), float(dr), int(nx), int(nz),
-                                                       int(row_first), int(row_count), _pd(xs), _pd(zs), _pd(g), len(xs),
-                                                       float(v_core), _pf(u), _pf(w), _pf(ome)))
+        f64 = _prec(precision) == PREC_F64
+        dt, ptr = (np.float64, _pd) if f64 else (np.float32, _pf)
+        fn = self._lib.ludvm_flowfield_rows_f64 if f64 else self._lib.ludvm_flowfield_rows_f32
+        u, w = np.empty(row_count * nz, dt), np.empty(row_count * nz, dt)
+        ome = np.empty(row_count * nz, dt) if vorticity else None
+        self._check(fn(self._ctx, float(xmin), float(zmin), float(dr), int(nx), int(nz), int(row_first), int(row_count),
+                       _pd(xs), _pd(zs), _pd(g), len(xs), float(v_core), ptr(u), ptr(w), ptr(ome)))
         sh = (row_count, nz)
         return u.reshape(sh), w.reshape(sh), (ome.reshape(sh) if vorticity else None)
 

@@ -400,9 +400,6 @@ class LUDVM:
         # device wake, in shedding order: FREE first, then each step's TEV (and LEV when shed)
         eng.wake_clear()
         eng.wake_reserve(nf + 2 * nv + npan + 2)
-        if self._shard is not None:
-            # the roll-up's unordered pairs in tile blocks over the ranks, one integer all-reduce per step
-            self._shard.attach(eng, nf + 2 * nv + npan + 2)
         eng.wake_append(free0[0], free0[1], g_free)
         tev_slot = np.zeros(nv, dtype=np.int64)
         lev_slot = np.zeros(nv, dtype=np.int64)
@@ -457,6 +454,10 @@ class LUDVM:
         march_chunk = int(getattr(self, '_march_chunk', 512 if dense_march else 32768))   # steps per ludvm_march_run call
 
         try:
+            if self._shard is not None:
+                # the roll-up's unordered pairs in tile blocks over the ranks, one integer all-reduce per step (attached
+                # inside the try: whatever goes wrong from here on, the engine is left unsharded)
+                self._shard.attach(eng, nf + 2 * nv + npan + 2)
             i = first_step
             while i < nt:
                 if can_march and (dense_march or not self._record_row(i)):
@@ -736,6 +737,12 @@ class LUDVM:
                           tev_slot, lev_slot):
         import json
         import os
+        # one simulation shared by several ranks: every rank holds the same state, rank 0 alone writes it (they would race on
+        # the temporary file), and nobody goes on before the file is in place
+        sh = self._shard if (self._shard is not None and self._shard.world > 1) else None
+        if sh is not None and sh.rank != 0:
+            sh.barrier()
+            return
         C, P = self.circulation, self.path
         n = self.engine.wake_size()
         wx, wz, wg = self.engine.wake_read(0, n, gamma=True)
@@ -762,12 +769,16 @@ class LUDVM:
         tmp = self.checkpoint_path + '.tmp.npz'
         np.savez(tmp, **d)
         os.replace(tmp, self.checkpoint_path)      # a reader never sees a half-written file
+        if sh is not None:
+            sh.barrier()
 
     @classmethod
-    def resume(cls, path, engine=None, device=0, verbose=True, checkpoint_every=0, checkpoint_path=None, march=True):
+    def resume(cls, path, engine=None, device=0, verbose=True, checkpoint_every=0, checkpoint_path=None, march=True,
+               distributed=None):
         """Continue a run from a checkpoint written with `checkpoint_every` / `checkpoint_path`: rebuilds
         geometry and kinematics from the stored constructor arguments, uploads the wake and marches
-        from the stored step to the end."""
+        from the stored step to the end.  `distributed` as in the constructor: every rank of the group resumes from the
+        same file."""
         import json
         R = np.load(path, allow_pickle=False)
         kw = json.loads(str(R['ctor']))
@@ -776,7 +787,7 @@ class LUDVM:
                 or float(np.abs(R['xy_freevort']).sum()) != 0.0:
             free = dict(circulation_freevort=R['circulation_freevort'], xy_freevort=R['xy_freevort'])
         sim = cls(**kw, **free, verbose=verbose, engine=engine, device=device, run=False,
-                  checkpoint_every=checkpoint_every, checkpoint_path=checkpoint_path, march=march)
+                  checkpoint_every=checkpoint_every, checkpoint_path=checkpoint_path, march=march, distributed=distributed)
         sim.time_loop(_resume=R)
         sim.compute_coefficients()
         return sim
@@ -873,7 +884,10 @@ class LUDVM:
         at the requested time steps (LUDVM.py:1186-1298).  The mesh points are generated on the
         device (x-major, as meshgrid(indexing='ij') ravels, :1194-1195); wake and bound vortices go in
         one launch; the vorticity stencil (:1224-1292) runs on the device on the velocity fields where they
-        are, and the three fields come back together."""
+        are, and the three fields come back together.  A run in precision 'f64' (what 'auto' picks for every case whose
+        dense history the reference itself could hold) evaluates the field in float64 throughout, as the reference does
+        (:1206, :1216-1217): u_ff, w_ff and ome_ff then equal the reference's to rounding; 'f32' / 'f32x2' runs evaluate
+        it in fp32 on local-origin sources (~1e-6 of max|u|; the stencil amplifies that by 1 / (2 dr) in ome_ff)."""
         x1, z1 = np.arange(xmin, xmax, dr), np.arange(zmin, zmax, dr)
         nx, nz = len(x1), len(z1)
         x, z = np.meshgrid(x1, z1, indexing='ij')
@@ -883,6 +897,7 @@ class LUDVM:
         ome = np.zeros([nsteps, nx, nz])
         fused = hasattr(self.engine, 'flowfield_vorticity')
         sh = self._shard if (self._shard is not None and self._shard.world > 1) else None
+        ffp = 'f64' if self.precision == 'f64' else 'f32'
         for ii, s in enumerate(tsteps):
             if self.verbose:
                 print('Flowfield tstep =', s)
@@ -897,16 +912,18 @@ class LUDVM:
                 # grid rows in contiguous blocks over the ranks, nothing exchanged until the finished rows are gathered
                 r0, r1, _ = sh.block(nx)
                 if hasattr(self.engine, 'flowfield_rows'):
-                    ub, wb, ob = self.engine.flowfield_rows(xmin, zmin, dr, nx, nz, r0, r1 - r0, g, xw, zw, self.v_core)
+                    ub, wb, ob = self.engine.flowfield_rows(xmin, zmin, dr, nx, nz, r0, r1 - r0, g, xw, zw, self.v_core,
+                                                            precision=ffp)
                 else:       # engines without the row entry: the block with one halo row per interior side
                     h0, h1 = max(0, r0 - 1), min(nx, r1 + 1)
                     uh, wh = self.engine.flowfield(x1[h0] if h1 > h0 else xmin, zmin, dr, h1 - h0, nz, g, xw, zw, self.v_core)
                     oh = self.engine.vorticity(uh, wh, dr) if h1 - h0 >= 2 else np.zeros_like(uh)
                     ub, wb, ob = uh[r0 - h0:r1 - h0], wh[r0 - h0:r1 - h0], oh[r0 - h0:r1 - h0]
-                fields = sh.gather_blocks(np.stack([ub, wb, ob], axis=1).astype(np.float32), nx)     # [nx, 3, nz]
+                fields = sh.gather_blocks(np.stack([ub, wb, ob], axis=1), nx)     # [nx, 3, nz]
                 u[ii], w[ii], ome[ii] = fields[:, 0], fields[:, 1], fields[:, 2]
             elif fused:
-                u[ii], w[ii], ome[ii] = self.engine.flowfield_vorticity(xmin, zmin, dr, nx, nz, g, xw, zw, self.v_core)
+                u[ii], w[ii], ome[ii] = self.engine.flowfield_vorticity(xmin, zmin, dr, nx, nz, g, xw, zw, self.v_core,
+                                                                        precision=ffp)
             else:
                 uf, wf = self.engine.flowfield(xmin, zmin, dr, nx, nz, g, xw, zw, self.v_core)
                 u[ii], w[ii] = uf, wf

@@ -348,6 +348,60 @@ def test_flowfield_over_a_far_wake_keeps_1e5(eng):
                 eng.set_stream(None)
 
 
+def test_flowfield_float64_mode_and_row_blocks(eng):
+    """ludvm_flowfield_rows_f64: float64 pair sums, grid coordinates and stencil -- the oracle's fields (the reference's
+    arithmetic, LUDVM.py:1206-1292) to 1e-12 of their maxima, vorticity included; any block of rows is bit for bit the
+    whole-grid call; no sources gives zeros."""
+    rng = np.random.default_rng(23)
+    ns, nx, nz = 1500, 37, 52
+    xs, zs, g = rng.uniform(-3, 0, ns), rng.uniform(-1, 1, ns), rng.standard_normal(ns) / ns
+    xmin, zmin, dr, vc = -3.2, -1.1, 0.043, 0.065
+    u, w, ome = eng.flowfield_vorticity(xmin, zmin, dr, nx, nz, g, xs, zs, vc, precision="f64")
+    assert u.dtype == np.float64 and u.shape == (nx, nz)
+    x1, z1 = xmin + np.arange(nx) * dr, zmin + np.arange(nz) * dr
+    X, Z = np.meshgrid(x1, z1, indexing="ij")
+    ur, wr = O.induced_velocity(g, xs, zs, X.ravel(), Z.ravel(), vc)
+    ur, wr = ur.reshape(nx, nz), wr.reshape(nx, nz)
+    orr = O.vorticity(ur[None], wr[None], X, Z)[0]
+    scale = max(np.abs(ur).max(), np.abs(wr).max())
+    assert np.abs(u - ur).max() <= 1e-12 * scale and np.abs(w - wr).max() <= 1e-12 * scale
+    assert np.abs(ome - orr).max() <= 1e-10 * np.abs(orr).max()
+    for first, count in ((0, 1), (0, 7), (5, 20), (36, 1), (30, 7)):
+        ub, wb, ob = eng.flowfield_rows(xmin, zmin, dr, nx, nz, first, count, g, xs, zs, vc, precision="f64")
+        assert np.array_equal(ub, u[first:first + count]) and np.array_equal(wb, w[first:first + count])
+        assert np.array_equal(ob, ome[first:first + count])
+    u0, w0, o0 = eng.flowfield_vorticity(xmin, zmin, dr, 5, 6, [], [], [], vc, precision="f64")
+    assert not u0.any() and not w0.any() and not o0.any()
+
+
+def test_fp32_flowfield_vorticity_against_the_float64_oracle_at_config5_resolution(eng):
+    """The reference differences float64 fields (LUDVM.py:1224-1292); the fp32 flow field differences sums that carry
+    ~1e-6 of max|u| of rounding, and the stencil divides by 2 dr: at BASELINE config 5's dr = 8 / 4096 that is a factor
+    256.  A 64 x 64 patch of that grid inside a 1e5-vortex synthetic wake against the oracle's float64 fields and THEIR
+    stencil: u, w to 3e-6 of max|u| (measured 1e-6), vorticity to 2e-4 of max|omega| (measured ~7e-5: the stated accuracy of
+    ome_ff in fp32; a float64 run has the reference's)."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(20260101)
+    n = 100_000
+    xs, zs, g = rng.uniform(-10, 0, n), rng.uniform(-2, 2, n), rng.standard_normal(n) / n
+    dr, nx, nz, vc = 8.0 / 4096, 64, 64, 0.065
+    xmin, zmin = -8.0 + 1800 * dr, -4.0 + 2100 * dr            # a patch of config 5's grid, inside the wake
+    u, w, ome = eng.flowfield_vorticity(xmin, zmin, dr, nx, nz, g, xs, zs, vc)
+    x1, z1 = xmin + np.arange(nx) * dr, zmin + np.arange(nz) * dr
+    X, Z = np.meshgrid(x1, z1, indexing="ij")
+    ur, wr = c_oracle.induced_velocity(g, xs, zs, X.ravel(), Z.ravel(), vc)
+    ur, wr = ur.reshape(nx, nz), wr.reshape(nx, nz)
+    orr = O.vorticity(ur[None], wr[None], X, Z)[0]
+    scale = max(np.abs(ur).max(), np.abs(wr).max())
+    ev = max(np.abs(u - ur).max(), np.abs(w - wr).max()) / scale
+    eo = np.abs(ome - orr).max() / np.abs(orr).max()
+    print(f"fp32 flow field at dr = 8/4096: velocity error {ev:.2e} of max|u|, vorticity error {eo:.2e} of max|omega|")
+    assert ev <= 3e-6 and eo <= 2e-4, (ev, eo)
+    # the float64 mode on the same patch: the oracle's vorticity to rounding
+    u64, w64, o64 = eng.flowfield_vorticity(xmin, zmin, dr, nx, nz, g, xs, zs, vc, precision="f64")
+    assert np.abs(o64 - orr).max() <= 1e-9 * np.abs(orr).max()
+
+
 def test_flowfield_row_blocks_with_halo_equal_the_full_grid(eng):
     """Multi-GPU flow field on one GPU: the row blocks of 3 owners (each with its halo rows) reproduce
     the single-launch fields bit for bit in (u, w) and in the vorticity."""
