@@ -16,7 +16,13 @@ value = ordered pair interactions (self pairs count) of all ranks / wall time, m
 
 Order of a run: CPU baseline (rank 0, N = 1 only) -> warmup -> the timed region of exactly --steps steps (barrier +
 synchronize on both sides) -> --repeats further regions of the same length, reported as `repeat_values` (box-to-box and
-run-to-run spread; they also keep the GPU busy long enough for a 5-second utilisation sampler to see the run).
+run-to-run spread; they also keep the GPU busy long enough for a 5-second utilisation sampler to see the run) -> at
+N = 1, --cfg4-steps steps of config 4's workload (N = 8e6) on the one GPU, reported as `config4_one_gpu`: the
+same-work reference point for the N = 2, 4, 8 lines (`value` stays config 3's).
+
+The collective of the N > 1 step is issued INSIDE libludvm_hip.so on its own RCCL communicator (ludvm_comm_*;
+--collectives library, the default on the nccl backend; torch.distributed only ships the 128-byte identifier and does
+the barrier / max-over-ranks of the contract) or by torch.distributed (--collectives torch; gloo rehearsals).
 
 Prints ONE JSON line on rank 0's stdout (everything else that libraries print there, e.g. RCCL's version
 banner, is routed to stderr).  Synthetic inputs follow SURVEY.md section 8(d):
@@ -101,6 +107,10 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=2048, help="targets in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work at most")
     ap.add_argument("--repeats", type=int, default=3, help="further timed regions of --steps steps after the reported one")
+    ap.add_argument("--collectives", choices=["auto", "torch", "library"], default="auto",
+                    help="N > 1: who issues the step's collective -- the library's own RCCL communicator (default on nccl) or torch.distributed")
+    ap.add_argument("--cfg4-steps", type=int, default=2,
+                    help="N = 1: steps of config 4's workload (N = 8e6, ~7 s each) timed on the one GPU after the config-3 run (0 = skip)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON.  Libraries write there too (RCCL prints a version banner when a
@@ -164,6 +174,7 @@ def main():
     # the symmetric kernel serves self-interaction launches (configs 3 and 4)
     symmetric = bool(args.symmetric) and n >= 16384
     variant = "symmetric" if symmetric else "direct"
+    coll = None
     if workload == "cfg3":
         dx, dz, dg = (torch.from_numpy(a).to(device) for a in (x, z, g))
         du, dw = torch.empty_like(dx), torch.empty_like(dx)
@@ -176,12 +187,22 @@ def main():
         desc = f"config 3: synthetic wake N={n}, one induced_velocity all-pairs call per step (targets = sources)"
         collective = None
     else:
-        wake = ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric)
+        coll = args.collectives if args.collectives != "auto" else ("library" if (backend == "nccl" and world > 1) else "torch")
+        if coll == "library":
+            # the engine's own communicator: rank 0's identifier goes round through torch (any channel would do); its
+            # sharding of resident-wake roll-ups is switched off (min_vortices), ShardedWake hands out the tile blocks itself
+            uid = [eng.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0, device=device if backend == "nccl" else None)
+            eng.comm_init(rank, world, uid[0], min_vortices=1 << 62)
+        wake = ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric, collectives=coll)
         step = wake.step
         pairs_per_step = wake.pairs_per_step
         pairs_per_launch = float(wake.n_pad) * float(wake.n_pad) / world if symmetric else float(wake.n_loc) * float(wake.n_pad)
         collective = ("one all_reduce(sum) of int64[2 N + 1] fixed-point sums per step" if symmetric
-                      else "one all_gather of fp32[2, N / G] positions per step")
+                      else "one all_gather of fp32[2, N / G] positions per step") + \
+            (" (ncclAllReduce / ncclAllGather issued inside libludvm_hip.so on its own communicator)" if coll == "library"
+             else " (torch.distributed)")
         desc = (f"config 4: synthetic wake N={n}, sharded over {world} GPU(s); per step: "
                 + ("symmetric kernel on the rank's I-tile block of the unordered pairs + ONE all-reduce of the 64-bit "
                    "fixed-point sums + replicated Euler update" if symmetric else
@@ -227,6 +248,28 @@ def main():
         u_first = du[: len(cpu_u)].cpu().numpy().astype(np.float64)
         w_first = dw[: len(cpu_u)].cpu().numpy().astype(np.float64)
     repeats = [timed_region()[0] for _ in range(max(0, args.repeats))]
+
+    # N = 1: config 4's workload (N = 8e6, what --gpus 2, 4, 8 run sharded) on this one GPU, so that "8 vs 1" compares the
+    # same work; not part of `value`
+    cfg4_rec = None
+    if world == 1 and workload == "cfg3" and args.cfg4_steps > 0 and not args.vortices:
+        n4 = 8_000_000
+        x4, z4, g4 = synthetic_wake(n4)
+        wake4 = ShardedWake(x4, z4, g4, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric)
+        torch.cuda.synchronize()
+        eng.kernel_timing(True)
+        eng.kernel_time_ms(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.cfg4_steps):
+            wake4.step()
+        torch.cuda.synchronize()
+        el4 = time.perf_counter() - t0
+        k4, _ = eng.kernel_time_ms(reset=True)
+        eng.kernel_timing(False)
+        cfg4_rec = {"workload": f"config 4 on ONE GPU: synthetic wake N={n4}, one self-advection step per step ({variant} kernel, "
+                                "no collective)", "value": wake4.pairs_per_step * args.cfg4_steps / el4, "unit": "pairs/s",
+                    "steps": args.cfg4_steps, "warmup": 0, "ms_per_step": el4 / args.cfg4_steps * 1e3, "pair_kernel_ms": k4}
+        del wake4
 
     # per-rank kernel time (the pair kernel alone, HIP events on the launch stream)
     kt = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
@@ -280,6 +323,8 @@ def main():
                                    "in this run)") if traffic else "no PMC pass on record for this kernel / size",
             },
         }
+        if cfg4_rec is not None:
+            out["config4_one_gpu"] = cfg4_rec
         if cpu_rec is not None:
             if u_first is not None:
                 scale = max(np.abs(cpu_u).max(), np.abs(cpu_w).max())
@@ -289,6 +334,9 @@ def main():
             out["cpu_baseline"] = cpu_rec
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if coll == "library":
+        torch.cuda.synchronize()
+        eng.comm_destroy()
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LUDVM_ABI_VERSION 2
+#define LUDVM_ABI_VERSION 3
 
 enum {
   LUDVM_OK = 0,
@@ -41,7 +41,8 @@ enum {
   LUDVM_E_HIP = 2,      /* a HIP runtime call failed; message has the HIP error string */
   LUDVM_E_NOMEM = 3,    /* device or host allocation failed */
   LUDVM_E_NODEVICE = 4, /* no usable gfx950 device */
-  LUDVM_E_STATE = 5     /* call not valid in the current state (e.g. wake not reserved) */
+  LUDVM_E_STATE = 5,    /* call not valid in the current state (e.g. wake not reserved) */
+  LUDVM_E_COMM = 6      /* RCCL could not be opened, or one of its calls failed; message has its error string */
 };
 
 /* Arithmetic the pair sum is evaluated in. */
@@ -106,6 +107,44 @@ int ludvm_set_sym_tuning(ludvm_ctx* ctx, int vortices_per_lane, int rotation_spl
 typedef int (*ludvm_allreduce_fn)(void* user, void* d_buf, size_t count, void* hip_stream);
 int ludvm_set_shard(ludvm_ctx* ctx, int rank, int world, size_t min_vortices, ludvm_allreduce_fn allreduce, void* user,
                     void* d_acc, size_t acc_bytes);
+
+/* ---- the library's own communicator: one simulation, or one synthetic wake, on the GPUs of a node ----------------
+ *
+ * One process per GPU, each with its own context; the collectives run on RCCL over xGMI INSIDE the library, on the
+ * context's stream -- a caller needs no communication library of its own, only a way to hand 128 bytes from rank 0 to
+ * the other processes (a file, an environment variable, MPI, torch.distributed ...).  librccl.so is opened when the
+ * first of these calls is made (environment LUDVM_RCCL_LIB names the file, default librccl.so.1); a process that never
+ * calls them does not need RCCL.
+ *
+ *   ludvm_comm_unique_id   rank 0: the identifier of a new communicator (LUDVM_COMM_ID_BYTES bytes).
+ *   ludvm_comm_init        every rank, with the same identifier: joins the communicator (returns when all `world` ranks
+ *                          have) and shards the context's symmetric roll-ups over it exactly as ludvm_set_shard does
+ *                          (LUDVM.time_loop's roll-up, LUDVM.py:1095-1127: every rank holds the whole wake and runs the
+ *                          whole loop, but evaluates only tile block `rank` of `world` of the unordered pairs) -- with
+ *                          the ONE collective per time step, an in-place ncclAllReduce (int64 sum) of the fixed-point
+ *                          accumulators and their NaN counter, issued by the library between the symmetric kernel and the
+ *                          Euler finisher.  Integer sums commute: every rank reads the bits one GPU would have produced.
+ *                          Roll-ups of fewer than min_vortices vortices are done whole by every rank, without a collective.
+ *   ludvm_comm_destroy     leaves the communicator (collective in RCCL's sense: every rank calls it) and unshards the context.
+ *   ludvm_comm_info        rank and world of the context's communicator (world = 0: none).
+ *   ludvm_comm_allreduce_i64_dev / ludvm_comm_allgather_dev
+ *                          the two collectives of the synthetic-wake step (BASELINE config 4, ludvm_amd/sharded.py) on
+ *                          caller-owned device buffers, asynchronous on the context's stream: in-place int64 sum (the
+ *                          symmetric variant's accumulators) and an all-gather of bytes_per_rank bytes per rank into
+ *                          d_recv[world * bytes_per_rank] (the direct variant's positions -- the north star's "single RCCL
+ *                          all-gather of sources per step").
+ *   ludvm_comm_allgather_host
+ *                          the same all-gather for host buffers (synchronous): how the ranks of one simulation exchange
+ *                          their blocks of a flow field (LUDVM.py:1186-1298) or of an induced_velocity call (:549-570).
+ */
+#define LUDVM_COMM_ID_BYTES 128
+int ludvm_comm_unique_id(void* id_out, size_t id_bytes);
+int ludvm_comm_init(ludvm_ctx* ctx, int rank, int world, const void* id, size_t id_bytes, size_t min_vortices);
+int ludvm_comm_destroy(ludvm_ctx* ctx);
+int ludvm_comm_info(ludvm_ctx* ctx, int* rank, int* world);
+int ludvm_comm_allreduce_i64_dev(ludvm_ctx* ctx, long long* d_buf, size_t count);
+int ludvm_comm_allgather_dev(ludvm_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+int ludvm_comm_allgather_host(ludvm_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank);
 
 /* ---- stateless pair sum: backs LUDVM.induced_velocity (LUDVM.py:549-570) ------------------ */
 

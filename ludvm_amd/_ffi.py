@@ -12,10 +12,11 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libludvm_hip.so")
 
-OK, E_ARG, E_HIP, E_NOMEM, E_NODEVICE, E_STATE = range(6)
+OK, E_ARG, E_HIP, E_NOMEM, E_NODEVICE, E_STATE, E_COMM = range(7)
 PREC_F32, PREC_F32X2, PREC_F64 = 0, 1, 2
 SYM_TILE = 512
-ABI_VERSION = 2
+ABI_VERSION = 3
+COMM_ID_BYTES = 128
 SYM_SCALE_BYTES = 32
 
 _pd, _pf = POINTER(c_double), POINTER(c_float)
@@ -34,6 +35,13 @@ SIGNATURES = {
     "ludvm_set_symmetric": [c_void_p, c_int],
     "ludvm_set_shard": [c_void_p, c_int, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t],
     "ludvm_set_sym_tuning": [c_void_p, c_int, c_int],
+    "ludvm_comm_unique_id": [c_void_p, c_size_t],
+    "ludvm_comm_init": [c_void_p, c_int, c_int, c_void_p, c_size_t, c_size_t],
+    "ludvm_comm_destroy": [c_void_p],
+    "ludvm_comm_info": [c_void_p, POINTER(c_int), POINTER(c_int)],
+    "ludvm_comm_allreduce_i64_dev": [c_void_p, c_void_p, c_size_t],
+    "ludvm_comm_allgather_dev": [c_void_p, c_void_p, c_void_p, c_size_t],
+    "ludvm_comm_allgather_host": [c_void_p, c_void_p, c_void_p, c_size_t],
     "ludvm_induce_f64": [c_void_p, _pd, _pd, _pd, c_size_t, _pd, _pd, c_size_t, c_double, c_int, _pd, _pd],
     "ludvm_induce_f32": [c_void_p, _pf, _pf, _pf, c_size_t, _pf, _pf, c_size_t, c_float, _pf, _pf],
     "ludvm_induce_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,
@@ -114,6 +122,25 @@ def _pin_hip_runtime():
             ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         except OSError:
             pass                                # unusable torch install: fall back to the system runtime
+
+
+def prefer_matching_rccl():
+    """The library opens librccl itself when a communicator is first created (ludvm_comm_*; LUDVM_RCCL_LIB names the file,
+    default librccl.so.1 from the loader's path).  When the process runs on the HIP runtime a PyTorch-ROCm install ships
+    (see _pin_hip_runtime) the RCCL built against THAT runtime is the one to open -- it sits next to it."""
+    if os.environ.get("LUDVM_RCCL_LIB"):
+        return os.environ["LUDVM_RCCL_LIB"]
+    try:
+        with open("/proc/self/maps") as f:
+            rts = {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:
+        rts = set()
+    for rt in rts:
+        cand = os.path.join(os.path.dirname(rt), "librccl.so")
+        if os.path.exists(cand):
+            os.environ["LUDVM_RCCL_LIB"] = cand
+            return cand
+    return "librccl.so.1"
 
 
 def load(path=None):

@@ -1,0 +1,127 @@
+"""One LUDVM simulation on the GPUs of a node WITHOUT torch.distributed: the collectives run inside libludvm_hip.so on its
+own RCCL communicator (ludvm_comm_*).  One process per GPU, started by any launcher that tells each process
+its rank (RANK / WORLD_SIZE / LOCAL_RANK as torchrun sets them, or OMPI_COMM_WORLD_*, or SLURM_PROCID / SLURM_NTASKS /
+SLURM_LOCALID); every process constructs
+
+    LUDVM(..., device=local_rank, distributed="rccl")            # or distributed=LibraryGroup(engine, ...)
+
+and calls the same methods.  What is sharded and exchanged is what ludvm_amd/distributed.py describes (flow-field rows,
+induced_velocity targets, the roll-up's unordered pairs with ONE in-library int64 all-reduce per time step); only the
+plumbing differs: the 128-byte communicator identifier travels from rank 0 to the others through a file every rank can
+reach (`rendezvous`), the blocks of results through ludvm_comm_allgather_host.
+"""
+import os
+import time
+
+import numpy as np
+
+
+def _env_int(*names, default=None):
+    for n in names:
+        v = os.environ.get(n)
+        if v not in (None, ""):
+            return int(v)
+    return default
+
+
+def launcher_rank():
+    """(rank, world, local_rank) as the process launcher announced them; (0, 1, 0) for a lone process."""
+    rank = _env_int("RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID", default=0)
+    world = _env_int("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS", default=1)
+    local = _env_int("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", default=rank)
+    return rank, world, local
+
+
+def default_rendezvous():
+    """A file name all processes of one launch agree on and later launches do not reuse: the launcher's job identifier
+    where there is one, else the parent process (the launcher itself) and the rendezvous port."""
+    if os.environ.get("LUDVM_RENDEZVOUS"):
+        return os.environ["LUDVM_RENDEZVOUS"]
+    job = (os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("SLURM_JOB_ID") or os.environ.get("OMPI_MCA_ess_base_jobid")
+           or "")
+    tag = f"{os.getuid()}_{job}_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ludvm_rdv_{tag}")
+
+
+def exchange_id(rank, make_id, path, timeout=600.0):
+    """Rank 0 creates the identifier (make_id() -> bytes) and publishes it atomically at `path`; the others wait for it."""
+    if rank == 0:
+        uid = make_id()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.monotonic()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) >= 128:
+                return uid[:128]
+        except OSError:
+            pass
+        if time.monotonic() - t0 > timeout:
+            raise TimeoutError(f"no communicator identifier at {path} after {timeout:.0f} s (is rank 0 running?)")
+        time.sleep(0.01)
+
+
+class LibraryGroup:
+    """The ranks that share one simulation, joined by the engine's own RCCL communicator.  Same surface as
+    ludvm_amd.distributed.ShardGroup (what LUDVM uses of it), no torch."""
+
+    backend = "rccl (in-library)"
+    _created = 0          # groups this process has created through a default rendezvous: every rank creates them in the same
+                          # order, so the count names the file (a rank must not pick up the identifier of the previous group)
+
+    def __init__(self, engine, rank=None, world=None, rendezvous=None, unique_id=None, min_targets=65536, min_wake=131072,
+                 timeout=600.0):
+        r, w, _ = launcher_rank()
+        self.engine = engine
+        self.rank = r if rank is None else int(rank)
+        self.world = w if world is None else int(world)
+        self.min_targets, self.min_wake = int(min_targets), int(min_wake)
+        self._path = None
+        if unique_id is None:
+            if rendezvous is None:
+                rendezvous = f"{default_rendezvous()}.{LibraryGroup._created}"
+                LibraryGroup._created += 1
+            self._path = rendezvous
+            unique_id = exchange_id(self.rank, engine.comm_unique_id, self._path, timeout)
+        engine.comm_init(self.rank, self.world, unique_id, self.min_wake)      # returns when every rank has joined
+        if self._path and self.rank == 0:
+            try:
+                os.remove(self._path)           # everyone has read it
+            except OSError:
+                pass
+
+    def close(self):
+        if self.engine is not None:
+            self.engine.comm_destroy()
+            self.engine = None
+
+    # ---- blocks (as ShardGroup) ------------------------------------------------------------------------------------
+    def block(self, n):
+        per = (n + self.world - 1) // self.world
+        lo = min(n, self.rank * per)
+        return lo, min(n, lo + per), per
+
+    def gather_blocks(self, local, n):
+        lo, hi, per = self.block(n)
+        local = np.ascontiguousarray(local)
+        send = np.zeros((per,) + local.shape[1:], local.dtype)
+        send[: hi - lo] = local
+        allb = self.engine.comm_allgather(send)                       # [world, per, ...]
+        return allb.reshape((self.world * per,) + local.shape[1:])[:n]
+
+    def barrier(self):
+        self.engine.comm_allgather(np.zeros(1, np.int8))
+
+    # ---- sharded roll-up: the communicator already shards the engine ------------------------------------------------------
+    def attach(self, engine, capacity):
+        if engine is not self.engine:
+            raise ValueError("LibraryGroup is bound to the engine it was created with")
+        return self.world > 1
+
+    def detach(self, engine):
+        pass

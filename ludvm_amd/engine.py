@@ -131,6 +131,50 @@ class Engine:
             self._check(self._lib.ludvm_set_shard(self._ctx, 0, 1, 0, None, None, None, 0))
             self._hook_c = None
 
+    # -- the library's own RCCL communicator -------------------------------------------------------
+    def comm_unique_id(self):
+        """128 bytes that identify a new communicator (rank 0 creates them and hands them to the other processes)."""
+        _ffi.prefer_matching_rccl()
+        buf = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
+        rc = self._lib.ludvm_comm_unique_id(buf, _ffi.COMM_ID_BYTES)
+        if rc != _ffi.OK:
+            raise LudvmHipError(rc, "ludvm_comm_unique_id failed (is librccl loadable? LUDVM_RCCL_LIB names it)")
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id, min_vortices=0):
+        """Join the communicator `unique_id` as rank `rank` of `world` (one process per GPU; returns when all have joined)
+        and shard this engine's symmetric roll-ups over it: one in-library ncclAllReduce per time step."""
+        _ffi.prefer_matching_rccl()
+        uid = bytes(unique_id)
+        if len(uid) != _ffi.COMM_ID_BYTES:
+            raise ValueError("comm_init: the identifier is 128 bytes (Engine.comm_unique_id)")
+        self._check(self._lib.ludvm_comm_init(self._ctx, int(rank), int(world), uid, len(uid), int(min_vortices)))
+
+    def comm_destroy(self):
+        self._check(self._lib.ludvm_comm_destroy(self._ctx))
+
+    def comm_info(self):
+        """(rank, world) of the engine's communicator; world = 0 when it has none."""
+        r, w = c_int(), c_int()
+        self._check(self._lib.ludvm_comm_info(self._ctx, byref(r), byref(w)))
+        return r.value, w.value
+
+    def comm_allreduce_i64_dev(self, d_buf, count):
+        self._check(self._lib.ludvm_comm_allreduce_i64_dev(self._ctx, d_buf, int(count)))
+
+    def comm_allgather_dev(self, d_send, d_recv, bytes_per_rank):
+        self._check(self._lib.ludvm_comm_allgather_dev(self._ctx, d_send, d_recv, int(bytes_per_rank)))
+
+    def comm_allgather(self, local):
+        """All ranks' copies of the contiguous array `local` (same shape and dtype everywhere) stacked along a new first
+        axis: [world, *local.shape] (host arrays; synchronous)."""
+        local = np.ascontiguousarray(local)
+        _, world = self.comm_info()
+        out = np.empty((world,) + local.shape, local.dtype)
+        self._check(self._lib.ludvm_comm_allgather_host(self._ctx, local.ctypes.data_as(c_void_p), out.ctypes.data_as(c_void_p),
+                                                        local.nbytes))
+        return out
+
     # -- stateless pair sum ----------------------------------------------------------------------
     def induce(self, circulation, xw, zw, xp, zp, v_core, precision="f32"):
         """(u, w) float64 arrays; host arrays in, host arrays out (LUDVM.py:549-570)."""

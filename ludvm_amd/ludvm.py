@@ -98,11 +98,13 @@ class LUDVM:
       march      True (default): stretches of time steps whose history row is not recorded run as a
                  device-resident march (Gamma solve on the GPU, no host round trip per step);
                  False: one device round trip per step throughout
-      distributed  None (default): one GPU.  True or a torch.distributed process group: the simulation is shared by
-                 the ranks of that group, one process per GPU (ludvm_amd/distributed.py) -- every rank constructs the same
-                 object and calls the same methods; flowfield shards the grid rows, induced_velocity the targets,
-                 time_loop the roll-up's unordered pairs (one integer all-reduce per step over RCCL), and every rank
-                 ends up with the reference's full result arrays
+      distributed  None (default): one GPU.  'rccl': the simulation is shared by the processes of one launch (one per GPU;
+                 rank and world from the launcher's environment), connected by the library's own RCCL communicator --
+                 no torch.distributed (ludvm_amd/comm.py).  True or a torch.distributed process group: the same through
+                 torch's collectives (ludvm_amd/distributed.py).  Either way every rank constructs the same object and
+                 calls the same methods; flowfield shards the grid rows, induced_velocity the targets, time_loop the
+                 roll-up's unordered pairs (one integer all-reduce per step over RCCL), and every rank ends up with the
+                 reference's full result arrays
     """
 
     def __init__(self, t0=0, tf=12, dt=1.5e-2, chord=1, rho=1.225, Uinf=1,
@@ -169,10 +171,15 @@ class LUDVM:
             raise ValueError("checkpoint_every needs a checkpoint_path")
         self.engine = engine if engine is not None else Engine(device)  # raises without the HIP library / GPU
         self._shard = None
-        if distributed is not None and distributed is not False:
-            from .distributed import ShardGroup
-            self._shard = distributed if isinstance(distributed, ShardGroup) else \
-                ShardGroup(None if distributed is True else distributed)
+        if isinstance(distributed, str) and distributed == 'rccl':
+            from .comm import LibraryGroup          # the library's own communicator: no torch.distributed
+            self._shard = LibraryGroup(self.engine)
+        elif distributed is not None and distributed is not False:
+            if hasattr(distributed, 'gather_blocks'):          # a ShardGroup or LibraryGroup
+                self._shard = distributed
+            else:
+                from .distributed import ShardGroup
+                self._shard = ShardGroup(None if distributed is True else distributed)
 
         self.start_time = timeit.default_timer()
         if Naca is not None:

@@ -144,13 +144,25 @@ class HipFlowfieldKernel:
 
 
 class ShardedWake:
-    def __init__(self, x, z, gamma, v_core, dt, kernel, device, group=None, symmetric=True, force_collectives=False):
+    def __init__(self, x, z, gamma, v_core, dt, kernel, device, group=None, symmetric=True, force_collectives=False,
+                 collectives="torch"):
         # force_collectives: issue the collectives even in a one-rank group (they are then identities); lets a
         # one-GPU box run the real RCCL calls with the layouts used at G > 1
+        # collectives: "torch" -- torch.distributed on `group`; "library" -- the engine's own RCCL communicator
+        # (ludvm_comm_init was called on kernel.engine): ncclAllReduce / ncclAllGather issued inside libludvm_hip.so on the
+        # stream the pair kernel runs on, rank and world taken from that communicator
         self.force = bool(force_collectives)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.library = collectives == "library"
+        if collectives not in ("torch", "library"):
+            raise ValueError("collectives must be 'torch' or 'library'")
+        if self.library:
+            self.rank, self.world = kernel.engine.comm_info()
+            if self.world < 1:
+                raise RuntimeError("collectives='library' needs Engine.comm_init first")
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.kernel, self.device = kernel, device
         self.v_core, self.dt = float(v_core), float(dt)
         self.symmetric = bool(symmetric)
@@ -193,7 +205,10 @@ class ShardedWake:
             self.kernel.sym_accumulate(self.xs, self.zs, self.gs, self.rank * tiles, tiles, self.v_core, self._scale,
                                        self._acc)
             if self.world > 1 or self.force:
-                dist.all_reduce(self._acc, op=dist.ReduceOp.SUM, group=self.group)
+                if self.library:
+                    self.kernel.engine.comm_allreduce_i64_dev(self._acc.data_ptr(), self._acc.numel())
+                else:
+                    dist.all_reduce(self._acc, op=dist.ReduceOp.SUM, group=self.group)
             nxt = self._xz if self.xs.data_ptr() != self._xz.data_ptr() else self._xz2()
             self.kernel.advect_from_sums(self._acc, self._scale, self.xs, self.zs, 0, self.n_pad, self.dt, nxt[0], nxt[1])
             self.xs, self.zs = nxt[0], nxt[1]
@@ -201,7 +216,10 @@ class ShardedWake:
         send = self._send
         self.kernel.advect(self.xs, self.zs, self.gs, self.lo, self.n_loc, self.v_core, self.dt, send[0], send[1])
         if self.world > 1 or self.force:
-            dist.all_gather_into_tensor(self._recv.view(-1), send.view(-1), group=self.group)
+            if self.library:
+                self.kernel.engine.comm_allgather_dev(send.data_ptr(), self._recv.data_ptr(), send.numel() * 4)
+            else:
+                dist.all_gather_into_tensor(self._recv.view(-1), send.view(-1), group=self.group)
             # [G, 2, n_loc] -> [2, G*n_loc].  In-place reuse of _xz is safe: in stream order the pair
             # kernel that read it has finished before this copy starts.
             self._xz.view(2, self.world, self.n_loc).copy_(self._recv.permute(1, 0, 2))

@@ -67,6 +67,19 @@ def test_sharded_wake_collectives_on_the_real_rccl_backend():
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
 
 
+def test_library_communicator_one_rank_through_the_c_abi():
+    """ludvm_comm_* on the real RCCL with ONE rank (tools/comm_one_rank.py; LUDVM_COMM_FORCE=1 makes the one-rank group issue
+    its collectives): the class-level sharded time loop with the in-library ncclAllReduce per step, the host all-gather of
+    result blocks, and config 4's step with ncclAllReduce / ncclAllGather on device buffers -- all bit for bit what the
+    same calls give without a communicator.  No torch.distributed in that process."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "comm_one_rank.py")], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert p.returncode == 0 and "COMM_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
 def _launch(nproc, extra_env, *args):
     env = dict(os.environ, **extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -141,12 +154,25 @@ def test_class_level_sharding_on_rccl_with_two_gpus():
     assert p.returncode == 0 and "DIST_OK nccl 2" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
 
 
+def test_class_level_sharding_on_the_library_communicator_with_two_gpus():
+    """... and with the library's own communicator instead of torch.distributed (LUDVM_DIST_COLLECTIVES=library): the
+    launcher only starts the two processes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL ranks cannot share a card)")
+    p = _torchrun(2, "dist_class_check.py", {"LUDVM_DIST_COLLECTIVES": "library"}, 29563)
+    assert p.returncode == 0 and "DIST_OK library 2" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+
+
 def test_bench_two_ranks_on_rccl_with_two_gpus():
-    """bench.py exactly as the driver launches it for N = 2, on RCCL: skips below two GPUs."""
+    """bench.py exactly as the driver launches it for N = 2, on RCCL: skips below two GPUs.  Default collectives (the
+    library's own communicator) and torch.distributed's."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL ranks cannot share a card)")
     for sym in ("1", "0"):
-        d = _launch(2, {}, "--vortices", "200000", "--steps", "2", "--warmup", "1", "--symmetric", sym)
-        assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 2
-        assert len(d["config"]["pair_kernel_ms_per_rank"]) == 2 and d["value"] > 1e11
+        for coll in ("auto", "torch"):
+            d = _launch(2, {}, "--vortices", "200000", "--steps", "2", "--warmup", "1", "--symmetric", sym, "--collectives", coll)
+            assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 2
+            assert len(d["config"]["pair_kernel_ms_per_rank"]) == 2 and d["value"] > 1e11
+            assert ("libludvm_hip" in d["config"]["collective"]) == (coll == "auto")

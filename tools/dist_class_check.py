@@ -6,6 +6,10 @@ several ranks sharing one card:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29551 \
         tools/dist_class_check.py
 
+LUDVM_DIST_COLLECTIVES=library: the same check with the library's own RCCL communicator (ludvm_amd/comm.py; the
+128-byte identifier travels through a file) -- torch.distributed is then not initialised at all, the launcher only
+starts the processes and tells them their rank.
+
 Every rank builds LUDVM(..., distributed=True) with the symmetric threshold and the sharding threshold lowered so that
 the README-size case runs sharded roll-ups (tile blocks + one integer all-reduce per step), and compares with a
 single-GPU run of its own: loads, circulations and the final wake must agree BIT FOR BIT (integer sums commute), the
@@ -23,15 +27,22 @@ from ludvm_amd import LUDVM, Engine  # noqa: E402
 from ludvm_amd.distributed import ShardGroup  # noqa: E402
 
 backend = os.environ.get("LUDVM_DIST_BACKEND", "nccl")
+library = os.environ.get("LUDVM_DIST_COLLECTIVES", "torch") == "library"
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
-if backend == "nccl":
+if library:
+    from ludvm_amd.comm import LibraryGroup  # noqa: E402
+    backend = "library"
+
+    def ShardGroup(min_targets, min_wake):        # noqa: N802  (same call below; bound to the engine of the moment)
+        return LibraryGroup(eng, min_targets=min_targets, min_wake=min_wake)
+elif backend == "nccl":
     dist.init_process_group(backend="nccl", device_id=dev)
 else:
     dist.init_process_group(backend=backend)
-assert dist.get_world_size() == world
+assert library or dist.get_world_size() == world
 kw = dict(t0=0, tf=8, dt=5e-2, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2, Naca="0012")
 ok = True
 for march in (True, False):
@@ -39,8 +50,13 @@ for march in (True, False):
         eng = Engine(local)
         eng.set_symmetric(8)                       # symmetric (and overlapped) steps from 8 vortices on
         sg = ShardGroup(min_targets=1000, min_wake=64)
+        # (an engine that owns a communicator stays sharded: the single-GPU reference then runs on an engine of its own)
+        eng_one = eng
+        if library:
+            eng_one = Engine(local)
+            eng_one.set_symmetric(8)
         sh = LUDVM(**kw, verbose=False, engine=eng, precision=prec, history="sparse", march=march, distributed=sg)
-        one = LUDVM(**kw, verbose=False, engine=eng, precision=prec, history="sparse", march=march)
+        one = LUDVM(**kw, verbose=False, engine=eng_one, precision=prec, history="sparse", march=march)
         same = all(np.array_equal(getattr(sh, n), getattr(one, n)) for n in ("Cl", "Cd", "Cm", "LESP", "LEV_shed")) and \
             np.array_equal(sh.path["TEV"][sh.nt - 1], one.path["TEV"][one.nt - 1]) and \
             np.array_equal(sh.circulation["TEV"], one.circulation["TEV"])
@@ -48,10 +64,10 @@ for march in (True, False):
         ok &= bool(same)
         if march and prec == "f32":
             args = dict(xmin=-6.0, xmax=1.0, zmin=-1.5, zmax=1.5, dr=0.05, tsteps=[0, 80, 159])
-            sg2 = ShardGroup(min_targets=1000, min_wake=64)
+            sg2 = sg if library else ShardGroup(min_targets=1000, min_wake=64)     # (one communicator per engine)
             shf = LUDVM(**kw, verbose=False, engine=eng, precision=prec, history="sparse", distributed=sg2,
                         snapshot_steps=LUDVM.flowfield_rows_needed(args["tsteps"]))
-            onef = LUDVM(**kw, verbose=False, engine=eng, precision=prec, history="sparse",
+            onef = LUDVM(**kw, verbose=False, engine=eng_one, precision=prec, history="sparse",
                          snapshot_steps=LUDVM.flowfield_rows_needed(args["tsteps"]))
             shf.flowfield(**args)
             onef.flowfield(**args)
@@ -65,11 +81,19 @@ for march in (True, False):
             iv = max(np.abs(u - ur).max(), np.abs(w - wr).max()) <= 1e-5 * max(np.abs(ur).max(), np.abs(wr).max())
             print(f"rank {rank}: sharded induced_velocity within fp32 rounding: {iv}", flush=True)
             ok &= bool(ff) and bool(iv)
+        if library:
+            allok = bool(eng.comm_allgather(np.array([1 if ok else 0], np.int8)).min())      # every rank's verdict so far
+            ok &= allok
+            sg.close()
+            eng_one.close()
         eng.close()
-t = torch.tensor([1 if ok else 0], device=dev if backend == "nccl" else "cpu")
-dist.all_reduce(t, op=dist.ReduceOp.MIN)
-dist.barrier()
-dist.destroy_process_group()
+if library:
+    t = torch.tensor([1 if ok else 0])
+else:
+    t = torch.tensor([1 if ok else 0], device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    dist.destroy_process_group()
 if int(t.item()) != 1:
     sys.exit("sharded run differs from the single-GPU run")
 if rank == 0:
