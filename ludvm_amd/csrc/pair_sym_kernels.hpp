@@ -134,6 +134,22 @@ __device__ __forceinline__ float dpp_rol1(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x134, 0xf, 0xf, false));
 }
 __device__ __forceinline__ f32x2 dpp_rol1(f32x2 v) { return (f32x2){dpp_rol1(v.x), dpp_rol1(v.y)}; }
+// The same move through the LDS crossbar (ds_bpermute_b32: no LDS memory involved) instead of the vector ALU: src4 = 4 *
+// ((lane + 1) % 64).  A DPP move costs 4 VALU issue cycles on gfx950 and the rotation loop is VALU-bound (16 of them per
+// rotation step of a 512-vortex tile = 3 % of its issue slots), so taking them off the VALU looked like 3 % -- measured
+// [MI355X] it LOSES 3-4 % (N = 1e6: 122.8 ms against 118-120 ms with DPP on the same box, profiles/
+// r03_rotation_through_lds_negative_result.txt): the accumulators come back after an LDS round trip that the next
+// half-step's first J-side FMAs wait for.  Kept as a build switch (-DLUDVM_SYM_ROTATE_LDS=1), off.
+#ifndef LUDVM_SYM_ROTATE_LDS
+#define LUDVM_SYM_ROTATE_LDS 0
+#endif
+__device__ __forceinline__ float lds_rol1(float v, int src4) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src4, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ f32x2 rol1(f32x2 v, int src4) {
+  if (LUDVM_SYM_ROTATE_LDS) return (f32x2){lds_rol1(v.x, src4), lds_rol1(v.y, src4)};
+  return dpp_rol1(v);
+}
 
 // Packed targets.  A v_pk_* instruction pairs two SOURCES against one target, so the target operand is the same number
 // in both halves.  Instead of keeping every target twice ({x, x}: what hipcc does with a splat, re-made with v_mov
@@ -248,6 +264,9 @@ pair_sym_f32(SymArgs a) {
   // RED: between two tile pairs a wave's slab also carries its 2 T x 64 partial sums to the reducing waves (it is dead
   // then; 2 T <= kComp T), component c of wave w at slab[w][0][c * 64 + lane]
   static_assert(2 * T * 64 <= kComp * 64 * T, "partial sums fit the slab");
+  // local origins: this wave's own T offsets per lane (x, z), written once: every pass over a partner tile re-refers the
+  // targets from them (4 KB per wave at T = 8; the hi+lo kernels do not use local origins)
+  __shared__ __attribute__((aligned(16))) float ioff[HILO ? 1 : kWaves][HILO ? 1 : 2][HILO ? 4 : 64 * T];
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: tile indices stay scalar
@@ -318,44 +337,52 @@ pair_sym_f32(SymArgs a) {
       xpl[h] = (f32x2){xl0[2 * h], xl0[2 * h + 1]}; zpl[h] = (f32x2){zl0[2 * h], zl0[2 * h + 1]};
       xq[0][h] = xp[h]; xq[1][h] = xp[h]; zq[0][h] = zp[h]; zq[1][h] = zp[h];
     }
+    if constexpr (!HILO) { slab_store<T>(ioff[wv][0], lane * 4, x0); slab_store<T>(ioff[wv][1], lane * 4, z0); }
   }
   const f32x2 vc4 = {a.vc4, a.vc4};
   const float fxs = a.scale->scale;
-  // local origins: the origins of this lane's own classes (block I W / 256 + q, the lane's parity)
+  // Local origins.  Origin records are wave-uniform data (the tile indices are scalars): they are fetched as scalars --
+  // for the own tile once, for a partner tile together with its vortices -- and a lane picks the record of its index
+  // parity when the targets are re-referred, so no global load sits between the passes.
   const bool local = !HILO && a.cx != nullptr;
-  const int pl = lane & 1;
+  const bool pl = (lane & 1) != 0;
+  // the two records (even / odd class) of origin block b, or zeros for a block past the last vortex (no record; its
+  // slots are padding, any finite number serves)
+  struct Org { float x0, x1, z0, z1; };      // (x, z) of the even class, of the odd class
+  auto scalar = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  auto origin_records = [&](unsigned b) -> Org {
+    const bool has = local && (b << kOriginShift) < n;
+    const unsigned s0 = has ? 2 * b : 0;
+    Org o{0.0f, 0.0f, 0.0f, 0.0f};
+    if (has) { o.x0 = scalar(a.cx[s0]); o.x1 = scalar(a.cx[s0 + 1]); o.z0 = scalar(a.cz[s0]); o.z1 = scalar(a.cz[s0 + 1]); }
+    return o;
+  };
   const unsigned blk_i = (I * W) >> kOriginShift;
+  Org oi[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) oi[q] = origin_records(blk_i + q);
+  // this lane's own origins (its index parity), per origin block of the tile
   float oix[NS], oiz[NS];
 #pragma unroll
-  for (int q = 0; q < NS; ++q) {
-    oix[q] = 0.0f; oiz[q] = 0.0f;
-    // (a block past the last vortex has no origin record: its slots are padding, any finite number serves)
-    if (local && active && ((blk_i + q) << kOriginShift) < n) { oix[q] = a.cx[2 * (blk_i + q) + pl]; oiz[q] = a.cz[2 * (blk_i + q) + pl]; }
-  }
-  // refer this lane's targets to the two origins of block q of tile Jt: [0] the class of the lane's own index parity,
-  // [1] the other.  One rounding of (origin_I - origin_J) + offset per target and class pair: neighbouring classes keep
-  // their relative precision, far ones do not need it.  (Offsets re-read rather than kept: 2 T loads per pass.)
-  auto refer_targets = [&](unsigned Jt, int q) {
-    // (the offsets are loaded anew for every pass: without this barrier the compiler keeps the 2 T values of one pass in
-    // registers for the next, through the whole rotation loop, and the 512-vortex tile no longer fits three waves per SIMD)
-    asm volatile("" ::: "memory");
-    const unsigned jb = ((Jt * W) >> kOriginShift) + q;
-    const bool has = (jb << kOriginShift) < n;
-    float ojx[2], ojz[2];
+  for (int q = 0; q < NS; ++q) { oix[q] = pl ? oi[q].x1 : oi[q].x0; oiz[q] = pl ? oi[q].z1 : oi[q].z0; }
+  // refer this lane's targets to the two origins (ojx / ojz: even, odd class) of one origin block of the partner tile:
+  // xq / zq[0] to the class of the lane's own index parity, [1] to the other.  One rounding of (origin_I - origin_J) +
+  // offset per target and class pair: neighbouring classes keep their relative precision, far ones do not need it.
+  auto refer_targets = [&](const Org oj) {
+    f32x2 xo[H], zo[H];
+    slab_load<T>(ioff[HILO ? 0 : wv][0], lane * 4, xo);
+    slab_load<T>(ioff[HILO ? 0 : wv][HILO ? 0 : 1], lane * 4, zo);
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-      ojx[rr] = has ? a.cx[2 * jb + (pl ^ rr)] : 0.0f;
-      ojz[rr] = has ? a.cz[2 * jb + (pl ^ rr)] : 0.0f;
-    }
+      // the partner class met at relative parity rr has index parity pl ^ rr
+      const bool odd = pl != (rr != 0);
+      const float jx = odd ? oj.x1 : oj.x0, jz = odd ? oj.z1 : oj.z0;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const unsigned i = I * W + lane + 64u * t;
-      const float xi = load_or(a.x, i, n, kPadPosF), zi = load_or(a.z, i, n, kPadPosF);
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const float xx = xi + (oix[t / 4] - ojx[rr]), zz = zi + (oiz[t / 4] - ojz[rr]);
-        if (t & 1) { xq[rr][t / 2].y = xx; zq[rr][t / 2].y = zz; }
-        else { xq[rr][t / 2].x = xx; zq[rr][t / 2].x = zz; }
+      for (int h = 0; h < H; ++h) {
+        // (targets 2 h and 2 h + 1 lie in the same origin block, h / 2)
+        const float ddx = oix[h / 2] - jx, ddz = oiz[h / 2] - jz;
+        xq[rr][h] = xo[h] + (f32x2){ddx, ddx};
+        zq[rr][h] = zo[h] + (f32x2){ddz, ddz};
       }
     }
   };
@@ -366,6 +393,7 @@ pair_sym_f32(SymArgs a) {
     out[1] = (f32x2){V.z, V.w};
   };
   float chk = 0.0f;   // sum of everything this lane hands to the accumulators: not finite <=> some partial is not
+  const int rot4 = ((lane + 1) & 63) * 4;   // lane l takes over from lane l + 1
 
   // ---- tile pairs: each unordered pair once, both sides accumulated ------------------------------------------------
   // Round -1 (items of d-chunk 0 only) is the diagonal tile, J = I, which holds the self pairs: the same code, but over
@@ -396,6 +424,9 @@ pair_sym_f32(SymArgs a) {
         slab_store<T>(lx, lane * 4, x); slab_store<T>(lz, lane * 4, z); slab_store<T>(lg, lane * 4, g);
         if (HILO) { slab_store<T>(lxl, lane * 4, xl); slab_store<T>(lzl, lane * 4, zl); }
       }
+      Org oj[NS];      // (scalars: fetched here, with the tile, for all passes)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) oj[q] = origin_records(((J * W) >> kOriginShift) + q);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -406,7 +437,7 @@ pair_sym_f32(SymArgs a) {
       // per SIMD the LDS latency is already covered.)
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
-        if (local) refer_targets(J, q);
+        if (local) refer_targets(oj[q]);
         for (int k = k_lo; k < k_hi; k += 2) {
 #pragma unroll
           for (int rr = 0; rr < 2; ++rr) {
@@ -437,7 +468,7 @@ pair_sym_f32(SymArgs a) {
             }
             // hand the pass's J accumulators to the lane that meets the same J vortices next step (lane - 1)
 #pragma unroll
-            for (int mm = 0; mm < 2; ++mm) { bu[2 * q + mm] = dpp_rol1(bu[2 * q + mm]); bw[2 * q + mm] = dpp_rol1(bw[2 * q + mm]); }
+            for (int mm = 0; mm < 2; ++mm) { bu[2 * q + mm] = rol1(bu[2 * q + mm], rot4); bw[2 * q + mm] = rol1(bw[2 * q + mm], rot4); }
           }
         }
       }
