@@ -45,6 +45,7 @@ struct ludvm_ctx {
   int tune_split = 0;
   int sym_mode = 1;
   int tune_sym_t = 0, tune_sym_rsplit = 0;   // ludvm_set_sym_tuning (0 = heuristics)
+  long long sym_tail_items = kSymTailItems;  // mixed granularity: work kept for the fine-grained end (LUDVM_SYM_TAIL_ITEMS)
   int grid_kernel = 2;                       // flow-field grids (LUDVM_GRID_KERNEL): 1 = 4 points of a row per lane; 2 = patch,
                                              // 4 x 4 from 2^20 grid points and 2 x 4 below; 3 / 4 = always the 2 x 4 / 4 x 4 patch
   long long small_tile_max = 14000;          // direct fp32 launches with at most this many sources use 256-source tiles
@@ -467,25 +468,27 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   a.tune_rsplit = c->tune_sym_rsplit;
   a.shard_rank = (n_dev && sharded) ? c->shard_rank : 0;       // (host-sized launches get their tile block as arguments)
   a.shard_world = (n_dev && sharded) ? c->shard_world : 1;
-  const SymGeom gm = sym_geometry(n, T, a.tune_split, a.tune_rsplit);
+  a.tail_items = c->sym_tail_items;
+  const SymGeom gm = sym_geometry(n, T, a.tune_split, a.tune_rsplit, a.tail_items);
   a.ntiles = gm.ntiles;
   a.dmax = gm.dmax;
   a.i_first = i_first;
   a.i_count = i_count;
   a.ysplit = gm.ysplit;
   a.rsplit = gm.rsplit;
+  a.ytail = gm.ytail;
   a.acc_u = o.acc_u;
   a.acc_w = o.acc_w;
   a.scale = o.scale;
   a.bad = o.bad;
   a.vc4 = (float)vc4;
   // workgroups: 4 / rsplit items (tile, d-chunk) each
-  long long blocks = sym_blocks(i_count, gm.ysplit, gm.rsplit);
+  long long blocks = sym_blocks(i_count, gm.ysplit, gm.rsplit, gm.ytail);
   if (n_dev) {
     const long long W = 64LL * T;
     for (long long nt = std::max<long long>(1, (std::max<long long>(n_lo, 1) + W - 1) / W); nt <= gm.ntiles; ++nt) {
-      const SymGeom q = sym_geometry(nt * W, T, a.tune_split, gm.rsplit);    // rsplit fixed by the bound: it picks the kernel
-      blocks = std::max(blocks, sym_blocks(q.ntiles, q.ysplit, gm.rsplit));
+      const SymGeom q = sym_geometry(nt * W, T, a.tune_split, gm.rsplit, a.tail_items);    // the waves-per-item rule fixed by the bound: it picks the kernel
+      blocks = std::max(blocks, sym_blocks(q.ntiles, q.ysplit, gm.rsplit, q.ytail));
     }
   }
   if (!n_dev && i_count == 0) return LUDVM_OK;     // an owner without tiles (fewer tiles than owners)
@@ -497,6 +500,7 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   const dim3 blk(kBlock);
 #define LUDVM_SYM_LAUNCH(TT, HH)                                                                              \
   switch (gm.rsplit) {                                                                                        \
+    case 0: hipLaunchKernelGGL((pair_sym_f32<TT, HH, 0>), grid, blk, 0, c->stream, a); break;                 \
     case 1: hipLaunchKernelGGL((pair_sym_f32<TT, HH, 1>), grid, blk, 0, c->stream, a); break;                 \
     case 2: hipLaunchKernelGGL((pair_sym_f32<TT, HH, 2>), grid, blk, 0, c->stream, a); break;                 \
     default: hipLaunchKernelGGL((pair_sym_f32<TT, HH, 4>), grid, blk, 0, c->stream, a); break;                \
@@ -736,6 +740,10 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
     const std::string k(gk);
     c->grid_kernel = k == "row" || k == "1" ? 1 : (k == "patch2" ? 3 : (k == "patch4" ? 4 : 2));
   }
+  if (const char* ti = std::getenv("LUDVM_SYM_TAIL_ITEMS")) c->sym_tail_items = std::max<long long>(0, std::atoll(ti));
+  if (const char* mx = std::getenv("LUDVM_SYM_MIXED")) {        // 0: round 2's rule, one granularity per launch
+    if (mx[0] == '0') c->tune_sym_rsplit = -1;
+  }
   if (small_env) { c->small_tile_max = std::atoll(small_env); c->small_tile_max_f64 = std::min<long long>(c->small_tile_max, 12000); }
   const char* small64_env = std::getenv("LUDVM_SMALL_TILE_MAX_F64");
   if (small64_env) c->small_tile_max_f64 = std::atoll(small64_env);
@@ -813,8 +821,8 @@ int ludvm_set_sym_tuning(ludvm_ctx* c, int vortices_per_lane, int rotation_split
   if (!c) return LUDVM_E_ARG;
   if (vortices_per_lane != 0 && vortices_per_lane != 4 && vortices_per_lane != 8)
     return fail(c, LUDVM_E_ARG, "vortices_per_lane must be 0 (heuristic), 4 or 8");
-  if (rotation_split != 0 && rotation_split != 1 && rotation_split != 2 && rotation_split != 4)
-    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (heuristic), 1, 2 or 4");
+  if (rotation_split != 0 && rotation_split != -1 && rotation_split != 1 && rotation_split != 2 && rotation_split != 4)
+    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (mixed), -1 (one granularity per launch, by size), 1, 2 or 4");
   c->tune_sym_t = vortices_per_lane;
   c->tune_sym_rsplit = rotation_split;
   return LUDVM_OK;

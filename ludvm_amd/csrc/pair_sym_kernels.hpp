@@ -49,8 +49,10 @@ struct SymArgs {
   long long dmax;        // floor((ntiles-1)/2): symmetric offsets 1..dmax (+ ntiles/2 when even)
   long long i_first;     // this launch owns I tiles [i_first, i_first + i_count): one GPU's block of the
   long long i_count;     //   global tile ring (multi-GPU), or all tiles
-  int ysplit;            // number of d-chunks (gridDim.x = ceil(i_count*ysplit*rsplit / 4))
-  int rsplit;            // 1, 2 or 4: the 64 rotation steps of a tile pair are shared by this many waves
+  int ysplit;            // number of d-chunks
+  int rsplit;            // 1, 2 or 4: the 64 rotation steps of a tile pair are shared by this many waves; 0: mixed --
+  int ytail;             //   the items of the last `ytail` d-chunks by 4 waves, the others by one (sym_geometry)
+  long long tail_items;  //   (how many single-wave items' worth of work that fine-grained end should hold)
   int tune_split, tune_rsplit;   // ludvm_set_tuning / ludvm_set_sym_tuning overrides (0 = heuristics), for n_dev launches
   long long* acc_u; long long* acc_w;   // raw fixed-point sums: u = acc_u / (scale 2 pi), w = -acc_w / (scale 2 pi)
   const SymScale* scale;
@@ -74,14 +76,33 @@ constexpr long long kSymMaxSplit = 64;
 constexpr long long kXcds = 8;                        // XCDs of an MI355X: workgroup b is dispatched to XCD b % 8
 constexpr long long kSymMaxRsplit = 4;
 constexpr long long kSymMinItems = 10500;          // measured (profiles/r02_atomics_cost_and_lds_reduction.txt, table 4)
-struct SymGeom { long long ntiles, dmax, dtot; int ysplit, rsplit; };
-// workgroups of a launch over i_count I tiles: the same number for each XCD, sized for the largest eighth
-__host__ __device__ inline long long sym_blocks(long long i_count, long long ysplit, int rsplit) {
-  const long long ipb = 4 / rsplit, per_xcd = (i_count + kXcds - 1) / kXcds;
-  return kXcds * ((per_xcd * ysplit + ipb - 1) / ipb);
+// Mixed granularity (rsplit = 0, the default): a launch ends when its last waves do, and with every workgroup the same
+// size the chip drains over about one workgroup lifetime.  So the items that are dispatched LAST -- those of the highest
+// d-chunks, in every owner's order -- are worked by four waves each (a quarter of the rotation steps per wave, partial sums
+// added through LDS), the bulk before them by one wave each with no barrier at all: about one chip-load of wave slots
+// (kSymTailItems single-wave items) is kept for the fine-grained end.  Which items those are is a function of the vortex
+// count alone (their d-chunk), so the partition into partial sums is the same for every owner of a sharded ring.
+constexpr long long kSymTailItems = 3072;          // 256 CUs x 4 SIMDs x 3 waves
+struct SymGeom { long long ntiles, dmax, dtot; int ysplit, rsplit, ytail; };
+// XCD-local block layout of a launch over i_count I tiles: every XCD gets the same number of workgroups, sized for the
+// largest eighth; with rsplit = 0 the first nb1 workgroups of an XCD hold four single-wave items each (d-chunks below
+// ysplit - ytail), the rest one four-wave item each
+struct SymBlocks { long long nb1, total; };
+__host__ __device__ inline SymBlocks sym_blocks_xcd(long long i_count, long long ysplit, int rsplit, long long ytail) {
+  const long long per_xcd = (i_count + kXcds - 1) / kXcds;
+  if (rsplit == 0) {
+    const long long nb1 = (per_xcd * (ysplit - ytail) + 3) / 4;
+    return SymBlocks{nb1, nb1 + per_xcd * ytail};
+  }
+  const long long ipb = 4 / rsplit;
+  return SymBlocks{0, (per_xcd * ysplit + ipb - 1) / ipb};
+}
+__host__ __device__ inline long long sym_blocks(long long i_count, long long ysplit, int rsplit, long long ytail = 0) {
+  return kXcds * sym_blocks_xcd(i_count, ysplit, rsplit, ytail).total;
 }
 
-__host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_split, int tune_rsplit) {
+__host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_split, int tune_rsplit,
+                                                 long long tail_items = kSymTailItems) {
   SymGeom g;
   const long long W = 64LL * T;
   g.ntiles = (n + W - 1) / W;
@@ -93,8 +114,16 @@ __host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_spl
   if (ys > g.dtot) ys = g.dtot;
   if (ys < 1) ys = 1;
   long long rs = 1;
-  if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) rs = tune_rsplit;
-  else while (rs < kSymMaxRsplit && nt1 * ys * rs < kSymMinItems) rs *= 2;
+  g.ytail = 0;
+  if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) {
+    rs = tune_rsplit;
+  } else if (tune_rsplit == -1) {              // round 2's rule: one granularity per launch
+    while (rs < kSymMaxRsplit && nt1 * ys * rs < kSymMinItems) rs *= 2;
+  } else {                                     // mixed: the last d-chunks by four waves per item
+    rs = 0;
+    long long yt = (tail_items + nt1 - 1) / nt1;
+    g.ytail = (int)(yt > ys ? ys : yt);
+  }
   g.ysplit = (int)ys;
   g.rsplit = (int)rs;
   return g;
@@ -234,16 +263,18 @@ __device__ __forceinline__ void slab_load(const float* l, int home4, f32x2 (&out
 // measurement build only (tools/sym_wave_trace.py): every wave stores its start and end time (100 MHz clock)
 __device__ unsigned long long* g_wave_trace = nullptr;
 #endif
-template <int T, bool HILO = false, int R = 1, bool RED = (R > 1)>
+// R = 0: mixed granularity -- a workgroup holds either four single-wave items or one four-wave item (sym_geometry).
+template <int T, bool HILO = false, int R = 1, bool RED = (R != 1)>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T == 8 || HILO ? LUDVM_SYM_OCC8 : 4)))
 pair_sym_f32(SymArgs a) {
   static_assert(T == 4 || T == 8, "T vortices per lane, read as T/4 ds_read_b128 per component");
-  static_assert(R == 1 || R == 2 || R == 4, "waves per item");
-  static_assert(!RED || R > 1, "nothing to reduce with one wave per item");
+  static_assert(R == 0 || R == 1 || R == 2 || R == 4, "waves per item");
+  static_assert(RED == (R != 1), "one wave per item has nothing to reduce");
+  constexpr int RR = R == 0 ? 4 : R;          // waves per item where several share one
   if (a.n_dev) {
-    // (rsplit stays what the host chose from its bound on n: it selects this very instantiation)
+    // (the instantiation -- tile and waves-per-item rule -- is what the host chose from its bound on n)
     a.n = *a.n_dev;
-    const SymGeom gm = sym_geometry(a.n, T, a.tune_split, R);
+    const SymGeom gm = sym_geometry(a.n, T, a.tune_split, R == 0 ? 0 : R, a.tail_items);
     a.ntiles = gm.ntiles;
     a.dmax = gm.dmax;
     a.i_first = 0;
@@ -253,6 +284,7 @@ pair_sym_f32(SymArgs a) {
       a.i_count = gm.ntiles * (a.shard_rank + 1) / a.shard_world - a.i_first;
     }
     a.ysplit = gm.ysplit;
+    a.ytail = gm.ytail;
   }
 #ifdef LUDVM_WAVE_TRACE
   const unsigned long long trace_t0 = wall_clock64();
@@ -270,8 +302,6 @@ pair_sym_f32(SymArgs a) {
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: tile indices stay scalar
-  const int r = wv % R;                    // this wave's share of the rotation steps
-  const int w0 = wv - r;                   // first wave of the item in the workgroup
   // XCD-aware placement.  Workgroups are dispatched to the 8 XCDs round-robin (workgroup b runs on XCD b % 8, each with its
   // own L2): XCD x takes the x-th eighth of the launch's I tiles, for every d-chunk y, and works through its items
   // (y-major: the diagonal-tile items first) in the order of its workgroups.  Waves that run on an XCD at the same time
@@ -280,10 +310,25 @@ pair_sym_f32(SymArgs a) {
   // profiles/r02_xcd_aware_mapping.txt).  The items, and with them the partial sums, are the same whatever the placement.
   const long long xcd = blockIdx.x % kXcds, qb = blockIdx.x / kXcds;
   const long long x_lo = a.i_count * xcd / kXcds, x_n = a.i_count * (xcd + 1) / kXcds - x_lo;   // this XCD's I tiles
-  const long long q = qb * (kWaves / R) + wv / R;                                               // item within the XCD
-  const bool active = q < x_n * a.ysplit;
+  // item within the XCD, and whether this workgroup's waves share one item (wave-uniform, workgroup-uniform)
+  long long q;
+  bool active, shared;
+  if constexpr (R == 0) {
+    const long long y1 = a.ysplit - a.ytail;                       // d-chunks worked by single waves
+    const long long nb1 = sym_blocks_xcd(a.i_count, a.ysplit, 0, a.ytail).nb1;
+    shared = qb >= nb1;
+    q = shared ? x_n * y1 + (qb - nb1) : qb * kWaves + wv;
+    active = shared ? q < x_n * a.ysplit : q < x_n * y1;
+  } else {
+    shared = R > 1;
+    q = qb * (kWaves / R) + wv / R;
+    active = q < x_n * a.ysplit;
+  }
+  const int r = shared ? wv % RR : 0;      // this wave's share of the rotation steps
+  const int w0 = wv - r;                   // first wave of the item in the workgroup
   const long long item = active ? (q / x_n) * a.i_count + x_lo + q % x_n : 0;
-  if (!RED && !active) return;             // no barriers on this path: whole waves leave
+  // single-wave items meet no barrier, and the four waves of a shared item are active or not together: idle waves leave
+  if ((R == 0 || !RED) && !active) return;
   // (vortex and tile indices are 32-bit from here on -- the launcher refuses n >= 2^31 -- so that per-lane addresses are
   // a scalar base plus a 32-bit offset register instead of 64-bit register pairs)
   const unsigned n = (unsigned)a.n, ntiles = (unsigned)a.ntiles;
@@ -291,8 +336,9 @@ pair_sym_f32(SymArgs a) {
   const int y = active ? (int)(item / a.i_count) : 0;
   // This wave does rotation steps [k_lo, k_hi) of every tile pair.  A J accumulator set that starts in lane l at step
   // k_lo belongs to home lane (l + k_lo) and, one lane per step, sits in lane (home - k_hi) after the last step.
-  const int k_lo = r * (64 / R);
-  const int k_hi = k_lo + 64 / R;
+  const int ksteps = shared ? 64 / RR : 64;
+  const int k_lo = r * ksteps;
+  const int k_hi = k_lo + ksteps;
   constexpr unsigned W = 64u * T;
   float* const lx = slab[wv][0];
   float* const lz = slab[wv][1];
@@ -408,7 +454,7 @@ pair_sym_f32(SymArgs a) {
     const bool valid = diag || (active && d < d_hi && !(even && d == dtot && I >= ntiles / 2));  // the half-way offset pairs each tile twice
     unsigned J = I + (unsigned)d;
     if (J >= ntiles) J -= ntiles;
-    if (!RED && !valid) continue;
+    if ((!RED || !shared) && !valid) continue;
     f32x2 bu[H], bw[H];
 #pragma unroll
     for (int m = 0; m < H; ++m) { bu[m] = (f32x2){0.f, 0.f}; bw[m] = (f32x2){0.f, 0.f}; }
@@ -481,7 +527,7 @@ pair_sym_f32(SymArgs a) {
     // 2m, 1: u of 2m+1, 2: w of 2m, 3: w of 2m+1}
     const int home = (lane + k_hi) & 63;
     if (diag) continue;        // (no barrier in this round)
-    if constexpr (!RED) {
+    if (!RED || !shared) {
       if (valid) {
 #pragma unroll
         for (int m = 0; m < H; ++m) {
@@ -502,10 +548,10 @@ pair_sym_f32(SymArgs a) {
       if (valid) {
         // the R waves of the item share the 2 T components; each adds the R partials in wave order
 #pragma unroll 1
-        for (int c = r; c < 2 * T; c += R) {
+        for (int c = r; c < 2 * T; c += RR) {
           float v = 0.0f;
 #pragma unroll
-          for (int q = 0; q < R; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
+          for (int q = 0; q < RR; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
           const unsigned j = J * W + lane + 64u * (2 * (c / 4) + (c & 1));
           if (j < n) { fx_add((c & 2) ? &a.acc_w[j] : &a.acc_u[j], -v, fxs); chk += v; }
         }
@@ -515,7 +561,7 @@ pair_sym_f32(SymArgs a) {
   }
 
   // ---- the I side ------------------------------------------------------------------------------------------------
-  if constexpr (!RED) {
+  if (!RED || !shared) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const unsigned i = I * W + lane + 64u * t;
@@ -531,10 +577,10 @@ pair_sym_f32(SymArgs a) {
     __syncthreads();
     if (active) {
 #pragma unroll 1
-      for (int c = r; c < 2 * T; c += R) {
+      for (int c = r; c < 2 * T; c += RR) {
         float v = 0.0f;
 #pragma unroll
-        for (int q = 0; q < R; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
+        for (int q = 0; q < RR; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
         const unsigned i = I * W + lane + 64u * (c / 2);
         if (i < n) { fx_add((c & 1) ? &a.acc_w[i] : &a.acc_u[i], v, fxs); chk += v; }
       }

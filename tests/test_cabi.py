@@ -166,6 +166,6 @@ def test_hot_kernels_do_not_spill():
     for name, r in pair.items():
         assert int(r["ScratchSize [bytes/lane]"]) == 0 and int(r["VGPRs Spill"]) == 0 and int(r["AGPRs"]) == 0, (name, r)
     t8 = {k: v for k, v in pair.items() if "pair_sym_f32ILi8" in k}
-    assert len(t8) == 3
+    assert len(t8) == 4        # mixed granularity (default), and 1, 2, 4 waves per work item
     for name, r in t8.items():
         assert int(r["VGPRs"]) <= 168 and int(r["Occupancy [waves/SIMD]"]) >= 3, (name, r)

@@ -791,11 +791,12 @@ def test_full_size_config4_self_advection_step(eng):
         eng.set_stream(None)
 
 
-@pytest.mark.parametrize("n", [16384 + 77, 50000])
+@pytest.mark.parametrize("n", [16384 + 77, 50000, 150001])
 def test_symmetric_kernel_rotation_split_variants(eng, n):
     """Every tiling of the symmetric kernel (256 / 512-vortex tiles) with a tile pair's 64 rotation steps done by
-    1, 2 or 4 wavefronts (ludvm_set_sym_tuning): sampled targets against the C oracle, all vortices against the
-    direct kernel."""
+    1, 2 or 4 wavefronts, by four for the work items dispatched last and one for the rest (0: mixed granularity, the
+    default), or by round 2's one-number-per-launch rule (-1) (ludvm_set_sym_tuning): sampled targets against the C
+    oracle, all vortices against the direct kernel; every variant repeats bit for bit."""
     import torch
     from ludvm_amd import LudvmHipError
     rng = np.random.default_rng(n)
@@ -822,11 +823,13 @@ def test_symmetric_kernel_rotation_split_variants(eng, n):
         ud, wd = velocities()
         eng.set_symmetric(2)
         for t in (4, 8):
-            for r in (1, 2, 4):
+            for r in (0, -1, 1, 2, 4):
                 eng.set_sym_tuning(t, r)
                 u, w = velocities()
                 assert _rel(u[sel], w[sel], ur, wr) < 1e-5, (t, r)
                 assert _rel(u, w, ud, wd) < 1e-5, (t, r)
+                u2, w2 = velocities()
+                assert np.array_equal(u, u2) and np.array_equal(w, w2), (t, r)
         with pytest.raises(LudvmHipError):
             eng.set_sym_tuning(3, 1)
         with pytest.raises(LudvmHipError):

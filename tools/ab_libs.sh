@@ -8,7 +8,7 @@ for rep in 1 2; do
     LUDVM_HIP_LIB=$lib python tools/sweep_rollup.py $SIZES 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
-    d=json.loads(l); print(d['n'], d['sym_f32_us'], d['sym_f32x2_us'], d['direct_f32_us'])"
+    d=json.loads(l); print(d['n'], d['sym_f32_us'], d['sym_f32x2_us'], d.get('direct_f32_us'))"
   done
 done
 for rep in 1 2; do

@@ -6,11 +6,11 @@ for rep in 1 2; do
   echo "== round-2 tree, sweep $rep"; (cd _ab/r2 && python tools/sweep_rollup.py $SIZES 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
-    d=json.loads(l); print(d['n'], d['sym_f32_us'], d['sym_f32x2_us'], d['direct_f32_us'])")
+    d=json.loads(l); print(d['n'], d['sym_f32_us'], d['sym_f32x2_us'], d.get('direct_f32_us'))")
   echo "== this tree, sweep $rep"; python tools/sweep_rollup.py $SIZES 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
-    d=json.loads(l); print(d['n'], d['sym_f32_us'], d['sym_f32x2_us'], d['direct_f32_us'])"
+    d=json.loads(l); print(d['n'], d['sym_f32_us'], d['sym_f32x2_us'], d.get('direct_f32_us'))"
 done
 for rep in 1 2; do
   echo "== round-2 tree, bench $rep"; (cd _ab/r2 && python bench.py --steps 10 --warmup 2 --cpu-rows 0 --repeats 1 2>/dev/null | python -c "

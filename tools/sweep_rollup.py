@@ -24,7 +24,7 @@ for n in sizes:
     z = 0.3 * np.sin(0.7 * x) + 1e-3 * rng.standard_normal(n)
     g = rng.standard_normal(n) * 1e-3
     res = {"n": n}
-    for mode, mname in ((2, "sym"), (0, "direct")):
+    for mode, mname in ((2, "sym"),) + (() if os.environ.get("SWEEP_SYM_ONLY") else ((0, "direct"),)):
         eng.set_symmetric(mode)
         for prec in ("f32", "f32x2"):
             eng.wake_clear()
