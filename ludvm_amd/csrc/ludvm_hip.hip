@@ -487,7 +487,7 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   if (n_dev) {
     const long long W = 64LL * T;
     for (long long nt = std::max<long long>(1, (std::max<long long>(n_lo, 1) + W - 1) / W); nt <= gm.ntiles; ++nt) {
-      const SymGeom q = sym_geometry(nt * W, T, a.tune_split, gm.rsplit, a.tail_items);    // the waves-per-item rule fixed by the bound: it picks the kernel
+      const SymGeom q = sym_geometry(nt * W, T, a.tune_split, gm.rsplit == 0 ? -1 : gm.rsplit, a.tail_items);    // the waves-per-item rule fixed by the bound: it picks the kernel
       blocks = std::max(blocks, sym_blocks(q.ntiles, q.ysplit, gm.rsplit, q.ytail));
     }
   }
@@ -741,8 +741,8 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
     c->grid_kernel = k == "row" || k == "1" ? 1 : (k == "patch2" ? 3 : (k == "patch4" ? 4 : 2));
   }
   if (const char* ti = std::getenv("LUDVM_SYM_TAIL_ITEMS")) c->sym_tail_items = std::max<long long>(0, std::atoll(ti));
-  if (const char* mx = std::getenv("LUDVM_SYM_MIXED")) {        // 0: round 2's rule, one granularity per launch
-    if (mx[0] == '0') c->tune_sym_rsplit = -1;
+  if (const char* mx = std::getenv("LUDVM_SYM_MIXED")) {        // 1: mixed granularity within a launch (measured: does not pay)
+    if (mx[0] == '1') c->tune_sym_rsplit = -1;
   }
   if (small_env) { c->small_tile_max = std::atoll(small_env); c->small_tile_max_f64 = std::min<long long>(c->small_tile_max, 12000); }
   const char* small64_env = std::getenv("LUDVM_SMALL_TILE_MAX_F64");
@@ -822,7 +822,7 @@ int ludvm_set_sym_tuning(ludvm_ctx* c, int vortices_per_lane, int rotation_split
   if (vortices_per_lane != 0 && vortices_per_lane != 4 && vortices_per_lane != 8)
     return fail(c, LUDVM_E_ARG, "vortices_per_lane must be 0 (heuristic), 4 or 8");
   if (rotation_split != 0 && rotation_split != -1 && rotation_split != 1 && rotation_split != 2 && rotation_split != 4)
-    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (mixed), -1 (one granularity per launch, by size), 1, 2 or 4");
+    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (by size), -1 (mixed granularity), 1, 2 or 4");
   c->tune_sym_t = vortices_per_lane;
   c->tune_sym_rsplit = rotation_split;
   return LUDVM_OK;

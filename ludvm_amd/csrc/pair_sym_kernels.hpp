@@ -76,12 +76,17 @@ constexpr long long kSymMaxSplit = 64;
 constexpr long long kXcds = 8;                        // XCDs of an MI355X: workgroup b is dispatched to XCD b % 8
 constexpr long long kSymMaxRsplit = 4;
 constexpr long long kSymMinItems = 10500;          // measured (profiles/r02_atomics_cost_and_lds_reduction.txt, table 4)
-// Mixed granularity (rsplit = 0, the default): a launch ends when its last waves do, and with every workgroup the same
-// size the chip drains over about one workgroup lifetime.  So the items that are dispatched LAST -- those of the highest
-// d-chunks, in every owner's order -- are worked by four waves each (a quarter of the rotation steps per wave, partial sums
-// added through LDS), the bulk before them by one wave each with no barrier at all: about one chip-load of wave slots
-// (kSymTailItems single-wave items) is kept for the fine-grained end.  Which items those are is a function of the vortex
-// count alone (their d-chunk), so the partition into partial sums is the same for every owner of a sharded ring.
+// Mixed granularity (rsplit = 0; ludvm_set_sym_tuning(.., -1) or LUDVM_SYM_MIXED=1 -- NOT the default): a launch ends when
+// its last waves do, and with every workgroup the same size the chip drains over about one workgroup lifetime.  So the
+// items that are dispatched LAST -- those of the highest d-chunks, in every owner's order -- are worked by four waves each
+// (a quarter of the rotation steps per wave, partial sums added through LDS), the bulk before them by one wave each with
+// no barrier at all: about one chip-load of wave slots (kSymTailItems single-wave items) is kept for the fine-grained
+// end.  Which items those are is a function of the vortex count alone (their d-chunk), so the partition into partial sums
+// is the same for every owner of a sharded ring.  Measured [MI355X] (profiles/r03_mixed_granularity_negative_result.txt,
+// same box, alternating): +2-3 % at 32 768, 49 152 and 65 536 vortices, -3 % at 40 960 and 98 304, nothing from 262 144
+// up, and BASELINE config 2 as a whole 1 % SLOWER (11.03 s against 10.92 s): a four-wave item pays the partner tile's
+// load latency, two workgroup barriers and the LDS reduction for a quarter of the arithmetic, which costs what the
+// shorter drain brings.  The size-dependent one-number-per-launch rule below therefore stays the default.
 constexpr long long kSymTailItems = 3072;          // 256 CUs x 4 SIMDs x 3 waves
 struct SymGeom { long long ntiles, dmax, dtot; int ysplit, rsplit, ytail; };
 // XCD-local block layout of a launch over i_count I tiles: every XCD gets the same number of workgroups, sized for the
@@ -117,12 +122,12 @@ __host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_spl
   g.ytail = 0;
   if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) {
     rs = tune_rsplit;
-  } else if (tune_rsplit == -1) {              // round 2's rule: one granularity per launch
-    while (rs < kSymMaxRsplit && nt1 * ys * rs < kSymMinItems) rs *= 2;
-  } else {                                     // mixed: the last d-chunks by four waves per item
+  } else if (tune_rsplit == -1) {              // mixed: the last d-chunks by four waves per item
     rs = 0;
     long long yt = (tail_items + nt1 - 1) / nt1;
     g.ytail = (int)(yt > ys ? ys : yt);
+  } else {                                     // one granularity per launch: the smallest that gives enough work items
+    while (rs < kSymMaxRsplit && nt1 * ys * rs < kSymMinItems) rs *= 2;
   }
   g.ysplit = (int)ys;
   g.rsplit = (int)rs;
@@ -274,7 +279,7 @@ pair_sym_f32(SymArgs a) {
   if (a.n_dev) {
     // (the instantiation -- tile and waves-per-item rule -- is what the host chose from its bound on n)
     a.n = *a.n_dev;
-    const SymGeom gm = sym_geometry(a.n, T, a.tune_split, R == 0 ? 0 : R, a.tail_items);
+    const SymGeom gm = sym_geometry(a.n, T, a.tune_split, R == 0 ? -1 : R, a.tail_items);
     a.ntiles = gm.ntiles;
     a.dmax = gm.dmax;
     a.i_first = 0;

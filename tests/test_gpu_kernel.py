@@ -794,9 +794,9 @@ def test_full_size_config4_self_advection_step(eng):
 @pytest.mark.parametrize("n", [16384 + 77, 50000, 150001])
 def test_symmetric_kernel_rotation_split_variants(eng, n):
     """Every tiling of the symmetric kernel (256 / 512-vortex tiles) with a tile pair's 64 rotation steps done by
-    1, 2 or 4 wavefronts, by four for the work items dispatched last and one for the rest (0: mixed granularity, the
-    default), or by round 2's one-number-per-launch rule (-1) (ludvm_set_sym_tuning): sampled targets against the C
-    oracle, all vortices against the direct kernel; every variant repeats bit for bit."""
+    1, 2 or 4 wavefronts, by the size rule (0, the default), or by four for the work items dispatched last and one for
+    the rest (-1: mixed granularity) (ludvm_set_sym_tuning): sampled targets against the C oracle, all vortices against
+    the direct kernel; every variant repeats bit for bit."""
     import torch
     from ludvm_amd import LudvmHipError
     rng = np.random.default_rng(n)
