@@ -106,31 +106,40 @@ __host__ __device__ inline long long sym_blocks(long long i_count, long long ysp
   return kXcds * sym_blocks_xcd(i_count, ysplit, rsplit, ytail).total;
 }
 
+// (I: long long on the host, unsigned on the device -- the kernel's prologue runs once per wave and a 64-bit division
+// costs ~100 instructions there; both give the same numbers for n < 2^31)
+template <typename I>
+__host__ __device__ inline void sym_geometry_t(I n, int T, int tune_split, int tune_rsplit, I tail_items, I& ntiles, I& dmax,
+                                               I& dtot, int& ysplit, int& rsplit, int& ytail) {
+  const I W = (I)(64 * T);
+  ntiles = (n + W - 1) / W;
+  dmax = ntiles > 0 ? (ntiles - 1) / 2 : 0;
+  dtot = dmax + ((ntiles % 2 == 0 && ntiles > 1) ? 1 : 0);
+  const I nt1 = ntiles > 0 ? ntiles : 1;
+  // (kSymTargetWaves / nt1 rounded up is at least kSymMaxSplit whenever nt1 <= kSymTargetWaves / kSymMaxSplit: no division)
+  I ys = tune_split > 0 ? (I)tune_split
+                        : (nt1 <= (I)(kSymTargetWaves / kSymMaxSplit) ? (I)kSymMaxSplit : ((I)kSymTargetWaves + nt1 - 1) / nt1);
+  if (ys > (I)kSymMaxSplit) ys = (I)kSymMaxSplit;
+  if (ys > dtot) ys = dtot;
+  if (ys < 1) ys = 1;
+  I rs = 1;
+  ytail = 0;
+  if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) {
+    rs = (I)tune_rsplit;
+  } else if (tune_rsplit == -1) {              // mixed: the last d-chunks by four waves per item
+    rs = 0;
+    const I yt = (tail_items + nt1 - 1) / nt1;
+    ytail = (int)(yt > ys ? ys : yt);
+  } else {                                     // one granularity per launch: the smallest that gives enough work items
+    while (rs < (I)kSymMaxRsplit && nt1 * ys * rs < (I)kSymMinItems) rs *= 2;
+  }
+  ysplit = (int)ys;
+  rsplit = (int)rs;
+}
 __host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_split, int tune_rsplit,
                                                  long long tail_items = kSymTailItems) {
   SymGeom g;
-  const long long W = 64LL * T;
-  g.ntiles = (n + W - 1) / W;
-  g.dmax = (g.ntiles - 1) / 2;
-  g.dtot = g.dmax + ((g.ntiles % 2 == 0 && g.ntiles > 1) ? 1 : 0);
-  const long long nt1 = g.ntiles > 0 ? g.ntiles : 1;
-  long long ys = tune_split > 0 ? tune_split : (kSymTargetWaves + nt1 - 1) / nt1;
-  if (ys > kSymMaxSplit) ys = kSymMaxSplit;
-  if (ys > g.dtot) ys = g.dtot;
-  if (ys < 1) ys = 1;
-  long long rs = 1;
-  g.ytail = 0;
-  if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) {
-    rs = tune_rsplit;
-  } else if (tune_rsplit == -1) {              // mixed: the last d-chunks by four waves per item
-    rs = 0;
-    long long yt = (tail_items + nt1 - 1) / nt1;
-    g.ytail = (int)(yt > ys ? ys : yt);
-  } else {                                     // one granularity per launch: the smallest that gives enough work items
-    while (rs < kSymMaxRsplit && nt1 * ys * rs < kSymMinItems) rs *= 2;
-  }
-  g.ysplit = (int)ys;
-  g.rsplit = (int)rs;
+  sym_geometry_t<long long>(n, T, tune_split, tune_rsplit, tail_items, g.ntiles, g.dmax, g.dtot, g.ysplit, g.rsplit, g.ytail);
   return g;
 }
 
@@ -276,20 +285,24 @@ pair_sym_f32(SymArgs a) {
   static_assert(R == 0 || R == 1 || R == 2 || R == 4, "waves per item");
   static_assert(RED == (R != 1), "one wave per item has nothing to reduce");
   constexpr int RR = R == 0 ? 4 : R;          // waves per item where several share one
+  // vortex, tile and item numbers are 32-bit on the device (the launcher refuses n >= 2^31): per-lane addresses are a
+  // scalar base plus a 32-bit offset register, and the prologue -- run once per wave, which at mid sizes lives for 16 or
+  // 32 rotation steps only -- needs two 32-bit divisions instead of a dozen 64-bit ones
+  unsigned n = (unsigned)a.n, ntiles = (unsigned)a.ntiles, dmax = (unsigned)a.dmax, i_first = (unsigned)a.i_first,
+           i_count = (unsigned)a.i_count;
+  int ysplit = a.ysplit, ytail = a.ytail;
   if (a.n_dev) {
     // (the instantiation -- tile and waves-per-item rule -- is what the host chose from its bound on n)
-    a.n = *a.n_dev;
-    const SymGeom gm = sym_geometry(a.n, T, a.tune_split, R == 0 ? -1 : R, a.tail_items);
-    a.ntiles = gm.ntiles;
-    a.dmax = gm.dmax;
-    a.i_first = 0;
-    a.i_count = gm.ntiles;
+    n = (unsigned)*a.n_dev;
+    unsigned dtot_;
+    int rs_;
+    sym_geometry_t<unsigned>(n, T, a.tune_split, R == 0 ? -1 : R, (unsigned)a.tail_items, ntiles, dmax, dtot_, ysplit, rs_, ytail);
+    i_first = 0;
+    i_count = ntiles;
     if (a.shard_world > 1) {
-      a.i_first = gm.ntiles * a.shard_rank / a.shard_world;
-      a.i_count = gm.ntiles * (a.shard_rank + 1) / a.shard_world - a.i_first;
+      i_first = (unsigned)((unsigned long long)ntiles * a.shard_rank / a.shard_world);
+      i_count = (unsigned)((unsigned long long)ntiles * (a.shard_rank + 1) / a.shard_world) - i_first;
     }
-    a.ysplit = gm.ysplit;
-    a.ytail = gm.ytail;
   }
 #ifdef LUDVM_WAVE_TRACE
   const unsigned long long trace_t0 = wall_clock64();
@@ -313,32 +326,30 @@ pair_sym_f32(SymArgs a) {
   // then hold neighbouring I tiles with the same offsets d, i.e. overlapping partner tiles J, and the L2 serves them:
   // memory-side fetches of an N = 2^20 launch 2.04 GB -> 0.03 GB at unchanged speed (the kernel is ALU-bound;
   // profiles/r02_xcd_aware_mapping.txt).  The items, and with them the partial sums, are the same whatever the placement.
-  const long long xcd = blockIdx.x % kXcds, qb = blockIdx.x / kXcds;
-  const long long x_lo = a.i_count * xcd / kXcds, x_n = a.i_count * (xcd + 1) / kXcds - x_lo;   // this XCD's I tiles
+  const unsigned xcd = blockIdx.x % (unsigned)kXcds, qb = blockIdx.x / (unsigned)kXcds;
+  const unsigned x_lo = i_count * xcd / (unsigned)kXcds, x_n = i_count * (xcd + 1) / (unsigned)kXcds - x_lo;   // this XCD's I tiles
   // item within the XCD, and whether this workgroup's waves share one item (wave-uniform, workgroup-uniform)
-  long long q;
+  unsigned q;
   bool active, shared;
   if constexpr (R == 0) {
-    const long long y1 = a.ysplit - a.ytail;                       // d-chunks worked by single waves
-    const long long nb1 = sym_blocks_xcd(a.i_count, a.ysplit, 0, a.ytail).nb1;
+    const unsigned y1 = (unsigned)(ysplit - ytail);                // d-chunks worked by single waves
+    const unsigned nb1 = (((i_count + (unsigned)kXcds - 1) / (unsigned)kXcds) * y1 + 3) / 4;      // (= sym_blocks_xcd(...).nb1)
     shared = qb >= nb1;
     q = shared ? x_n * y1 + (qb - nb1) : qb * kWaves + wv;
-    active = shared ? q < x_n * a.ysplit : q < x_n * y1;
+    active = shared ? q < x_n * (unsigned)ysplit : q < x_n * y1;
   } else {
     shared = R > 1;
     q = qb * (kWaves / R) + wv / R;
-    active = q < x_n * a.ysplit;
+    active = q < x_n * (unsigned)ysplit;
   }
   const int r = shared ? wv % RR : 0;      // this wave's share of the rotation steps
   const int w0 = wv - r;                   // first wave of the item in the workgroup
-  const long long item = active ? (q / x_n) * a.i_count + x_lo + q % x_n : 0;
   // single-wave items meet no barrier, and the four waves of a shared item are active or not together: idle waves leave
   if ((R == 0 || !RED) && !active) return;
-  // (vortex and tile indices are 32-bit from here on -- the launcher refuses n >= 2^31 -- so that per-lane addresses are
-  // a scalar base plus a 32-bit offset register instead of 64-bit register pairs)
-  const unsigned n = (unsigned)a.n, ntiles = (unsigned)a.ntiles;
-  const unsigned I = (unsigned)(a.i_first + (active ? item % a.i_count : 0));
-  const int y = active ? (int)(item / a.i_count) : 0;
+  // item q of the XCD's list (d-chunk-major): d-chunk y = q / x_n of I tile x_lo + q % x_n
+  const unsigned yq = active ? q / x_n : 0;
+  const unsigned I = i_first + (active ? x_lo + (q - yq * x_n) : 0);
+  const int y = (int)yq;
   // This wave does rotation steps [k_lo, k_hi) of every tile pair.  A J accumulator set that starts in lane l at step
   // k_lo belongs to home lane (l + k_lo) and, one lane per step, sits in lane (home - k_hi) after the last step.
   const int ksteps = shared ? 64 / RR : 64;
@@ -352,8 +363,8 @@ pair_sym_f32(SymArgs a) {
   float* const lzl = slab[wv][HILO ? 4 : 1];
 
   const bool even = (ntiles % 2 == 0) && ntiles > 1;
-  const int dtot = (int)a.dmax + (even ? 1 : 0);
-  const int per = (dtot + a.ysplit - 1) / a.ysplit;
+  const int dtot = (int)dmax + (even ? 1 : 0);
+  const int per = (int)(((unsigned)dtot + (unsigned)ysplit - 1) / (unsigned)ysplit);
   const int d_lo = 1 + y * per;
   int d_hi = d_lo + per;  // exclusive
   if (d_hi > dtot + 1) d_hi = dtot + 1;
@@ -453,34 +464,56 @@ pair_sym_f32(SymArgs a) {
   // of 11 packed ops per two pairs on 1 of ~NT/2 tile pairs -- made the compiler carry ~60 more live registers through
   // the rotation loops.)  Rounds 0 .. per - 1 are the item's tile pairs; every wave of the workgroup runs all of them,
   // valid or not, because the reducing variants meet at two workgroup barriers per round (none in round -1).
-  for (int dd = (active && y == 0) ? -1 : 0; dd < per; ++dd) {
-    const bool diag = dd < 0;
-    const int d = diag ? 0 : d_lo + dd;
-    const bool valid = diag || (active && d < d_hi && !(even && d == dtot && I >= ntiles / 2));  // the half-way offset pairs each tile twice
-    unsigned J = I + (unsigned)d;
-    if (J >= ntiles) J -= ntiles;
-    if ((!RED || !shared) && !valid) continue;
+  // The partner tile of a round is fetched one round ahead -- for the first round here, before anything waits on the own
+  // tile -- so its latency lies under the previous round's rotation loops (or under the own tile's loads): a wave of a
+  // mid-size launch lives for one tile pair's 16 or 32 rotation steps, and a microsecond of exposed latency per round is
+  // several per cent of that.
+  struct Round { unsigned J; bool diag, valid; };
+  auto round_of = [&](int dd) -> Round {
+    Round rd;
+    rd.diag = dd < 0;
+    const int d = rd.diag ? 0 : d_lo + dd;
+    rd.valid = rd.diag || (active && dd < per && d < d_hi && !(even && d == dtot && I >= ntiles / 2));  // the half-way offset pairs each tile twice
+    rd.J = I + (unsigned)d;
+    if (rd.J >= ntiles) rd.J -= ntiles;
+    return rd;
+  };
+  float pjx[T], pjz[T], pjg[T], pjxl[T], pjzl[T];
+  Org poj[NS];
+  auto fetch_tile = [&](const Round& rd) {
+    // (an invalid round loads the own tile's addresses: harmless, unused)
+    const unsigned Jt = rd.valid ? rd.J : I;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const unsigned j = Jt * W + lane + 64u * t;
+      pjx[t] = load_or(a.x, j, n, kPadPosF); pjz[t] = load_or(a.z, j, n, kPadPosF); pjg[t] = load_or(a.g, j, n, 0.0f);
+      pjxl[t] = HILO ? load_or(a.xl, j, n, 0.0f) : 0.0f; pjzl[t] = HILO ? load_or(a.zl, j, n, 0.0f) : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) poj[q] = origin_records(((Jt * W) >> kOriginShift) + q);
+  };
+  const int dd0 = (active && y == 0) ? -1 : 0;
+  fetch_tile(round_of(dd0));
+  for (int dd = dd0; dd < per; ++dd) {
+    const Round rd = round_of(dd);
+    const bool diag = rd.diag, valid = rd.valid;
+    const unsigned J = rd.J;
     f32x2 bu[H], bw[H];
 #pragma unroll
     for (int m = 0; m < H; ++m) { bu[m] = (f32x2){0.f, 0.f}; bw[m] = (f32x2){0.f, 0.f}; }
+    Org oj[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) oj[q] = poj[q];
     if (valid) {
-      {
-        float x[T], z[T], g[T], xl[T], zl[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const unsigned j = J * W + lane + 64u * t;
-          x[t] = load_or(a.x, j, n, kPadPosF); z[t] = load_or(a.z, j, n, kPadPosF); g[t] = load_or(a.g, j, n, 0.0f);
-          xl[t] = HILO ? load_or(a.xl, j, n, 0.0f) : 0.0f; zl[t] = HILO ? load_or(a.zl, j, n, 0.0f) : 0.0f;
-        }
-        slab_store<T>(lx, lane * 4, x); slab_store<T>(lz, lane * 4, z); slab_store<T>(lg, lane * 4, g);
-        if (HILO) { slab_store<T>(lxl, lane * 4, xl); slab_store<T>(lzl, lane * 4, zl); }
-      }
-      Org oj[NS];      // (scalars: fetched here, with the tile, for all passes)
-#pragma unroll
-      for (int q = 0; q < NS; ++q) oj[q] = origin_records(((J * W) >> kOriginShift) + q);
+      slab_store<T>(lx, lane * 4, pjx); slab_store<T>(lz, lane * 4, pjz); slab_store<T>(lg, lane * 4, pjg);
+      if (HILO) { slab_store<T>(lxl, lane * 4, pjxl); slab_store<T>(lzl, lane * 4, pjzl); }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // the next round's partner tile: loads in flight during this round's rotation loops
+    if (dd + 1 < per) fetch_tile(round_of(dd + 1));
+    if (valid) {
 
       // Pass q: my T targets against the 4 J vortices per home lane of J's origin block q (J accumulators bu / bw[2 q],
       // [2 q + 1]); every pass walks the wave's rotation steps [k_lo, k_hi), so all J accumulators end up with the same
