@@ -49,6 +49,7 @@ struct ludvm_ctx {
   int grid_kernel = 2;                       // flow-field grids (LUDVM_GRID_KERNEL): 1 = 4 points of a row per lane; 2 = patch,
                                              // 4 x 4 from 2^20 grid points and 2 x 4 below; 3 / 4 = always the 2 x 4 / 4 x 4 patch
   long long small_tile_max = 14000;          // direct fp32 launches with at most this many sources use 256-source tiles
+  bool few_packed = true;                    // fp64 launches with <= 128 targets: several source splits per workgroup (LUDVM_FEW_PACKED=0: off)
   long long small_tile_max_f64 = 12000;      // fp64 launches with at most this many sources use 128-source tiles
                                              // (roll-up step 52 -> 26 us at 2400 vortices, 87 -> 72 at 8192 [MI355X])
 
@@ -304,6 +305,7 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
   const size_t elt = precision == LUDVM_PREC_F64 ? sizeof(double) : sizeof(float);
   a.chunk = p.chunk;
   a.nt_pad = p.nt_pad;
+  a.nsplit = p.nsplit;
   a.u = u;
   a.w = w;
   a.part = nullptr;
@@ -322,7 +324,15 @@ int launch_pair(ludvm_ctx* c, PairArgs a, const Plan& p, int precision, void* u,
   bool active = false;
   CHK(timed_begin(c, t, active));
   if (precision == LUDVM_PREC_F64) {
-    if (p.tile == kTileF64Few)
+    // few array targets, results in the slab: several source splits per workgroup (launch sized from the host's bound on
+    // the target count when that lives on the device: never, for these launches)
+    const long long nt_few = a.nt_dev ? 0 : a.nt;
+    if (p.tile == kTileF64Few && c->few_packed && a.part != nullptr && a.grid_nz == 0 && nt_few >= 1 && 2 * nt_few <= kBlock &&
+        grid.x == 1 && p.nsplit > 1) {
+      const int groups = (int)std::min<long long>(kBlock / nt_few, kFewGroupsMax);
+      grid = dim3(1, (unsigned)((p.nsplit + groups - 1) / groups), 1);
+      hipLaunchKernelGGL((pair_f64_few<kTileF64Few>), grid, dim3(kBlock), 0, c->stream, a);
+    } else if (p.tile == kTileF64Few)
       hipLaunchKernelGGL((pair_f64<kTileF64Few>), grid, dim3(kBlock), 0, c->stream, a);
     else
       hipLaunchKernelGGL((pair_f64<kTileF64>), grid, dim3(kBlock), 0, c->stream, a);
@@ -740,6 +750,7 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
     const std::string k(gk);
     c->grid_kernel = k == "row" || k == "1" ? 1 : (k == "patch2" ? 3 : (k == "patch4" ? 4 : 2));
   }
+  if (const char* fp = std::getenv("LUDVM_FEW_PACKED")) c->few_packed = !(fp[0] == '0');
   if (const char* ti = std::getenv("LUDVM_SYM_TAIL_ITEMS")) c->sym_tail_items = std::max<long long>(0, std::atoll(ti));
   if (const char* mx = std::getenv("LUDVM_SYM_MIXED")) {        // 1: mixed granularity within a launch (measured: does not pay)
     if (mx[0] == '1') c->tune_sym_rsplit = -1;

@@ -87,6 +87,7 @@ struct PairArgs {
   const float* scx; const float* scz;
   const float* tcx; const float* tcz;
   long long t_index0;
+  int nsplit;                 // number of source splits of the launch (rows of the partial slab)
 };
 
 struct PairSizes { long long ns, nt; };
@@ -447,6 +448,73 @@ pair_f64(PairArgs a) {
       row[ti] = uu;
       row[a.nt_pad + ti] = ww;
     }
+  }
+}
+
+// The same sums for FEW targets (the 80 chord points of a time step, plus three in the march: nt <= 128), where one
+// target per lane leaves most of a 256-lane workgroup idle -- and an idle lane still walks its tile: lane l serves
+// target l % nt of source split  blockIdx.y * groups + l / nt, so a workgroup works `groups` = 256 / nt splits at once
+// (3 for 83 targets) and the launch needs a third of the workgroups.  Every (split, target) partial sum is formed by
+// one lane walking that split's sources in order, exactly as pair_f64 does: the slab -- and every bit of the result --
+// is the same.  In the overlapped march this launch runs beside the symmetric kernel and its waves take issue slots
+// from it: 2096 wave-walks per step at 67 000 vortices become 700.
+constexpr int kFewGroupsMax = 4;
+template <int TILE>
+__global__ void __launch_bounds__(kBlock)
+pair_f64_few(PairArgs a) {
+  __shared__ __attribute__((aligned(16))) double lx[kFewGroupsMax][TILE];
+  __shared__ __attribute__((aligned(16))) double lz[kFewGroupsMax][TILE];
+  __shared__ __attribute__((aligned(16))) double lg[kFewGroupsMax][TILE];
+  const double* __restrict__ xs = static_cast<const double*>(a.xs);
+  const double* __restrict__ zs = static_cast<const double*>(a.zs);
+  const double* __restrict__ gs = static_cast<const double*>(a.gs);
+  const int tid = threadIdx.x;
+  const PairSizes sz = pair_sizes(a);
+  const int nt = (int)sz.nt;                               // 1 .. kBlock / 2
+  int groups = kBlock / nt;
+  if (groups > kFewGroupsMax) groups = kFewGroupsMax;
+  const int g = tid / nt, p = tid - g * nt;
+  const long long split0 = (long long)blockIdx.y * groups;
+  const long long split = split0 + g;
+  const bool mine = g < groups && split < a.nsplit;
+  double xp = 0.0, zp = 0.0;
+  if (mine) {
+    xp = static_cast<const double*>(a.xt)[p];
+    zp = static_cast<const double*>(a.zt)[p];
+  }
+  double au = 0.0, aw = 0.0;
+  const double vc4 = a.vc4;
+  for (long long off = 0; off < a.chunk; off += TILE) {
+    __syncthreads();
+    for (int l = tid; l < groups * TILE; l += kBlock) {
+      const int gg = l / TILE, idx = l - gg * TILE;
+      const long long s_begin = (split0 + gg) * a.chunk;
+      long long s_end = s_begin + a.chunk;
+      if (s_end > sz.ns) s_end = sz.ns;
+      const long long si = s_begin + off + idx;
+      const bool ok = si < s_end;
+      lx[gg][idx] = ok ? xs[si] : kPadPosD;
+      lz[gg][idx] = ok ? zs[si] : kPadPosD;
+      lg[gg][idx] = ok ? gs[si] : 0.0;
+    }
+    __syncthreads();
+    if (mine) {
+#pragma unroll 4
+      for (int j = 0; j < TILE; ++j) {
+        const double dx = xp - lx[g][j];
+        const double dz = zp - lz[g][j];
+        const double r2 = __builtin_fma(dz, dz, dx * dx);
+        const double q = __builtin_fma(r2, r2, vc4);
+        const double sv = lg[g][j] * rsqrt_f64(q);
+        au = __builtin_fma(dz, sv, au);
+        aw = __builtin_fma(dx, sv, aw);
+      }
+    }
+  }
+  if (mine) {
+    double* row = static_cast<double*>(a.part) + split * 2 * a.nt_pad;
+    row[p] = au * kInv2PiD;
+    row[a.nt_pad + p] = -aw * kInv2PiD;
   }
 }
 
