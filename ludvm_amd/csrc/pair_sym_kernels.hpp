@@ -237,19 +237,28 @@ __device__ __forceinline__ float load_or(const float* p, unsigned i, unsigned n,
 }
 
 // Slab helpers: a wave's LDS slab holds T floats per home lane and component, as T/4 planes of
-// [64 home lanes][4 floats]: every ds_read_b128 / ds_write_b128 of a wave then covers 64 consecutive
-// 16-byte slots (conflict-free); `home4` is 4 * home lane.
-template <int T>
+// [96 slots][4 floats]: slots 0..63 are the home lanes, slots 64..95 repeat home lanes 0..31.  Every ds_read_b128 /
+// ds_write_b128 of a wave covers consecutive 16-byte slots (conflict-free); `home4` is 4 * home lane.
+// The repeated slots take the modulo out of the rotation loop: at rotation step k a lane reads the slot of home lane
+// (lane + k) % 64, and for k = 32 s + kk (s = 0, 1; kk < 32) that is slot b + kk without wrap-around, b = lane for
+// s = 0 and (lane + 32) % 64 for s = 1 -- a base register plus an offset that grows by 16 bytes per step, instead of an
+// add, a mask and a shift per step (5 of the ~440 VALU instructions of a rotation step of the 512-vortex tile).
+// (PLANE = 256: a plain [64][4] plane without the repeated slots, for data that is only read by its own lane)
+constexpr int kPlane = 96 * 4;       // floats per plane
+template <int T, int PLANE = kPlane>
 __device__ __forceinline__ void slab_store(float* l, int home4, const float (&v)[T]) {
 #pragma unroll
-  for (int q = 0; q < T / 4; ++q)
-    *reinterpret_cast<f32x4*>(&l[q * 256 + home4]) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  for (int q = 0; q < T / 4; ++q) {
+    const f32x4 V = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    *reinterpret_cast<f32x4*>(&l[q * PLANE + home4]) = V;
+    if (PLANE > 256 && home4 < 128) *reinterpret_cast<f32x4*>(&l[q * PLANE + 256 + home4]) = V;
+  }
 }
-template <int T>
+template <int T, int PLANE = kPlane>
 __device__ __forceinline__ void slab_load(const float* l, int home4, f32x2 (&out)[T / 2]) {
 #pragma unroll
   for (int q = 0; q < T / 4; ++q) {
-    const f32x4 V = *reinterpret_cast<const f32x4*>(&l[q * 256 + home4]);
+    const f32x4 V = *reinterpret_cast<const f32x4*>(&l[q * PLANE + home4]);
     out[2 * q] = (f32x2){V.x, V.y};
     out[2 * q + 1] = (f32x2){V.z, V.w};
   }
@@ -310,10 +319,10 @@ pair_sym_f32(SymArgs a) {
   constexpr int H = T / 2;
   constexpr int kWaves = kBlock / 64;
   constexpr int kComp = HILO ? 5 : 3;
-  __shared__ __attribute__((aligned(16))) float slab[kWaves][kComp][64 * T];
+  __shared__ __attribute__((aligned(16))) float slab[kWaves][kComp][(T / 4) * kPlane];
   // RED: between two tile pairs a wave's slab also carries its 2 T x 64 partial sums to the reducing waves (it is dead
   // then; 2 T <= kComp T), component c of wave w at slab[w][0][c * 64 + lane]
-  static_assert(2 * T * 64 <= kComp * 64 * T, "partial sums fit the slab");
+  static_assert(2 * T * 64 <= kComp * (T / 4) * kPlane, "partial sums fit the slab");
   // local origins: this wave's own T offsets per lane (x, z), written once: every pass over a partner tile re-refers the
   // targets from them (4 KB per wave at T = 8; the hi+lo kernels do not use local origins)
   __shared__ __attribute__((aligned(16))) float ioff[HILO ? 1 : kWaves][HILO ? 1 : 2][HILO ? 4 : 64 * T];
@@ -399,7 +408,7 @@ pair_sym_f32(SymArgs a) {
       xpl[h] = (f32x2){xl0[2 * h], xl0[2 * h + 1]}; zpl[h] = (f32x2){zl0[2 * h], zl0[2 * h + 1]};
       xq[0][h] = xp[h]; xq[1][h] = xp[h]; zq[0][h] = zp[h]; zq[1][h] = zp[h];
     }
-    if constexpr (!HILO) { slab_store<T>(ioff[wv][0], lane * 4, x0); slab_store<T>(ioff[wv][1], lane * 4, z0); }
+    if constexpr (!HILO) { slab_store<T, 256>(ioff[wv][0], lane * 4, x0); slab_store<T, 256>(ioff[wv][1], lane * 4, z0); }
   }
   const f32x2 vc4 = {a.vc4, a.vc4};
   const float fxs = a.scale->scale;
@@ -432,8 +441,8 @@ pair_sym_f32(SymArgs a) {
   // offset per target and class pair: neighbouring classes keep their relative precision, far ones do not need it.
   auto refer_targets = [&](const Org oj) {
     f32x2 xo[H], zo[H];
-    slab_load<T>(ioff[HILO ? 0 : wv][0], lane * 4, xo);
-    slab_load<T>(ioff[HILO ? 0 : wv][HILO ? 0 : 1], lane * 4, zo);
+    slab_load<T, 256>(ioff[HILO ? 0 : wv][0], lane * 4, xo);
+    slab_load<T, 256>(ioff[HILO ? 0 : wv][HILO ? 0 : 1], lane * 4, zo);
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       // the partner class met at relative parity rr has index parity pl ^ rr
@@ -450,12 +459,17 @@ pair_sym_f32(SymArgs a) {
   };
   // the 4 J vortices (two packed pairs) that plane q of the slab holds for the home lane at byte position pos4 / 4
   auto load_plane = [&](const float* l, int q, int pos4, f32x2 (&out)[2]) {
-    const f32x4 V = *reinterpret_cast<const f32x4*>(&l[q * 256 + pos4]);
+    const f32x4 V = *reinterpret_cast<const f32x4*>(&l[q * kPlane + pos4]);
     out[0] = (f32x2){V.x, V.y};
     out[1] = (f32x2){V.z, V.w};
   };
-  float chk = 0.0f;   // sum of everything this lane hands to the accumulators: not finite <=> some partial is not
+  // NaN / inf cannot be represented in the integer accumulators: chk sums what this lane hands over for its OWN tile (the
+  // I side); not finite <=> the launch met a non-finite input.  The I side alone sees every bad input: a vortex with a
+  // non-finite position or strength is a source (J member) of its own tile's diagonal round, where it poisons the I-side
+  // sums of that tile's lanes -- so the J-side partials need no check of their own.
+  float chk = 0.0f;
   const int rot4 = ((lane + 1) & 63) * 4;   // lane l takes over from lane l + 1
+  const int lane32x4 = ((lane + 32) & 63) * 4;
 
   // ---- tile pairs: each unordered pair once, both sides accumulated ------------------------------------------------
   // Round -1 (items of d-chunk 0 only) is the diagonal tile, J = I, which holds the self pairs: the same code, but over
@@ -483,11 +497,20 @@ pair_sym_f32(SymArgs a) {
   auto fetch_tile = [&](const Round& rd) {
     // (an invalid round loads the own tile's addresses: harmless, unused)
     const unsigned Jt = rd.valid ? rd.J : I;
+    if ((Jt + 1) * W <= n) {           // a whole tile (all but the last one): no guards (wave-uniform)
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const unsigned j = Jt * W + lane + 64u * t;
-      pjx[t] = load_or(a.x, j, n, kPadPosF); pjz[t] = load_or(a.z, j, n, kPadPosF); pjg[t] = load_or(a.g, j, n, 0.0f);
-      pjxl[t] = HILO ? load_or(a.xl, j, n, 0.0f) : 0.0f; pjzl[t] = HILO ? load_or(a.zl, j, n, 0.0f) : 0.0f;
+      for (int t = 0; t < T; ++t) {
+        const unsigned j = Jt * W + lane + 64u * t;
+        pjx[t] = a.x[j]; pjz[t] = a.z[j]; pjg[t] = a.g[j];
+        pjxl[t] = HILO ? a.xl[j] : 0.0f; pjzl[t] = HILO ? a.zl[j] : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const unsigned j = Jt * W + lane + 64u * t;
+        pjx[t] = load_or(a.x, j, n, kPadPosF); pjz[t] = load_or(a.z, j, n, kPadPosF); pjg[t] = load_or(a.g, j, n, 0.0f);
+        pjxl[t] = HILO ? load_or(a.xl, j, n, 0.0f) : 0.0f; pjzl[t] = HILO ? load_or(a.zl, j, n, 0.0f) : 0.0f;
+      }
     }
 #pragma unroll
     for (int q = 0; q < NS; ++q) poj[q] = origin_records(((Jt * W) >> kOriginShift) + q);
@@ -522,11 +545,13 @@ pair_sym_f32(SymArgs a) {
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         if (local) refer_targets(oj[q]);
+        // steps k = 32 s + kk: slot (lane + 32 s) % 64 + kk of the plane, no wrap-around (slots 64..95 repeat 0..31)
         for (int k = k_lo; k < k_hi; k += 2) {
+          const int pos0 = ((k & 32) ? lane32x4 : lane * 4) + (k & 31) * 4;
 #pragma unroll
           for (int rr = 0; rr < 2; ++rr) {
             // at step k this lane holds the accumulators of the J vortices whose home lane is (lane + k) % 64
-            const int pos = ((lane + k + rr) & 63) * 4;
+            const int pos = pos0 + 4 * rr;
             f32x2 xj[2], zj[2], gj[2], xjl[2], zjl[2];
             load_plane(lx, q, pos, xj); load_plane(lz, q, pos, zj); load_plane(lg, q, pos, gj);
             if (HILO) { load_plane(lxl, q, pos, xjl); load_plane(lzl, q, pos, zjl); }
@@ -570,8 +595,8 @@ pair_sym_f32(SymArgs a) {
 #pragma unroll
         for (int m = 0; m < H; ++m) {
           const unsigned j0 = J * W + home + 64u * (2 * m), j1 = j0 + 64;
-          if (j0 < n) { fx_add(&a.acc_u[j0], -bu[m].x, fxs); fx_add(&a.acc_w[j0], -bw[m].x, fxs); chk += bu[m].x + bw[m].x; }
-          if (j1 < n) { fx_add(&a.acc_u[j1], -bu[m].y, fxs); fx_add(&a.acc_w[j1], -bw[m].y, fxs); chk += bu[m].y + bw[m].y; }
+          if (j0 < n) { fx_add(&a.acc_u[j0], -bu[m].x, fxs); fx_add(&a.acc_w[j0], -bw[m].x, fxs); }
+          if (j1 < n) { fx_add(&a.acc_u[j1], -bu[m].y, fxs); fx_add(&a.acc_w[j1], -bw[m].y, fxs); }
         }
       }
     } else {
@@ -591,7 +616,7 @@ pair_sym_f32(SymArgs a) {
 #pragma unroll
           for (int q = 0; q < RR; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
           const unsigned j = J * W + lane + 64u * (2 * (c / 4) + (c & 1));
-          if (j < n) { fx_add((c & 2) ? &a.acc_w[j] : &a.acc_u[j], -v, fxs); chk += v; }
+          if (j < n) fx_add((c & 2) ? &a.acc_w[j] : &a.acc_u[j], -v, fxs);
         }
       }
       __syncthreads();     // the slabs are rewritten by the next tile pair
