@@ -421,17 +421,20 @@ pair_sym_f32(SymArgs a) {
   // slots are padding, any finite number serves)
   struct Org { float x0, x1, z0, z1; };      // (x, z) of the even class, of the odd class
   auto scalar = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  // (the loads: same address in every lane; the values become scalars -- `to_scalars` -- only where they are used, so that a
+  // prefetch does not wait for its own loads)
   auto origin_records = [&](unsigned b) -> Org {
     const bool has = local && (b << kOriginShift) < n;
     const unsigned s0 = has ? 2 * b : 0;
     Org o{0.0f, 0.0f, 0.0f, 0.0f};
-    if (has) { o.x0 = scalar(a.cx[s0]); o.x1 = scalar(a.cx[s0 + 1]); o.z0 = scalar(a.cz[s0]); o.z1 = scalar(a.cz[s0 + 1]); }
+    if (has) { o.x0 = a.cx[s0]; o.x1 = a.cx[s0 + 1]; o.z0 = a.cz[s0]; o.z1 = a.cz[s0 + 1]; }
     return o;
   };
+  auto to_scalars = [&](const Org& v) -> Org { return Org{scalar(v.x0), scalar(v.x1), scalar(v.z0), scalar(v.z1)}; };
   const unsigned blk_i = (I * W) >> kOriginShift;
   Org oi[NS];
 #pragma unroll
-  for (int q = 0; q < NS; ++q) oi[q] = origin_records(blk_i + q);
+  for (int q = 0; q < NS; ++q) oi[q] = to_scalars(origin_records(blk_i + q));
   // this lane's own origins (its index parity), per origin block of the tile
   float oix[NS], oiz[NS];
 #pragma unroll
@@ -515,10 +518,12 @@ pair_sym_f32(SymArgs a) {
 #pragma unroll
     for (int q = 0; q < NS; ++q) poj[q] = origin_records(((Jt * W) >> kOriginShift) + q);
   };
+  constexpr bool kPrefetch = R != 0;      // (the mixed-granularity variant has no registers to spare for it)
   const int dd0 = (active && y == 0) ? -1 : 0;
-  fetch_tile(round_of(dd0));
+  if (kPrefetch) fetch_tile(round_of(dd0));
   for (int dd = dd0; dd < per; ++dd) {
     const Round rd = round_of(dd);
+    if (!kPrefetch) fetch_tile(rd);
     const bool diag = rd.diag, valid = rd.valid;
     const unsigned J = rd.J;
     f32x2 bu[H], bw[H];
@@ -526,7 +531,7 @@ pair_sym_f32(SymArgs a) {
     for (int m = 0; m < H; ++m) { bu[m] = (f32x2){0.f, 0.f}; bw[m] = (f32x2){0.f, 0.f}; }
     Org oj[NS];
 #pragma unroll
-    for (int q = 0; q < NS; ++q) oj[q] = poj[q];
+    for (int q = 0; q < NS; ++q) oj[q] = to_scalars(poj[q]);
     if (valid) {
       slab_store<T>(lx, lane * 4, pjx); slab_store<T>(lz, lane * 4, pjz); slab_store<T>(lg, lane * 4, pjg);
       if (HILO) { slab_store<T>(lxl, lane * 4, pjxl); slab_store<T>(lzl, lane * 4, pjzl); }
@@ -535,7 +540,7 @@ pair_sym_f32(SymArgs a) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // the next round's partner tile: loads in flight during this round's rotation loops
-    if (dd + 1 < per) fetch_tile(round_of(dd + 1));
+    if (kPrefetch && dd + 1 < per) fetch_tile(round_of(dd + 1));
     if (valid) {
 
       // Pass q: my T targets against the 4 J vortices per home lane of J's origin block q (J accumulators bu / bw[2 q],
