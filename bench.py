@@ -53,12 +53,13 @@ EXECUTED_FLOP_PER_PAIR = {"direct": 13, "symmetric": 9}   # the symmetric kernel
 PMC_TRAFFIC_CFG3 = {
     "ludvm::pair_f32<2,1024> direct, partial slabs": {"bytes": 2 * 73.2e6 + 72.0e6,
                                                       "source": "profiles/r01_bench_cfg3_direct_pmc_{fetch,write}.csv"},
-    # 2 x FETCH_SIZE 29 453 KB (gfx950 tallies the 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section; the
-    # 16 MB read of finish_sym in the same pass shows the factor; 1.44e6 KB before the XCD-aware item mapping) + WRITE_SIZE
-    # 1.727e7 KB (exact for stores: the 16 MB memset reads 15 625 KB); the write side is the 64-bit integer atomics
-    # (2.93e8 64-B requests, memory-side, mostly Infinity-Cache resident: the accumulators are 16 MB)
-    "ludvm::pair_sym_f32<8> fixed-point accumulation": {"bytes": (2 * 29453.4 + 1.72739e7) * 1024,
-                                                        "source": "profiles/r02_final_bench_cfg3_sym_pmc_{fetch,write}.csv"},
+    # 2 x FETCH_SIZE 29 474 KB (gfx950 tallies the 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section; the
+    # 16 MB read of finish_sym in the same pass shows the factor) + WRITE_SIZE 1.727e7 KB (exact for stores: the 16 MB
+    # memset reads 15 625 KB); the write side is the 64-bit integer atomics (2.93e8 64-B requests, memory-side, mostly
+    # Infinity-Cache resident: the accumulators are 16 MB).  Round 3's kernel (origins per block and index parity, one
+    # pass per origin block of the partner tile), passes taken on the round's final code.
+    "ludvm::pair_sym_f32<8> fixed-point accumulation": {"bytes": (2 * 29474.0 + 1.72739e7) * 1024,
+                                                        "source": "profiles/r03_final_bench_cfg3_sym_pmc_{fetch,write}.csv"},
 }
 V_CORE = 0.065
 DT = 5e-2
