@@ -1,0 +1,97 @@
+"""CPU tier: the host side of the torch-free multi-GPU path (ludvm_amd/comm.py) -- rank discovery from the launcher's
+environment, the file rendezvous that carries the communicator identifier from rank 0 to the other ranks, and
+LibraryGroup's block partition / gather over an engine stand-in.  (The communicator itself -- ludvm_comm_* on RCCL -- is
+exercised in the GPU tier: tests/test_gpu_bench.py::test_library_communicator_one_rank_through_the_c_abi.)"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from ludvm_amd import comm
+
+
+def test_launcher_rank_reads_the_usual_launchers(monkeypatch):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_RANK",
+              "PMI_RANK", "PMI_SIZE", "SLURM_PROCID", "SLURM_NTASKS", "SLURM_LOCALID"):
+        monkeypatch.delenv(k, raising=False)
+    assert comm.launcher_rank() == (0, 1, 0)
+    monkeypatch.setenv("OMPI_COMM_WORLD_RANK", "3")
+    monkeypatch.setenv("OMPI_COMM_WORLD_SIZE", "8")
+    monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", "3")
+    assert comm.launcher_rank() == (3, 8, 3)
+    monkeypatch.setenv("RANK", "5")            # torchrun's variables win
+    monkeypatch.setenv("WORLD_SIZE", "6")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert comm.launcher_rank() == (5, 6, 1)
+
+
+def test_default_rendezvous_is_per_launch(monkeypatch):
+    monkeypatch.delenv("LUDVM_RENDEZVOUS", raising=False)
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    a = comm.default_rendezvous()
+    monkeypatch.setenv("MASTER_PORT", "29501")
+    assert comm.default_rendezvous() != a and str(os.getppid()) in a
+    monkeypatch.setenv("LUDVM_RENDEZVOUS", "/somewhere/else")
+    assert comm.default_rendezvous() == "/somewhere/else"
+
+
+def test_identifier_travels_through_the_file(tmp_path):
+    path = str(tmp_path / "rdv")
+    uid = bytes(range(128))
+    got = {}
+
+    def reader(r):
+        got[r] = comm.exchange_id(r, None, path, timeout=30)
+    threads = [threading.Thread(target=reader, args=(r,)) for r in (1, 2)]
+    for t in threads:
+        t.start()
+    assert comm.exchange_id(0, lambda: uid, path) == uid        # rank 0 publishes (atomically: write + rename)
+    for t in threads:
+        t.join(30)
+    assert got == {1: uid, 2: uid}
+    with pytest.raises(TimeoutError):
+        comm.exchange_id(1, None, str(tmp_path / "nobody_writes_here"), timeout=0.2)
+
+
+class _OneRankEngine:
+    """Stand-in for Engine's communicator calls with a group of one."""
+
+    def __init__(self):
+        self.calls = []
+
+    def comm_unique_id(self):
+        return bytes(128)
+
+    def comm_init(self, rank, world, uid, min_vortices=0):
+        self.calls.append(("init", rank, world, len(uid), min_vortices))
+
+    def comm_destroy(self):
+        self.calls.append(("destroy",))
+
+    def comm_allgather(self, local):
+        return np.ascontiguousarray(local)[None].copy()
+
+
+def test_library_group_over_an_engine_stand_in(tmp_path):
+    eng = _OneRankEngine()
+    g = comm.LibraryGroup(eng, rank=0, world=1, rendezvous=str(tmp_path / "rdv"), min_wake=777)
+    assert eng.calls == [("init", 0, 1, 128, 777)] and not os.path.exists(str(tmp_path / "rdv"))   # rank 0 removes the file
+    rows = np.arange(35.0).reshape(7, 5)
+    assert np.array_equal(g.gather_blocks(rows, 7), rows) and g.block(7) == (0, 7, 7)
+    g.barrier()
+    assert g.attach(eng, 100) is False            # a one-rank group shards nothing
+    with pytest.raises(ValueError):
+        g.attach(_OneRankEngine(), 100)           # bound to its engine
+    g.close()
+    assert eng.calls[-1] == ("destroy",)
+    # the block partition of a larger group (as ShardGroup: equal blocks, the last ones may be short or empty)
+    g3 = comm.LibraryGroup.__new__(comm.LibraryGroup)
+    g3.world = 3
+    covered = []
+    for r in range(3):
+        g3.rank = r
+        lo, hi, per = g3.block(8)
+        assert per == 3
+        covered += list(range(lo, hi))
+    assert covered == list(range(8))

@@ -69,3 +69,31 @@ def test_distributed_needs_a_process_group():
     from ludvm_amd import LUDVM
     with pytest.raises(RuntimeError):
         LUDVM(**dict(CONFIG1, tf=0.2), verbose=False, engine=FakeEngine(), distributed=True)
+
+
+def _ckpt_worker(rank, world, port, ck):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_engine import FakeEngine
+        from ludvm_amd import LUDVM
+        from ludvm_amd.distributed import ShardGroup
+        kw = dict(CONFIG1, tf=3)
+        ref = LUDVM(**kw, verbose=False, engine=FakeEngine(), precision="f64")
+        # every rank runs the whole loop and reaches the checkpoint steps together: rank 0 alone writes the file (the ranks
+        # would race on the temporary file), the others wait at the barrier behind it
+        sim = LUDVM(**kw, verbose=False, engine=FakeEngine(), precision="f64", distributed=ShardGroup(), checkpoint_every=20,
+                    checkpoint_path=ck)
+        assert np.array_equal(sim.Cl, ref.Cl)
+        dist.barrier()
+        assert os.path.exists(ck) and not os.path.exists(ck + ".tmp.npz")
+        # ... and a shared run resumes shared, from the same file on every rank
+        res = LUDVM.resume(ck, engine=FakeEngine(), verbose=False, distributed=ShardGroup())
+        assert res._shard is not None and res._shard.world == world
+        assert np.array_equal(res.Cl, ref.Cl) and np.array_equal(res.LEV_shed, ref.LEV_shed)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shared_run_writes_its_checkpoint_once_and_resumes_shared(tmp_path):
+    mp.spawn(_ckpt_worker, args=(2, _free_port(), str(tmp_path / "ck.npz")), nprocs=2, join=True)
