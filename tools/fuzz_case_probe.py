@@ -16,6 +16,10 @@ KW = dict(t0=0, tf=2.58, dt=0.02, chord=1, rho=1.225, Uinf=1, Npoints=121, Ncoef
           h_max=1.3773564435731436, method="Faure")
 
 
+if os.environ.get("FUZZ_CASE_KW"):        # another configuration: the "kw" object of a fuzz_march.py failure line (JSON)
+    KW = dict(t0=0, chord=1, rho=1.225, Uinf=1, Naca="0012", **json.loads(os.environ["FUZZ_CASE_KW"]))
+
+
 def run(precision, march, threshold):
     from ludvm_amd import LUDVM, Engine
     eng = Engine(0)
