@@ -291,6 +291,11 @@ int ludvm_wake_step(ludvm_ctx* ctx, const double* new_x, const double* new_z, co
  *   [3] a LEV was shed in the previous step          [4] LESPcrit with its current sign (:802-805)
  *   [5] sum Gamma_TEV   [6] sum Gamma_LEV            [7..10] tev_x, lev_x, tev_z, lev_z of the coming step
  *   [11] out: vortices shed by the last step (1 or 2)
+ *   [12..14] in: the wake sizes after the three anchor steps max(64 (floor(first_step / 64) - 2 + q) - 1, 0), q = 0, 1, 2
+ *            (the caller knows the wake size after every step it has run; step 0 = the initial wake).  Each step's launch
+ *            geometry is derived from the wake size two 64-step periods back -- read from the device inside a call, given
+ *            here across calls -- so a run's bits do not depend on where its calls begin.  0 = not given: the bounds
+ *            restart at this call (results then depend on the chunking, to fp32 rounding, near the tile thresholds)
  *   [12..15] out: x[size-2], x[size-1], z[size-2], z[size-1] after the last roll-up
  *   [16..16+ncoef) Fourier coefficients of the previous step.
  * rows (out): count rows of 12 + 2 ncoef + 2 npan doubles:
@@ -303,8 +308,9 @@ int ludvm_wake_step(ludvm_ctx* ctx, const double* new_x, const double* new_z, co
  * Synchronous: returns when the last step has finished.  `precision` selects the roll-up arithmetic as in
  * ludvm_wake_advect; the solve is float64.  From the symmetric-kernel threshold on, a step's chord sums and solve run on
  * a second stream beside the symmetric kernel (environment LUDVM_MARCH_OVERLAP=0 keeps every step serial).  The launch
- * geometry of every step is a function of the arguments and of the simulation itself (never of host timing), and every
- * sum is order-independent or done in a fixed order: two runs of the same call return the same bits. */
+ * geometry of every step is a function of the step number and of the simulation itself (never of host timing, nor -- with
+ * state[12..14] given -- of where the calls begin), and every sum is order-independent or done in a fixed order: two runs
+ * return the same bits, however they are cut into calls. */
 int ludvm_march_setup(ludvm_ctx* ctx, int npan, int ncoef, const double* scalars, const double* tables, const double* kin,
                       size_t kin_rows);
 int ludvm_march_run(ludvm_ctx* ctx, long long first_step, long long count, int precision, double* state, double* rows,

@@ -1731,11 +1731,52 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   // finished, and always the same one.  All bounds are therefore functions of the call's arguments and of the
   // simulation itself, never of how far the host happens to run ahead: two runs repeat bit for bit, direct or
   // symmetric kernel (whose fixed-point sums do not depend on the order of their atomics).
-  bool ev_used[2] = {false, false};
-  long long ev_step[2] = {0, 0};          // the last step enqueued before the slot's event was recorded
+  //
+  // Round 3: the bounds no longer restart at the call.  Step s is sized from the ANCHOR step A(s) = 64 (floor(s / 64) - 2) - 1
+  // (the last step of the sync period two periods back; step 0 for the first 128 steps of a run): an anchor inside this
+  // call is read from the ring as above, an anchor before it is given by the caller in state[12..14] (the class knows
+  // the wake size after every step it has run).  Tile size, waves per item, serial or overlapped step and the direct
+  // kernels' source splits are then functions of the step number and of the simulation alone: the same bits whatever
+  // the chunking (march_chunk, checkpoint_every, dense or sparse history) -- and a resumed run continues bit for bit.
+  // A caller that leaves state[12..14] at 0 gets the old behaviour (bounds restart at the call's exact wake size).
   constexpr long long kSyncEvery = 64;
-  long long p_step = first_step - 1, p_n = n0;   // a finished step and the wake size after it
-  long long n_before = n0;          // upper bound of the wake size before the current step's solve
+  auto anchor_of = [](long long s) { return std::max<long long>(kSyncEvery * (s / kSyncEvery - 2) - 1, 0); };
+  long long ev_anchor[2] = {-1, -1};      // the last step enqueued before the slot's event was recorded
+  const long long k0 = first_step / kSyncEvery - 2;
+  long long given_step[3], given_n[3];
+  bool anchors_given = true;
+  for (int q = 0; q < 3; ++q) {
+    given_step[q] = std::max<long long>(kSyncEvery * (k0 + q) - 1, 0);
+    given_n[q] = (long long)state[12 + q];
+    if (given_n[q] <= 0) anchors_given = false;
+  }
+  long long cur_a = -1, cur_n = 0;        // the anchor in force and the wake size after it
+  // wake size after step s's solve is at most n_after(anchor) + 2 (s - anchor)
+  auto set_anchor = [&](long long sstep) -> int {
+    if (!anchors_given) {
+      // (no history from the caller: anchors before the call are replaced by the call's own start)
+      const long long a = anchor_of(sstep);
+      if (a < first_step) { cur_a = first_step - 1; cur_n = n0; return LUDVM_OK; }
+    }
+    const long long a = anchor_of(sstep);
+    if (a == cur_a) return LUDVM_OK;
+    if (a < first_step) {
+      for (int q = 0; q < 3; ++q)
+        if (given_step[q] == a) { cur_a = a; cur_n = given_n[q]; return LUDVM_OK; }
+      return fail(c, LUDVM_E_STATE, "march: anchor step not among the caller's");
+    }
+    const int slot = (int)(((a + 1) / kSyncEvery) & 1);
+    if (ev_anchor[slot] != a) return fail(c, LUDVM_E_STATE, "march: no event for the anchor step");
+    HIPCHK(c, hipEventSynchronize(c->march_ev[slot]));
+    const unsigned long long w = __atomic_load_n(c->progress + (a % kProgressRing), __ATOMIC_RELAXED);
+    if ((long long)(w >> 32) != a) return fail(c, LUDVM_E_STATE, "march: progress ring out of step");
+    cur_a = a;
+    cur_n = (long long)(w & 0xffffffffULL);
+    return LUDVM_OK;
+  };
+  CHK(set_anchor(first_step - 1 > 0 ? first_step - 1 : 0));
+  long long prev_ub = cur_n + 2 * (std::max<long long>(first_step - 1, 0) - cur_a);   // bound after step first_step - 1
+  if (prev_ub < n0) return fail(c, LUDVM_E_ARG, "march: state[12..14] (wake sizes after the anchor steps) contradict state[0]");
   bool overlapped = false;          // the accumulators have been zeroed for the overlapped steps
   bool fork_signalled = false;      // the previous step's finisher already signals ev_fork
   static const bool ext_fork = [] { const char* e = std::getenv("LUDVM_MARCH_EXT_EVENTS"); return !(e && e[0] == '0'); }();
@@ -1747,26 +1788,18 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   const long long thr = sym_threshold(c, overlap_ok);      // serial symmetric steps pay from the usual size only
   for (long long s = first_step; s < first_step + count; ++s) {
     const long long rel = s - first_step;
-    if (rel % kSyncEvery == 0) {
-      const int slot = (int)((rel / kSyncEvery) & 1);
-      if (ev_used[slot]) {
-        HIPCHK(c, hipEventSynchronize(c->march_ev[slot]));
-        const long long q = ev_step[slot];
-        if (q >= first_step) {
-          const unsigned long long w = __atomic_load_n(c->progress + (q % kProgressRing), __ATOMIC_RELAXED);
-          if ((long long)(w >> 32) != q) return fail(c, LUDVM_E_STATE, "march: progress ring out of step");
-          p_step = q;
-          p_n = (long long)(w & 0xffffffffULL);
-        }
-      }
+    CHK(set_anchor(s));       // (may wait for, and read, the event slot that is re-used just below)
+    if (s % kSyncEvery == 0 && s - 1 >= first_step) {
+      // everything up to step s - 1 is enqueued: this event's completion makes s - 1 an anchor that can be read
+      const int slot = (int)((s / kSyncEvery) & 1);
       HIPCHK(c, hipEventRecord(c->march_ev[slot], c->stream));
-      ev_used[slot] = true;
-      ev_step[slot] = s - 1;
+      ev_anchor[slot] = s - 1;
     }
-    // wake size after this step's solve: at most two vortices per step since the last known size
-    const long long n_ub = p_n + 2 * (s - p_step);
-    const long long n_lo = p_n + (s - 1 - p_step);      // ... and before it: at least one per step
-    n_before = std::min<long long>(n_before, n_ub);
+    // wake size after this step's solve: at most two vortices per step since the anchor
+    const long long n_ub = cur_n + 2 * (s - cur_a);
+    const long long n_lo = cur_n + (s - 1 - cur_a);      // ... and before it: at least one per step
+    long long n_before = std::min<long long>(prev_ub, n_ub);     // upper bound of the wake size before this step's solve
+    prev_ub = n_ub;
     const bool symreg = precision != LUDVM_PREC_F64 && use_symmetric(c, n_ub, vc4, overlap_ok);
     // overlapped steps need an old wake that already fills the symmetric kernel
     const bool fork = symreg && overlap_ok && n_lo >= thr;
@@ -1848,7 +1881,6 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
       HIPCHK(c, hipGetLastError());
     }
     if (!fork) fork_signalled = false;
-    n_before = n_ub;
   }
   // results: per-step rows, final state, the two newest wake vortices
   HIPCHK(c, hipMemcpyAsync(rows, drows, (size_t)count * row_doubles * 8, hipMemcpyDeviceToHost, c->stream));

@@ -683,6 +683,12 @@ class LUDVM:
         n_wake = nf + itev + ilev
         st = np.zeros(16 + nc)
         st[:11] = [n_wake, itev, ilev, float(LEV_shed[i - 1] != -1), lesp_crit, sum_tev, sum_lev] + list(place)
+        # wake sizes after the three anchor steps before this call (ludvm_march_run, state[12..14]): the launch geometry of
+        # every step then follows from the step number and the run itself, not from where the stretches begin
+        shed_before = np.cumsum(LEV_shed[:i] != -1)            # LEVs shed in steps 0 .. q (step 0 sheds none)
+        for q in range(3):
+            a = max(64 * (i // 64 - 2 + q) - 1, 0)
+            st[12 + q] = nf + a + (shed_before[a] if a < i else 0)
         st[16:] = self.fourier[i - 1, 0, :]
         if record:
             R, hist = self.engine.march_run(i, cnt, prec_code, st, hist_nmax=n_wake + 2 * cnt)
