@@ -189,13 +189,22 @@ def main():
         collective = None
     else:
         coll = args.collectives if args.collectives != "auto" else ("library" if (backend == "nccl" and world > 1) else "torch")
+        coll_note = None
         if coll == "library":
             # the engine's own communicator: rank 0's identifier goes round through torch (any channel would do); its
-            # sharding of resident-wake roll-ups is switched off (min_vortices), ShardedWake hands out the tile blocks itself
-            uid = [eng.comm_unique_id() if rank == 0 else None]
+            # sharding of resident-wake roll-ups is switched off (min_vortices), ShardedWake hands out the tile blocks itself.
+            # If librccl cannot be opened (every rank fails alike, before any collective), torch's collectives take over.
+            try:
+                uid = [eng.comm_unique_id() if rank == 0 else None]
+            except Exception as e:       # noqa: BLE001
+                uid = [None]
+                coll_note = f"library communicator unavailable on rank 0 ({e}); torch.distributed collectives used"
             if world > 1:
                 dist.broadcast_object_list(uid, src=0, device=device if backend == "nccl" else None)
-            eng.comm_init(rank, world, uid[0], min_vortices=1 << 62)
+            if uid[0] is None:
+                coll = "torch"
+            else:
+                eng.comm_init(rank, world, uid[0], min_vortices=1 << 62)
         wake = ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric, collectives=coll)
         step = wake.step
         pairs_per_step = wake.pairs_per_step
