@@ -595,6 +595,11 @@ pair_sym_f32(SymArgs a) {
     // 2m, 1: u of 2m+1, 2: w of 2m, 3: w of 2m+1}
     const int home = (lane + k_hi) & 63;
     if (diag) continue;        // (no barrier in this round)
+#ifdef LUDVM_SYM_BARRIER_PROBE
+    // measurement build only: what two workgroup barriers per round would cost the barrier-free single-wave items (the
+    // price of sharing a partner tile's J-side sums among the four waves of a workgroup)
+    if (!RED) { __syncthreads(); __syncthreads(); }
+#endif
     if (!RED || !shared) {
       if (valid) {
 #pragma unroll
