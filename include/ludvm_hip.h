@@ -187,6 +187,9 @@ int ludvm_advect_dev_f32(ludvm_ctx* ctx, const float* d_xs, const float* d_zs, c
  *     target t_first + i) into the Euler step x_out[i] = x[t_first + i] + dt * u, z_out likewise
  *     (LUDVM.py:1108-1109); NaN when *d_bad != 0, as the reference's sum over a NaN source would be. */
 #define LUDVM_SYM_TILE 512
+#define LUDVM_SYM_OWNER_ALIGN 4   /* an owner's tile block starts and ends on multiples of this many tiles (or ends with the
+                                     ring): large launches add the partial sums of four consecutive tiles' wavefronts in fp32
+                                     before they are converted to fixed point, so such a quad must not be cut between owners */
 #define LUDVM_SYM_SCALE_BYTES 32
 int ludvm_sym_scale_dev_f32(ludvm_ctx* ctx, const float* d_g, size_t n, float vcore, void* d_scale);
 int ludvm_sym_accumulate_dev_f32(ludvm_ctx* ctx, const float* d_x, const float* d_z, const float* d_g, size_t n,

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libludvm_hip.so")
 OK, E_ARG, E_HIP, E_NOMEM, E_NODEVICE, E_STATE, E_COMM = range(7)
 PREC_F32, PREC_F32X2, PREC_F64 = 0, 1, 2
 SYM_TILE = 512
+SYM_OWNER_ALIGN = 4      # tiles: an owner's block of the tile ring is a whole number of these quads (include/ludvm_hip.h)
 ABI_VERSION = 3
 COMM_ID_BYTES = 128
 SYM_SCALE_BYTES = 32

@@ -49,6 +49,8 @@ struct ludvm_ctx {
   int grid_kernel = 2;                       // flow-field grids (LUDVM_GRID_KERNEL): 1 = 4 points of a row per lane; 2 = patch,
                                              // 4 x 4 from 2^20 grid points and 2 x 4 below; 3 / 4 = always the 2 x 4 / 4 x 4 patch
   long long small_tile_max = 14000;          // direct fp32 launches with at most this many sources use 256-source tiles
+  bool sym_quad = true;                      // large symmetric launches: four I tiles per workgroup share each partner tile (LUDVM_SYM_QUAD=0: off)
+  long long sym_quad_min_tiles = 1024;       //   ... from this many 512-vortex tiles on (LUDVM_SYM_QUAD_MIN_TILES)
   bool few_packed = true;                    // fp64 launches with <= 128 targets: several source splits per workgroup (LUDVM_FEW_PACKED=0: off)
   long long small_tile_max_f64 = 12000;      // fp64 launches with at most this many sources use 128-source tiles
                                              // (roll-up step 52 -> 26 us at 2400 vortices, 87 -> 72 at 8192 [MI355X])
@@ -503,6 +505,27 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   }
   if (!n_dev && i_count == 0) return LUDVM_OK;     // an owner without tiles (fewer tiles than owners)
   blocks = std::max<long long>(blocks, 1);         // (n_dev: the share is decided on the device; surplus waves leave)
+  // Large launches: the quad variant (four I tiles of a workgroup share each partner tile: a quarter of the atomics) plus a
+  // launch of the plain kernel restricted to the diagonal tiles.  The choice is a function of the vortex count (the march's
+  // bound) alone, so every owner of a sharded ring makes the same one; owners must own whole quads.
+  const bool quad = c->sym_quad && T == 8 && !hilo && gm.rsplit == 1 && c->tune_sym_rsplit == 0 && gm.ntiles >= c->sym_quad_min_tiles;
+  if (quad) {
+    if (i_first % 4 != 0 || (i_count % 4 != 0 && i_first + i_count != gm.ntiles))
+      return fail(c, LUDVM_E_ARG, "symmetric kernel, quad variant: an owner's tile block must start and end on multiples of 4 tiles");
+    TimedLaunch tq{};
+    bool act = false;
+    CHK(timed_begin(c, tq, act));
+    SymArgs d = a;
+    d.diag_only = 1;
+    const long long dblocks = std::max<long long>(1, sym_blocks(n_dev ? gm.ntiles : i_count, 1, 1));
+    hipLaunchKernelGGL((pair_sym_f32<8, false, 1>), dim3((unsigned)dblocks), dim3(kBlock), 0, c->stream, d);
+    const QuadGeom qg = quad_geometry<long long>(n, 8, a.tune_split);
+    long long qblocks = quad_blocks(n_dev ? gm.ntiles : i_count, qg.ysplit);
+    hipLaunchKernelGGL((pair_sym_quad_f32<8>), dim3((unsigned)std::max<long long>(qblocks, 1)), dim3(kBlock), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    CHK(timed_end(c, tq, act));
+    return LUDVM_OK;
+  }
   TimedLaunch t{};
   bool active = false;
   CHK(timed_begin(c, t, active));
@@ -604,10 +627,12 @@ int reduce_accumulators(ludvm_ctx* c, long long* acc, long long nt_pad) {
   return LUDVM_OK;
 }
 
-// tile block of a shard owner
+// tile block of a shard owner (whole quads of 4 tiles: pair_sym_kernels.hpp, shard_block)
 void shard_tiles(const ludvm_ctx* c, long long ntiles, long long* first, long long* count) {
-  *first = ntiles * c->shard_rank / c->shard_world;
-  *count = ntiles * (c->shard_rank + 1) / c->shard_world - *first;
+  unsigned long long f, cnt;
+  shard_block((unsigned long long)ntiles, c->shard_rank, c->shard_world, &f, &cnt);
+  *first = (long long)f;
+  *count = (long long)cnt;
 }
 
 SymScale* ctx_scale(ludvm_ctx* c) { return static_cast<SymScale*>(c->symsc.p); }
@@ -751,6 +776,8 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
     c->grid_kernel = k == "row" || k == "1" ? 1 : (k == "patch2" ? 3 : (k == "patch4" ? 4 : 2));
   }
   if (const char* fp = std::getenv("LUDVM_FEW_PACKED")) c->few_packed = !(fp[0] == '0');
+  if (const char* sq = std::getenv("LUDVM_SYM_QUAD")) c->sym_quad = !(sq[0] == '0');
+  if (const char* sq = std::getenv("LUDVM_SYM_QUAD_MIN_TILES")) c->sym_quad_min_tiles = std::max<long long>(16, std::atoll(sq));
   if (const char* ti = std::getenv("LUDVM_SYM_TAIL_ITEMS")) c->sym_tail_items = std::max<long long>(0, std::atoll(ti));
   if (const char* mx = std::getenv("LUDVM_SYM_MIXED")) {        // 1: mixed granularity within a launch (measured: does not pay)
     if (mx[0] == '1') c->tune_sym_rsplit = -1;

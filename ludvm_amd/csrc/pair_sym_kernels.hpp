@@ -53,6 +53,7 @@ struct SymArgs {
   int rsplit;            // 1, 2 or 4: the 64 rotation steps of a tile pair are shared by this many waves; 0: mixed --
   int ytail;             //   the items of the last `ytail` d-chunks by 4 waves, the others by one (sym_geometry)
   long long tail_items;  //   (how many single-wave items' worth of work that fine-grained end should hold)
+  int diag_only;         // != 0: only the diagonal tiles (round -1 of the d-chunk-0 items): the quad variant's companion launch
   int tune_split, tune_rsplit;   // ludvm_set_tuning / ludvm_set_sym_tuning overrides (0 = heuristics), for n_dev launches
   long long* acc_u; long long* acc_w;   // raw fixed-point sums: u = acc_u / (scale 2 pi), w = -acc_w / (scale 2 pi)
   const SymScale* scale;
@@ -104,6 +105,20 @@ __host__ __device__ inline SymBlocks sym_blocks_xcd(long long i_count, long long
 }
 __host__ __device__ inline long long sym_blocks(long long i_count, long long ysplit, int rsplit, long long ytail = 0) {
   return kXcds * sym_blocks_xcd(i_count, ysplit, rsplit, ytail).total;
+}
+
+// Tile block of owner `rank` of `world` on a ring of ntiles tiles: whole quads of 4 consecutive tiles (the quad variant of
+// the kernel adds the partial sums of a quad's four waves in fp32 before they are converted, so a quad must not be cut
+// between two owners; the last block ends with the ring)
+__host__ __device__ inline void shard_block(unsigned long long ntiles, int rank, int world, unsigned long long* first,
+                                            unsigned long long* count) {
+  const unsigned long long quads = (ntiles + 3) / 4;
+  unsigned long long lo = 4 * (quads * (unsigned long long)rank / (unsigned long long)world);
+  unsigned long long hi = 4 * (quads * (unsigned long long)(rank + 1) / (unsigned long long)world);
+  if (lo > ntiles) lo = ntiles;
+  if (hi > ntiles) hi = ntiles;
+  *first = lo;
+  *count = hi - lo;
 }
 
 // (I: long long on the host, unsigned on the device -- the kernel's prologue runs once per wave and a 64-bit division
@@ -299,7 +314,7 @@ pair_sym_f32(SymArgs a) {
   // 32 rotation steps only -- needs two 32-bit divisions instead of a dozen 64-bit ones
   unsigned n = (unsigned)a.n, ntiles = (unsigned)a.ntiles, dmax = (unsigned)a.dmax, i_first = (unsigned)a.i_first,
            i_count = (unsigned)a.i_count;
-  int ysplit = a.ysplit, ytail = a.ytail;
+  int ysplit = a.diag_only ? 1 : a.ysplit, ytail = a.ytail;
   if (a.n_dev) {
     // (the instantiation -- tile and waves-per-item rule -- is what the host chose from its bound on n)
     n = (unsigned)*a.n_dev;
@@ -309,9 +324,12 @@ pair_sym_f32(SymArgs a) {
     i_first = 0;
     i_count = ntiles;
     if (a.shard_world > 1) {
-      i_first = (unsigned)((unsigned long long)ntiles * a.shard_rank / a.shard_world);
-      i_count = (unsigned)((unsigned long long)ntiles * (a.shard_rank + 1) / a.shard_world) - i_first;
+      unsigned long long f, cnt;
+      shard_block(ntiles, a.shard_rank, a.shard_world, &f, &cnt);
+      i_first = (unsigned)f;
+      i_count = (unsigned)cnt;
     }
+    if (a.diag_only) ysplit = 1;
   }
 #ifdef LUDVM_WAVE_TRACE
   const unsigned long long trace_t0 = wall_clock64();
@@ -373,7 +391,7 @@ pair_sym_f32(SymArgs a) {
 
   const bool even = (ntiles % 2 == 0) && ntiles > 1;
   const int dtot = (int)dmax + (even ? 1 : 0);
-  const int per = (int)(((unsigned)dtot + (unsigned)ysplit - 1) / (unsigned)ysplit);
+  const int per = a.diag_only ? 0 : (int)(((unsigned)dtot + (unsigned)ysplit - 1) / (unsigned)ysplit);
   const int d_lo = 1 + y * per;
   int d_hi = d_lo + per;  // exclusive
   if (d_hi > dtot + 1) d_hi = dtot + 1;
@@ -667,6 +685,280 @@ pair_sym_f32(SymArgs a) {
     g_wave_trace[2 * wid + 1] = wall_clock64();
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Quad variant (round 3; large launches): the four waves of a workgroup hold four CONSECUTIVE I tiles I0 .. I0 + 3 and
+// meet the SAME partner tile J in every round (wave w at ring offset d_w = D - w, D = J - I0).  The partner tile is staged
+// once per workgroup (each wave loads a quarter of it), and the four waves' J-side partial sums are added through LDS in
+// wave order before ONE fixed-point atomic per J vortex and component leaves the workgroup: a quarter of the atomics of
+// the single-wave kernel (whose every tile pair sends its own), i.e. of the launch's memory-side write traffic, for two
+// workgroup barriers per round (measured cost of those, by themselves: 0.1-0.25 % at N = 1e6).  Wave w misses the offsets
+// D - w outside 1 .. dtot at the two ends of the D range (three partly empty rounds per quad and launch), so the variant
+// is used from ~1000 tiles up, where that is < 0.5 % of a quad's rounds.  The diagonal tiles (the self pairs) are left
+// to a launch of pair_sym_f32 restricted to them (SymArgs::diag_only).  Owners of a sharded ring must own whole quads
+// (blocks of 4 tiles): the fp32 sum of four partials is not the integer sum of their conversions.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr unsigned kQuad = 4;
+struct QuadGeom { unsigned ntiles, dmax, dtot, Dtot; int ysplit, per; };
+template <typename I>
+__host__ __device__ inline QuadGeom quad_geometry(I n, int T, int tune_split) {
+  QuadGeom g;
+  const I W = (I)(64 * T);
+  const I nt = (n + W - 1) / W;
+  g.ntiles = (unsigned)nt;
+  g.dmax = nt > 0 ? (unsigned)((nt - 1) / 2) : 0;
+  g.dtot = g.dmax + ((nt % 2 == 0 && nt > 1) ? 1u : 0u);
+  g.Dtot = g.dtot + (kQuad - 1);
+  unsigned ys = tune_split > 0 ? (unsigned)tune_split : (unsigned)kSymMaxSplit;
+  if (ys > (unsigned)kSymMaxSplit) ys = (unsigned)kSymMaxSplit;
+  if (ys > g.Dtot) ys = g.Dtot;
+  if (ys < 1) ys = 1;
+  g.ysplit = (int)ys;
+  g.per = (int)((g.Dtot + ys - 1) / ys);
+  return g;
+}
+// workgroups of a quad launch over I tiles [i_first, i_first + i_count) (i_first a multiple of 4): one per (quad, d-chunk),
+// the same number for each XCD
+__host__ __device__ inline long long quad_blocks(long long i_count, int ysplit) {
+  const long long quads = (i_count + kQuad - 1) / kQuad, per_xcd = (quads + kXcds - 1) / kXcds;
+  return kXcds * per_xcd * ysplit;
+}
+
+template <int T>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LUDVM_SYM_OCC8)))
+pair_sym_quad_f32(SymArgs a) {
+  static_assert(T == 8, "the quad variant is built for the 512-vortex tile");
+  constexpr int H = T / 2, NS = T / 4;
+  constexpr unsigned W = 64u * T;
+  constexpr int kWaves = kBlock / 64;
+  static_assert(kWaves == (int)kQuad, "one I tile per wave");
+  __shared__ __attribute__((aligned(16))) float slab[3][(T / 4) * kPlane];     // the partner tile: x, z, Gamma
+  __shared__ __attribute__((aligned(16))) float ex[kWaves][2 * T * 64];        // the waves' J-side partial sums
+  __shared__ __attribute__((aligned(16))) float ioff[kWaves][2][64 * T];       // own offsets (local origins)
+
+  unsigned n = (unsigned)a.n, i_first = (unsigned)a.i_first, i_count = (unsigned)a.i_count;
+  if (a.n_dev) {
+    n = (unsigned)*a.n_dev;
+    const unsigned nt = (n + W - 1) / W;
+    i_first = 0;
+    i_count = nt;
+    if (a.shard_world > 1) {       // owners own whole quads
+      unsigned long long f, cnt;
+      shard_block(nt, a.shard_rank, a.shard_world, &f, &cnt);
+      i_first = (unsigned)f;
+      i_count = (unsigned)cnt;
+    }
+  }
+  const QuadGeom gm = quad_geometry<unsigned>(n, T, a.tune_split);
+  const unsigned ntiles = gm.ntiles, dmax = gm.dmax;
+  const int dtot = (int)gm.dtot, per = gm.per;
+  const bool even = (ntiles % 2 == 0) && ntiles > 1;
+
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // XCD-aware placement over quads (as pair_sym_f32 over tiles): one workgroup per (quad, d-chunk)
+  const unsigned xcd = blockIdx.x % (unsigned)kXcds, qb = blockIdx.x / (unsigned)kXcds;
+  const unsigned quads = (i_count + kQuad - 1) / kQuad;
+  const unsigned x_lo = quads * xcd / (unsigned)kXcds, x_n = quads * (xcd + 1) / (unsigned)kXcds - x_lo;
+  if (qb >= x_n * (unsigned)gm.ysplit) return;                 // (the whole workgroup)
+  const unsigned yq = qb / x_n;
+  const unsigned I0 = i_first + kQuad * (x_lo + (qb - yq * x_n));
+  const unsigned I = I0 + (unsigned)wv;
+  const bool mine = I < i_first + i_count && I < ntiles;       // this wave's tile exists and is this owner's
+  const int D_lo = 1 + (int)yq * per;
+  int D_hi = D_lo + per;
+  if (D_hi > (int)gm.Dtot + 1) D_hi = (int)gm.Dtot + 1;
+
+  float* const lx = slab[0];
+  float* const lz = slab[1];
+  float* const lg = slab[2];
+
+  // ---- my targets (as pair_sym_f32) ----------------------------------------------------------------------------------
+  f32x2 gp[H], au[T], aw[T];
+  f32x2 xq[2][H], zq[2][H];
+  {
+    float x0[T], z0[T], g0[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const unsigned i = I * W + lane + 64u * t;
+      const unsigned nl = mine ? n : 0u;
+      x0[t] = load_or(a.x, i, nl, kPadPosF); z0[t] = load_or(a.z, i, nl, kPadPosF); g0[t] = load_or(a.g, i, nl, 0.0f);
+      au[t] = (f32x2){0.f, 0.f}; aw[t] = (f32x2){0.f, 0.f};
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      gp[h] = (f32x2){g0[2 * h], g0[2 * h + 1]};
+      xq[0][h] = (f32x2){x0[2 * h], x0[2 * h + 1]}; xq[1][h] = xq[0][h];
+      zq[0][h] = (f32x2){z0[2 * h], z0[2 * h + 1]}; zq[1][h] = zq[0][h];
+    }
+    slab_store<T, 256>(ioff[wv][0], lane * 4, x0); slab_store<T, 256>(ioff[wv][1], lane * 4, z0);
+  }
+  const f32x2 vc4 = {a.vc4, a.vc4};
+  const float fxs = a.scale->scale;
+  const bool local = a.cx != nullptr;
+  const bool pl = (lane & 1) != 0;
+  struct Org { float x0, x1, z0, z1; };
+  auto scalar = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  auto origin_records = [&](unsigned b) -> Org {
+    const bool has = local && (b << kOriginShift) < n;
+    const unsigned s0 = has ? 2 * b : 0;
+    Org o{0.0f, 0.0f, 0.0f, 0.0f};
+    if (has) { o.x0 = a.cx[s0]; o.x1 = a.cx[s0 + 1]; o.z0 = a.cz[s0]; o.z1 = a.cz[s0 + 1]; }
+    return o;
+  };
+  auto to_scalars = [&](const Org& v) -> Org { return Org{scalar(v.x0), scalar(v.x1), scalar(v.z0), scalar(v.z1)}; };
+  float oix[NS], oiz[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const Org o = to_scalars(origin_records(mine ? ((I * W) >> kOriginShift) + q : 0xffffffffu >> kOriginShift));
+    oix[q] = pl ? o.x1 : o.x0; oiz[q] = pl ? o.z1 : o.z0;
+  }
+  auto refer_targets = [&](const Org oj) {
+    f32x2 xo[H], zo[H];
+    slab_load<T, 256>(ioff[wv][0], lane * 4, xo);
+    slab_load<T, 256>(ioff[wv][1], lane * 4, zo);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const bool odd = pl != (rr != 0);
+      const float jx = odd ? oj.x1 : oj.x0, jz = odd ? oj.z1 : oj.z0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float ddx = oix[h / 2] - jx, ddz = oiz[h / 2] - jz;
+        xq[rr][h] = xo[h] + (f32x2){ddx, ddx};
+        zq[rr][h] = zo[h] + (f32x2){ddz, ddz};
+      }
+    }
+  };
+  auto load_plane = [&](const float* l, int q, int pos4, f32x2 (&out)[2]) {
+    const f32x4 V = *reinterpret_cast<const f32x4*>(&l[q * kPlane + pos4]);
+    out[0] = (f32x2){V.x, V.y};
+    out[1] = (f32x2){V.z, V.w};
+  };
+  const int lane32x4 = ((lane + 32) & 63) * 4;
+  float chk = 0.0f;
+
+  // ---- this wave's quarter of a partner tile: slices t = 2 wv, 2 wv + 1 of every lane, fetched one round ahead ---------------
+  float pjx[2], pjz[2], pjg[2];
+  Org poj[NS];
+  auto partner_of = [&](int dd) -> unsigned {
+    unsigned J = I0 + (unsigned)(D_lo + dd);
+    if (J >= ntiles) J -= ntiles;
+    return J;
+  };
+  auto fetch_quarter = [&](int dd) {
+    const unsigned J = (D_lo + dd < D_hi) ? partner_of(dd) : I0;      // (beyond the chunk: any valid tile, unused)
+    const unsigned Jc = J < ntiles ? J : 0u;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const unsigned j = Jc * W + lane + 64u * (2 * wv + s);
+      pjx[s] = load_or(a.x, j, n, kPadPosF); pjz[s] = load_or(a.z, j, n, kPadPosF); pjg[s] = load_or(a.g, j, n, 0.0f);
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) poj[q] = origin_records(((Jc * W) >> kOriginShift) + q);
+  };
+  // slices 2 wv, 2 wv + 1 are components (2 wv) % 4, +1 of plane (2 wv) / 4: one 8-byte store per lane and array
+  auto store_quarter = [&]() {
+    const int q = (2 * wv) / 4, c = (2 * wv) % 4;
+    auto put = [&](float* l, const float (&v)[2]) {
+      *reinterpret_cast<f32x2*>(&l[q * kPlane + lane * 4 + c]) = (f32x2){v[0], v[1]};
+      if (lane < 32) *reinterpret_cast<f32x2*>(&l[q * kPlane + 256 + lane * 4 + c]) = (f32x2){v[0], v[1]};
+    };
+    put(lx, pjx); put(lz, pjz); put(lg, pjg);
+  };
+
+  fetch_quarter(0);
+  for (int dd = 0; dd < per; ++dd) {
+    const int D = D_lo + dd;
+    if (D >= D_hi) break;                                       // (uniform over the workgroup)
+    const unsigned J = partner_of(dd);
+    // wave w meets J at ring offset D - w: one of its offsets 1 .. dmax, or the half-way offset of an even ring (lower half)
+    auto valid_of = [&](int w) -> bool {
+      const int d = D - w;
+      const unsigned Iw = I0 + (unsigned)w;
+      const bool own = Iw < i_first + i_count && Iw < ntiles;
+      return own && ((d >= 1 && d <= (int)dmax) || (even && d == dtot && Iw < ntiles / 2));
+    };
+    const bool valid = valid_of(wv);
+    const bool any = valid_of(0) || valid_of(1) || valid_of(2) || valid_of(3);
+    if (any) store_quarter();
+    Org oj[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) oj[q] = to_scalars(poj[q]);
+    __syncthreads();                                            // the partner tile is complete (and the previous round's ex read)
+    if (dd + 1 < per) fetch_quarter(dd + 1);
+    if (!any) continue;                                         // (uniform: nobody reads the slab, nothing to hand over)
+    f32x2 bu[H], bw[H];
+#pragma unroll
+    for (int m = 0; m < H; ++m) { bu[m] = (f32x2){0.f, 0.f}; bw[m] = (f32x2){0.f, 0.f}; }
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        if (local) refer_targets(oj[q]);
+        for (int k = 0; k < 64; k += 2) {
+          const int pos0 = ((k & 32) ? lane32x4 : lane * 4) + (k & 31) * 4;
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int pos = pos0 + 4 * rr;
+            f32x2 xj[2], zj[2], gj[2];
+            load_plane(lx, q, pos, xj); load_plane(lz, q, pos, zj); load_plane(lg, q, pos, gj);
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+              const int m = 2 * q + mm;
+#pragma unroll
+              for (int t = 0; t < T; ++t) {
+                const f32x2 dx = pk_sub_sel(xq[rr][t / 2], xj[mm], t & 1);
+                const f32x2 dz = pk_sub_sel(zq[rr][t / 2], zj[mm], t & 1);
+                f32x2 r2 = dx * dx;
+                r2 = __builtin_elementwise_fma(dz, dz, r2);
+                const f32x2 qq = __builtin_elementwise_fma(r2, r2, vc4);
+                const f32x2 sv = {__builtin_amdgcn_rsqf(qq.x), __builtin_amdgcn_rsqf(qq.y)};
+                const f32x2 sj = sv * gj[mm];
+                const f32x2 si = pk_mul_sel(sv, gp[t / 2], t & 1, sj);
+                au[t] = __builtin_elementwise_fma(dz, sj, au[t]);
+                aw[t] = __builtin_elementwise_fma(dx, sj, aw[t]);
+                bu[m] = __builtin_elementwise_fma(dz, si, bu[m]);
+                bw[m] = __builtin_elementwise_fma(dx, si, bw[m]);
+              }
+            }
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) { bu[2 * q + mm] = dpp_rol1(bu[2 * q + mm]); bw[2 * q + mm] = dpp_rol1(bw[2 * q + mm]); }
+          }
+        }
+      }
+    }
+    // after the 64 steps every lane holds the sums of its own home lane: J vortex J W + lane + 64 t, packed elements
+    // t = 0 .. T - 1; component c = 4 m + {0: u of 2 m, 1: u of 2 m + 1, 2: w of 2 m, 3: w of 2 m + 1}
+#pragma unroll
+    for (int m = 0; m < H; ++m) {
+      ex[wv][(4 * m + 0) * 64 + lane] = bu[m].x; ex[wv][(4 * m + 1) * 64 + lane] = bu[m].y;
+      ex[wv][(4 * m + 2) * 64 + lane] = bw[m].x; ex[wv][(4 * m + 3) * 64 + lane] = bw[m].y;
+    }
+    __syncthreads();                                            // every wave has left the slab and handed its sums over
+    // the four waves share the 2 T components; each adds the four partials in wave order (zeros from waves without a pair)
+#pragma unroll 1
+    for (int c = wv; c < 2 * T; c += kWaves) {
+      float v = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) v += ex[w][c * 64 + lane];
+      const unsigned j = J * W + lane + 64u * (2 * (c / 4) + (c & 1));
+      if (j < n) fx_add((c & 2) ? &a.acc_w[j] : &a.acc_u[j], -v, fxs);      // j feels the opposite of what i feels
+    }
+  }
+
+  // ---- the I side ------------------------------------------------------------------------------------------------
+  if (mine) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const unsigned i = I * W + lane + 64u * t;
+      if (i < n) {
+        const float su = au[t].x + au[t].y, sw = aw[t].x + aw[t].y;
+        fx_add(&a.acc_u[i], su, fxs); fx_add(&a.acc_w[i], sw, fxs);
+        chk += su + sw;
+      }
+    }
+  }
+  if (!(__builtin_fabsf(chk) < __builtin_inff())) atomicAdd(reinterpret_cast<unsigned long long*>(a.bad), 1ULL);
 }
 
 // One workgroup: the fixed-point scale of a launch from sum |Gamma| (summed in a fixed order -> the same bits every

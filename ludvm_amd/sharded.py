@@ -32,7 +32,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ._ffi import SYM_TILE
+from ._ffi import SYM_OWNER_ALIGN, SYM_TILE
 
 PAD_POS = 1.0e6  # padding vortices (block sizes are rounded up): zero strength, far away
 
@@ -169,8 +169,9 @@ class ShardedWake:
         self.n = len(x)
         g = self.world
         n_loc = (self.n + g - 1) // g
-        if self.symmetric:   # block boundaries must fall on tile boundaries of the symmetric kernel
-            n_loc = (n_loc + SYM_TILE - 1) // SYM_TILE * SYM_TILE
+        if self.symmetric:   # block boundaries must fall on quad boundaries (4 tiles) of the symmetric kernel
+            unit = SYM_TILE * SYM_OWNER_ALIGN
+            n_loc = (n_loc + unit - 1) // unit * unit
         self.n_loc = n_loc
         n_pad = n_loc * g
         pad = n_pad - self.n

@@ -525,13 +525,16 @@ def test_symmetric_kernel_tile_edges(eng, n):
         eng.set_stream(None)
 
 
-@pytest.mark.parametrize("ranks,n", [(2, 70000), (3, 100000), (8, 300001)])
+@pytest.mark.parametrize("ranks,n", [(2, 70000), (3, 100000), (8, 300001), (3, 600001), (8, 1100000)])
 def test_symmetric_tile_ring_partition(eng, ranks, n):
     """Multi-GPU building block on one GPU: the owners of the tile ring, run one after the other with
     separate accumulators, add up (integer sums: what the all-reduce does) to BIT FOR BIT the self-interaction
-    one owner of all tiles computes, and one owner's block step equals the direct advection of that block."""
+    one owner of all tiles computes, and one owner's block step equals the direct advection of that block.  The two
+    largest sizes run the quad variant of the kernel (from 1024 tiles: four I tiles per workgroup share each partner tile,
+    J-side sums added in LDS before one atomic): owners own whole quads (LUDVM_SYM_OWNER_ALIGN)."""
     import torch
-    from ludvm_amd._ffi import SYM_TILE as tile
+    from ludvm_amd._ffi import SYM_OWNER_ALIGN, SYM_TILE
+    tile = SYM_TILE * SYM_OWNER_ALIGN
     n_loc = ((n + ranks - 1) // ranks + tile - 1) // tile * tile
     n_pad = n_loc * ranks
     rng = np.random.default_rng(n)
@@ -544,7 +547,7 @@ def test_symmetric_tile_ring_partition(eng, ranks, n):
     try:
         scale = torch.zeros([32], dtype=torch.uint8, device=dev)
         eng.sym_scale_dev(dg.data_ptr(), n_pad, 0.065, scale.data_ptr())
-        tiles = n_loc // tile
+        tiles = n_loc // SYM_TILE
 
         def accumulate(first, count, acc):
             base = acc.data_ptr()

@@ -108,7 +108,7 @@ def _worker(rank, world, port, n, steps, out, symmetric):
         x, z, g = _wake(n)
         wake = ShardedWake(x, z, g, 0.065, 5e-2, OracleShardKernel(), torch.device("cpu"), symmetric=symmetric)
         per = (n + world - 1) // world
-        assert wake.n_loc == ((per + 511) // 512 * 512 if symmetric else per) and wake.lo == rank * wake.n_loc
+        assert wake.n_loc == ((per + 2047) // 2048 * 2048 if symmetric else per) and wake.lo == rank * wake.n_loc   # whole quads of 4 tiles
         assert wake.pairs_per_step == float(n) * n
         for _ in range(steps):
             wake.step()

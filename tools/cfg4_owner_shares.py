@@ -21,7 +21,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ludvm_amd import Engine  # noqa: E402
-from ludvm_amd._ffi import SYM_TILE  # noqa: E402
+from ludvm_amd._ffi import SYM_OWNER_ALIGN, SYM_TILE  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--vortices", type=int, default=8_000_000)
@@ -50,7 +50,8 @@ def timed(fn):
 
 print(f"config 4 on one GPU, N = {n}: per-owner share of one step [ms] ({eng.device_info()['name']})")
 for G in args.owners:
-    n_loc = ((n + G - 1) // G + SYM_TILE - 1) // SYM_TILE * SYM_TILE
+    unit = SYM_TILE * SYM_OWNER_ALIGN
+    n_loc = ((n + G - 1) // G + unit - 1) // unit * unit
     n_pad = n_loc * G
     pad = n_pad - n
     xs = torch.from_numpy(np.concatenate([x, np.full(pad, 1e6, np.float32)])).to(dev)
