@@ -53,13 +53,15 @@ EXECUTED_FLOP_PER_PAIR = {"direct": 13, "symmetric": 9}   # the symmetric kernel
 PMC_TRAFFIC_CFG3 = {
     "ludvm::pair_f32<2,1024> direct, partial slabs": {"bytes": 2 * 73.2e6 + 72.0e6,
                                                       "source": "profiles/r01_bench_cfg3_direct_pmc_{fetch,write}.csv"},
-    # 2 x FETCH_SIZE 29 474 KB (gfx950 tallies the 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section; the
-    # 16 MB read of finish_sym in the same pass shows the factor) + WRITE_SIZE 1.727e7 KB (exact for stores: the 16 MB
-    # memset reads 15 625 KB); the write side is the 64-bit integer atomics (2.93e8 64-B requests, memory-side, mostly
-    # Infinity-Cache resident: the accumulators are 16 MB).  Round 3's kernel (origins per block and index parity, one
-    # pass per origin block of the partner tile), passes taken on the round's final code.
-    "ludvm::pair_sym_f32<8> fixed-point accumulation": {"bytes": (2 * 29474.0 + 1.72739e7) * 1024,
-                                                        "source": "profiles/r03_final_bench_cfg3_sym_pmc_{fetch,write}.csv"},
+    # Round 3's kernel at this size: the quad variant (four I tiles of a workgroup share each partner tile: one fixed-point
+    # atomic per J vortex and workgroup instead of one per wave) + a launch of the plain kernel for the diagonal tiles.
+    # 2 x FETCH_SIZE (29 461 + 5 999) KB (gfx950 tallies the 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section)
+    # + WRITE_SIZE (5.132e6 + 16 602) KB (exact for stores and 8-byte atomics: 8.69e7 + 2.8e5 64-B atomic requests,
+    # memory-side, mostly Infinity-Cache resident: the accumulators are 16 MB); round 2 / early round 3 (one atomic per
+    # wave and tile pair): 2 x 29 474 + 1.727e7 KB.
+    "ludvm::pair_sym_quad_f32<8> (+ pair_sym_f32<8> on the diagonal tiles), fixed-point accumulation": {
+        "bytes": (2 * (29461.0 + 5999.0) + 5131948.0 + 16602.0) * 1024,
+        "source": "profiles/r03_final_bench_cfg3_sym_pmc_{fetch,write}.csv"},
 }
 V_CORE = 0.065
 DT = 5e-2
@@ -299,7 +301,9 @@ def main():
         ns_l = n if workload == "cfg3" else wake.n_pad
         nt_l = n if workload == "cfg3" else (wake.n_pad if symmetric else wake.n_loc)
         alg_bytes = 12.0 * ns_l + 16.0 * nt_l
-        kernel_name = ("ludvm::pair_sym_f32<8> fixed-point accumulation" if symmetric
+        quad = symmetric and ns_l >= 1024 * 512 and os.environ.get("LUDVM_SYM_QUAD", "1") != "0"     # (the library's rule)
+        kernel_name = (("ludvm::pair_sym_quad_f32<8> (+ pair_sym_f32<8> on the diagonal tiles), fixed-point accumulation" if quad
+                        else "ludvm::pair_sym_f32<8> fixed-point accumulation") if symmetric
                        else "ludvm::pair_f32<2,1024> direct, partial slabs")
         traffic = PMC_TRAFFIC_CFG3.get(kernel_name) if (workload == "cfg3" and n == 1_000_000 and not args.tpl and not args.splits) else None
         out = {
