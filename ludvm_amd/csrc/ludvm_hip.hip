@@ -508,7 +508,8 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   // Large launches: the quad variant (four I tiles of a workgroup share each partner tile: a quarter of the atomics) plus a
   // launch of the plain kernel restricted to the diagonal tiles.  The choice is a function of the vortex count (the march's
   // bound) alone, so every owner of a sharded ring makes the same one; owners must own whole quads.
-  const bool quad = c->sym_quad && T == 8 && !hilo && gm.rsplit == 1 && c->tune_sym_rsplit == 0 && gm.ntiles >= c->sym_quad_min_tiles;
+  const bool quad = T == 8 && !hilo && gm.ntiles >= 16 &&
+                    (c->tune_sym_rsplit == -4 || (c->sym_quad && gm.rsplit == 1 && c->tune_sym_rsplit == 0 && gm.ntiles >= c->sym_quad_min_tiles));
   if (quad) {
     if (i_first % 4 != 0 || (i_count % 4 != 0 && i_first + i_count != gm.ntiles))
       return fail(c, LUDVM_E_ARG, "symmetric kernel, quad variant: an owner's tile block must start and end on multiples of 4 tiles");
@@ -859,8 +860,8 @@ int ludvm_set_sym_tuning(ludvm_ctx* c, int vortices_per_lane, int rotation_split
   if (!c) return LUDVM_E_ARG;
   if (vortices_per_lane != 0 && vortices_per_lane != 4 && vortices_per_lane != 8)
     return fail(c, LUDVM_E_ARG, "vortices_per_lane must be 0 (heuristic), 4 or 8");
-  if (rotation_split != 0 && rotation_split != -1 && rotation_split != 1 && rotation_split != 2 && rotation_split != 4)
-    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (by size), -1 (mixed granularity), 1, 2 or 4");
+  if (rotation_split != 0 && rotation_split != -1 && rotation_split != -4 && rotation_split != 1 && rotation_split != 2 && rotation_split != 4)
+    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (by size), -1 (mixed granularity), -4 (quad variant), 1, 2 or 4");
   c->tune_sym_t = vortices_per_lane;
   c->tune_sym_rsplit = rotation_split;
   return LUDVM_OK;

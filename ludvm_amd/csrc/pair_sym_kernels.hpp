@@ -139,7 +139,9 @@ __host__ __device__ inline void sym_geometry_t(I n, int T, int tune_split, int t
   if (ys < 1) ys = 1;
   I rs = 1;
   ytail = 0;
-  if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) {
+  if (tune_rsplit == -4) {                     // the quad variant, whatever the size: single-wave geometry
+    rs = 1;
+  } else if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) {
     rs = (I)tune_rsplit;
   } else if (tune_rsplit == -1) {              // mixed: the last d-chunks by four waves per item
     rs = 0;

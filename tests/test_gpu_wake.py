@@ -627,6 +627,36 @@ def test_march_bits_do_not_depend_on_where_the_calls_begin(threshold, prec, tmp_
         e.close()
 
 
+def test_march_with_the_quad_variant_of_the_symmetric_kernel():
+    """The quad variant (four I tiles per workgroup share each partner tile; default from 1024 tiles) inside the march, where
+    the kernel reads the wake size -- and with it its whole geometry, quads and owner blocks included -- on the device:
+    forced from 16 tiles (ludvm_set_sym_tuning(8, -4)) on a wake that starts with 9000 free vortices.  Marched (serial and
+    overlapped steps) and per-step runs agree with a float64 run to fp32 rounding, shed alike, and repeat bit for bit."""
+    from ludvm_amd import Engine, LUDVM
+    rng = np.random.default_rng(12)
+    nfree = 9000
+    xy = np.stack([rng.uniform(-3.0, -0.5, nfree), rng.uniform(-1.0, 1.0, nfree)], axis=1)
+    gam = rng.standard_normal(nfree) * 2e-5
+    kw = dict(CONFIG1, tf=1.5, circulation_freevort=gam, xy_freevort=xy.T)
+    e = Engine(0)
+    try:
+        ref = LUDVM(**kw, verbose=False, engine=e, precision="f64", history="sparse", march=False)
+        e.set_symmetric(4096)
+        e.set_sym_tuning(8, -4)
+        runs = {}
+        for name, march in (("march", True), ("march again", True), ("per step", False)):
+            runs[name] = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse", march=march)
+        for name, r in runs.items():
+            assert np.array_equal(r.LEV_shed, ref.LEV_shed), name
+            for q in ("Cl", "Cd", "Cm"):
+                assert np.abs(getattr(r, q) - getattr(ref, q)).max() <= 2e-5 * max(1.0, np.abs(getattr(ref, q)).max()), (name, q)
+            assert np.abs(r.path["FREE"][r.nt - 1] - ref.path["FREE"][ref.nt - 1]).max() <= 1e-5, name
+        a, b = runs["march"], runs["march again"]
+        assert np.array_equal(a.Cl, b.Cl) and np.array_equal(a.path["FREE"][a.nt - 1], b.path["FREE"][b.nt - 1])
+    finally:
+        e.close()
+
+
 def test_march_and_overlap_logic_isolated_from_rounding():
     """Deterministic A/B of the overlapped step against the serial one (LUDVM_MARCH_OVERLAP=0) on the same symmetric
     kernels: the two differ only in how the vortices shed in a step are handled (their velocity from the fp64 chord

@@ -87,6 +87,35 @@ for march in (True, False):
             sg.close()
             eng_one.close()
         eng.close()
+# ... and once with the quad variant of the symmetric kernel forced (ludvm_set_sym_tuning(8, -4): four I tiles per workgroup share
+# each partner tile; the library's default from 1024 tiles on): the owners then own whole quads of 4 tiles, cut on the device
+# from the wake size.  A wake that starts with 9000 free vortices makes it 18+ tiles from the first step.
+rng = np.random.default_rng(12)
+nfree = 9000
+xy = np.stack([rng.uniform(-3.0, -0.5, nfree), rng.uniform(-1.0, 1.0, nfree)], axis=0)
+gam = rng.standard_normal(nfree) * 2e-5
+kwq = dict(kw, tf=1.5, circulation_freevort=gam, xy_freevort=xy)
+eng = Engine(local)
+eng.set_symmetric(4096)
+eng.set_sym_tuning(8, -4)
+sg = ShardGroup(min_targets=1000, min_wake=4096)
+eng_one = eng
+if library:
+    eng_one = Engine(local)
+    eng_one.set_symmetric(4096)
+    eng_one.set_sym_tuning(8, -4)
+for march in (True, False):
+    sh = LUDVM(**kwq, verbose=False, engine=eng, precision="f32", history="sparse", march=march, distributed=sg)
+    one = LUDVM(**kwq, verbose=False, engine=eng_one, precision="f32", history="sparse", march=march)
+    same = all(np.array_equal(getattr(sh, n), getattr(one, n)) for n in ("Cl", "Cd", "Cm", "LEV_shed")) and \
+        np.array_equal(sh.path["FREE"][sh.nt - 1], one.path["FREE"][one.nt - 1])
+    print(f"rank {rank} march={march} quad variant: sharded time_loop == single-GPU bit for bit: {same}", flush=True)
+    ok &= bool(same)
+if library:
+    ok &= bool(eng.comm_allgather(np.array([1 if ok else 0], np.int8)).min())
+    sg.close()
+    eng_one.close()
+eng.close()
 if library:
     t = torch.tensor([1 if ok else 0])
 else:
