@@ -177,7 +177,7 @@ def main():
     # the symmetric kernel serves self-interaction launches (configs 3 and 4)
     symmetric = bool(args.symmetric) and n >= 16384
     variant = "symmetric" if symmetric else "direct"
-    coll = None
+    coll = coll_note = None
     if workload == "cfg3":
         dx, dz, dg = (torch.from_numpy(a).to(device) for a in (x, z, g))
         du, dw = torch.empty_like(dx), torch.empty_like(dx)
@@ -191,7 +191,6 @@ def main():
         collective = None
     else:
         coll = args.collectives if args.collectives != "auto" else ("library" if (backend == "nccl" and world > 1) else "torch")
-        coll_note = None
         if coll == "library":
             # the engine's own communicator: rank 0's identifier goes round through torch (any channel would do); its
             # sharding of resident-wake roll-ups is switched off (min_vortices), ShardedWake hands out the tile blocks itself.
@@ -206,8 +205,33 @@ def main():
             if uid[0] is None:
                 coll = "torch"
             else:
-                eng.comm_init(rank, world, uid[0], min_vortices=1 << 62)
-        wake = ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric, collectives=coll)
+                # join, then prove the communicator on a known sum before the steps depend on it; the ranks agree on
+                # the outcome through torch (one rank falling back alone would leave the others inside a collective)
+                ok, why = 1, ""
+                try:
+                    eng.comm_init(rank, world, uid[0], min_vortices=1 << 62)
+                    chk = torch.arange(1, 9, dtype=torch.int64, device=device) * (rank + 1)
+                    torch.cuda.synchronize()
+                    eng.comm_allreduce_i64_dev(chk.data_ptr(), chk.numel())
+                    torch.cuda.synchronize()
+                    want = torch.arange(1, 9, dtype=torch.int64) * (world * (world + 1) // 2)
+                    if not torch.equal(chk.cpu(), want):
+                        ok, why = 0, "wrong sum from the library's all-reduce"
+                except Exception as e:       # noqa: BLE001
+                    ok, why = 0, str(e)
+                flag = torch.tensor([ok], dtype=torch.int64, device=device)
+                if world > 1:
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    try:
+                        eng.comm_destroy()
+                    except Exception:       # noqa: BLE001
+                        pass
+                    coll = "torch"
+                    coll_note = f"library communicator not usable ({why or 'another rank failed'}); torch.distributed collectives used"
+        # (a one-rank run that asks for the library's collectives issues them all the same: identities on real RCCL)
+        wake = ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric, collectives=coll,
+                           force_collectives=(coll == "library" and world == 1))
         step = wake.step
         pairs_per_step = wake.pairs_per_step
         pairs_per_launch = float(wake.n_pad) * float(wake.n_pad) / world if symmetric else float(wake.n_loc) * float(wake.n_pad)
@@ -314,6 +338,7 @@ def main():
             "repeat_values": [pairs_per_step * args.steps / r for r in repeats],
             "config": {"workload": desc, "collective_backend": backend if world > 1 else None,
                        "ranks": dist.get_world_size() if (world > 1 or force_dist) else 1, "collective": collective,
+                       "collective_note": coll_note,
                        "n_vortices": n, "v_core": V_CORE, "device": info["name"],
                        "cu_count": info["cu_count"], "kernel_variant": variant, "targets_per_lane": args.tpl or "auto",
                        "source_splits": args.splits or "auto", "pair_kernel_ms_per_rank": per_rank_ms},

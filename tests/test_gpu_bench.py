@@ -55,6 +55,18 @@ def test_bench_config4_shape_on_one_gpu():
     assert d["value"] > 1e11
 
 
+def test_bench_config4_through_the_library_communicator_on_one_rank():
+    """The N > 1 bench path with the collective inside the library, on a one-rank communicator (real RCCL): the
+    communicator is created, proven on a known sum, used by every step and destroyed; no fallback note."""
+    d = _run("--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1", "--cpu-rows", "0",
+             "--collectives", "library")
+    assert d["config"]["collective_note"] is None, d["config"]["collective_note"]
+    assert "inside libludvm_hip.so" in d["config"]["collective"] and d["value"] > 1e11
+    ref = _run("--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1", "--cpu-rows", "0",
+               "--collectives", "torch")
+    assert "torch.distributed" in ref["config"]["collective"] and ref["config"]["collective_note"] is None
+
+
 def test_sharded_wake_collectives_on_the_real_rccl_backend():
     """One rank, backend "nccl" (= RCCL): the int64 all-reduce / fp32 all-gather calls of the sharded step with the
     layouts used at G > 1 (identities in a one-rank group) against the same step without collectives, bit for bit
