@@ -579,29 +579,32 @@ struct Rccl {
 };
 
 Rccl& rccl() {
-  static Rccl r;
-  if (r.handle || !r.error.empty()) return r;
-  const char* name = std::getenv("LUDVM_RCCL_LIB");
-  if (!name || !name[0]) name = "librccl.so.1";
-  r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-  if (!r.handle) {
-    const char* e = dlerror();
-    r.error = std::string("cannot open ") + name + ": " + (e ? e : "?");
+  // opened once per process, on first use (a function-local static: safe when two contexts' threads get here together)
+  static Rccl lib = [] {
+    Rccl r;
+    const char* name = std::getenv("LUDVM_RCCL_LIB");
+    if (!name || !name[0]) name = "librccl.so.1";
+    r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!r.handle) {
+      const char* e = dlerror();
+      r.error = std::string("cannot open ") + name + ": " + (e ? e : "?");
+      return r;
+    }
+    auto sym = [&](const char* n) -> void* {
+      void* p = dlsym(r.handle, n);
+      if (!p && r.error.empty()) r.error = std::string("librccl has no symbol ") + n;
+      return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!r.error.empty()) { dlclose(r.handle); r.handle = nullptr; }
     return r;
-  }
-  auto sym = [&](const char* n) -> void* {
-    void* p = dlsym(r.handle, n);
-    if (!p && r.error.empty()) r.error = std::string("librccl has no symbol ") + n;
-    return p;
-  };
-  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
-  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
-  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-  if (!r.error.empty()) { dlclose(r.handle); r.handle = nullptr; }
-  return r;
+  }();
+  return lib;
 }
 
 int fail_rccl(ludvm_ctx* c, const char* what, ncclResult_t e) {
@@ -795,6 +798,7 @@ int ludvm_destroy(ludvm_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
+  if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);   // before its stream and buffers go
   for (auto& t : c->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   for (auto& t : c->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   void* bufs[] = {c->part.p, c->acc.p, c->symsc.p, c->arena.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32,
@@ -809,7 +813,6 @@ int ludvm_destroy(ludvm_ctx* c) {
   if (c->progress) (void)hipHostFree(c->progress);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_out) (void)hipHostFree(c->pin_out);
-  if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return LUDVM_OK;
