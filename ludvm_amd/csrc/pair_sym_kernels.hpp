@@ -74,6 +74,7 @@ struct SymArgs {
 // march step sized from an upper bound, for one GPU and for G GPUs that own I-tile blocks of the same ring.
 constexpr long long kSymTargetWaves = 8 * 65536;   // (I, d-chunk) work items aimed for over the whole ring
 constexpr long long kSymMaxSplit = 64;
+constexpr long long kSymMaxSplitTuned = 1024;      // what ludvm_set_tuning may ask for (measurements)
 constexpr long long kXcds = 8;                        // XCDs of an MI355X: workgroup b is dispatched to XCD b % 8
 constexpr long long kSymMaxRsplit = 4;
 constexpr long long kSymMinItems = 10500;          // measured (profiles/r02_atomics_cost_and_lds_reduction.txt, table 4)
@@ -134,7 +135,8 @@ __host__ __device__ inline void sym_geometry_t(I n, int T, int tune_split, int t
   // (kSymTargetWaves / nt1 rounded up is at least kSymMaxSplit whenever nt1 <= kSymTargetWaves / kSymMaxSplit: no division)
   I ys = tune_split > 0 ? (I)tune_split
                         : (nt1 <= (I)(kSymTargetWaves / kSymMaxSplit) ? (I)kSymMaxSplit : ((I)kSymTargetWaves + nt1 - 1) / nt1);
-  if (ys > (I)kSymMaxSplit) ys = (I)kSymMaxSplit;
+  if (ys > (I)kSymMaxSplit && tune_split <= 0) ys = (I)kSymMaxSplit;
+  if (ys > (I)kSymMaxSplitTuned) ys = (I)kSymMaxSplitTuned;
   if (ys > dtot) ys = dtot;
   if (ys < 1) ys = 1;
   I rs = 1;
@@ -713,7 +715,7 @@ __host__ __device__ inline QuadGeom quad_geometry(I n, int T, int tune_split) {
   g.dtot = g.dmax + ((nt % 2 == 0 && nt > 1) ? 1u : 0u);
   g.Dtot = g.dtot + (kQuad - 1);
   unsigned ys = tune_split > 0 ? (unsigned)tune_split : (unsigned)kSymMaxSplit;
-  if (ys > (unsigned)kSymMaxSplit) ys = (unsigned)kSymMaxSplit;
+  if (ys > (unsigned)kSymMaxSplitTuned) ys = (unsigned)kSymMaxSplitTuned;
   if (ys > g.Dtot) ys = g.Dtot;
   if (ys < 1) ys = 1;
   g.ysplit = (int)ys;

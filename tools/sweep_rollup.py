@@ -26,16 +26,25 @@ for n in sizes:
     res = {"n": n}
     for mode, mname in ((2, "sym"),) + (() if os.environ.get("SWEEP_SYM_ONLY") else ((0, "direct"),)):
         eng.set_symmetric(mode)
-        for prec in ("f32", "f32x2"):
+        for prec in (("f32",) if os.environ.get("SWEEP_F32_ONLY") else ("f32", "f32x2")):
             eng.wake_clear()
             eng.wake_append(x, z, g)
-            reps = max(5, min(300, int(4e10 / (n * n))))
+            # SWEEP_SECONDS (default 0.3) of back-to-back steps per timed block, three blocks, the median.  SWEEP_SECONDS=0 gives
+            # the blocks rounds 1-3 used (>= 5 steps: ~10 ms at 1e5 vortices, right after the upload's idle time -- the first
+            # 20-30 ms after an idle period run ~14 % slower, profiles/r03_sweep_rollup_sustained.txt)
+            secs = float(os.environ.get("SWEEP_SECONDS", "0.3"))
+            reps = max(5, min(300, int(4e10 / (n * n)))) if secs <= 0 else max(5, int(secs * 8.5e12 / (n * n)))
             for _ in range(3):
                 eng.wake_advect(1e-6, fx, fz, fg, 1.3e-3, precision=prec)
             eng.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                eng.wake_advect(1e-6, fx, fz, fg, 1.3e-3, precision=prec)
-            eng.synchronize()
-            res[f"{mname}_{prec}_us"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+            blocks = []
+            for _ in range(1 if secs <= 0 else 3):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    eng.wake_advect(1e-6, fx, fz, fg, 1.3e-3, precision=prec)
+                eng.synchronize()
+                blocks.append((time.perf_counter() - t0) / reps * 1e6)
+            res[f"{mname}_{prec}_us"] = round(sorted(blocks)[len(blocks) // 2], 1)
+            if secs > 0:
+                res[f"{mname}_{prec}_blocks_us"] = [round(b, 1) for b in blocks]
     print(json.dumps(res), flush=True)
