@@ -45,6 +45,15 @@ for n in sizes:
                 eng.synchronize()
                 blocks.append((time.perf_counter() - t0) / reps * 1e6)
             res[f"{mname}_{prec}_us"] = round(sorted(blocks)[len(blocks) // 2], 1)
+            if os.environ.get("SWEEP_KERNEL_TIME"):     # the pair kernel alone (HIP events around it), a further block
+                eng.kernel_timing(True)
+                eng.kernel_time_ms(reset=True)
+                for _ in range(reps):
+                    eng.wake_advect(1e-6, fx, fz, fg, 1.3e-3, precision=prec)
+                eng.synchronize()
+                ms, nl = eng.kernel_time_ms(reset=True)
+                eng.kernel_timing(False)
+                res[f"{mname}_{prec}_kernel_us"] = round(ms * 1e3, 1)
             if secs > 0:
                 res[f"{mname}_{prec}_blocks_us"] = [round(b, 1) for b in blocks]
     print(json.dumps(res), flush=True)
