@@ -704,6 +704,7 @@ pair_sym_f32(SymArgs a) {
 // (blocks of 4 tiles): the fp32 sum of four partials is not the integer sum of their conversions.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr unsigned kQuad = 4;
+constexpr unsigned kQuadSplit = 128;
 struct QuadGeom { unsigned ntiles, dmax, dtot, Dtot; int ysplit, per; };
 template <typename I>
 __host__ __device__ inline QuadGeom quad_geometry(I n, int T, int tune_split) {
@@ -714,7 +715,11 @@ __host__ __device__ inline QuadGeom quad_geometry(I n, int T, int tune_split) {
   g.dmax = nt > 0 ? (unsigned)((nt - 1) / 2) : 0;
   g.dtot = g.dmax + ((nt % 2 == 0 && nt > 1) ? 1u : 0u);
   g.Dtot = g.dtot + (kQuad - 1);
-  unsigned ys = tune_split > 0 ? (unsigned)tune_split : (unsigned)kSymMaxSplit;
+  // d-chunks per quad: an item of `per` rounds lives per x ~0.17 ms, and a launch drains over about half an item's lifetime
+  // while every item pays ~4 % of one round for its own targets (loads, I-side conversions and atomics): the loss
+  // 0.5 per 0.17 ms / T_launch + 0.04 / per is smallest near per = N / 140 000, i.e. ~128 chunks at every size the variant
+  // serves (measured at N = 1e6, same box: 64 chunks 112.0 ms, 128: 111.6, 256: 111.6; tools/ab_quad_chunks.sh)
+  unsigned ys = tune_split > 0 ? (unsigned)tune_split : (unsigned)kQuadSplit;
   if (ys > (unsigned)kSymMaxSplitTuned) ys = (unsigned)kSymMaxSplitTuned;
   if (ys > g.Dtot) ys = g.Dtot;
   if (ys < 1) ys = 1;
