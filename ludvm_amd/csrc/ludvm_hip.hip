@@ -522,6 +522,11 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
     hipLaunchKernelGGL((pair_sym_f32<8, false, 1>), dim3((unsigned)dblocks), dim3(kBlock), 0, c->stream, d);
     const QuadGeom qg = quad_geometry<long long>(n, 8, a.tune_split);
     long long qblocks = quad_blocks(n_dev ? gm.ntiles : i_count, qg.ysplit);
+    if (n_dev) {      // the device derives the chunks from its own vortex count: cover every count the bounds allow
+      const long long W = 64LL * 8;
+      for (long long nt = std::max<long long>(1, (std::max<long long>(n_lo, 1) + W - 1) / W); nt < gm.ntiles; ++nt)
+        qblocks = std::max(qblocks, quad_blocks(nt, quad_geometry<long long>(nt * W, 8, a.tune_split).ysplit));
+    }
     hipLaunchKernelGGL((pair_sym_quad_f32<8>), dim3((unsigned)std::max<long long>(qblocks, 1)), dim3(kBlock), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
     CHK(timed_end(c, tq, act));

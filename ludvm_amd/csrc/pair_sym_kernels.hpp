@@ -705,7 +705,7 @@ pair_sym_f32(SymArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr unsigned kQuad = 4;
 constexpr unsigned kQuadSplit = 128;
-struct QuadGeom { unsigned ntiles, dmax, dtot, Dtot; int ysplit, per; };
+struct QuadGeom { unsigned ntiles, dmax, dtot, Dtot; int ysplit, per, nlong, pshort; };
 template <typename I>
 __host__ __device__ inline QuadGeom quad_geometry(I n, int T, int tune_split) {
   QuadGeom g;
@@ -715,17 +715,41 @@ __host__ __device__ inline QuadGeom quad_geometry(I n, int T, int tune_split) {
   g.dmax = nt > 0 ? (unsigned)((nt - 1) / 2) : 0;
   g.dtot = g.dmax + ((nt % 2 == 0 && nt > 1) ? 1u : 0u);
   g.Dtot = g.dtot + (kQuad - 1);
-  // d-chunks per quad: an item of `per` rounds lives per x ~0.17 ms, and a launch drains over about half an item's lifetime
-  // while every item pays ~4 % of one round for its own targets (loads, I-side conversions and atomics): the loss
-  // 0.5 per 0.17 ms / T_launch + 0.04 / per is smallest near per = N / 140 000, i.e. ~128 chunks at every size the variant
-  // serves (measured at N = 1e6, same box: 64 chunks 112.0 ms, 128: 111.6, 256: 111.6; tools/ab_quad_chunks.sh)
-  unsigned ys = tune_split > 0 ? (unsigned)tune_split : (unsigned)kQuadSplit;
-  if (ys > (unsigned)kSymMaxSplitTuned) ys = (unsigned)kSymMaxSplitTuned;
-  if (ys > g.Dtot) ys = g.Dtot;
-  if (ys < 1) ys = 1;
-  g.ysplit = (int)ys;
-  g.per = (int)((g.Dtot + ys - 1) / ys);
+  // d-chunks per quad.  An item of `per` rounds lives per x ~0.17 ms; a launch drains over about half the lifetime of the
+  // items dispatched LAST, while every item pays ~4 % of one round for its own targets (loads, I-side conversions and
+  // atomics).  Uniform chunks (measured at N = 1e6, same box: 64 chunks 112.0 ms, 128: 111.6, 256: 111.6;
+  // tools/ab_quad_chunks.sh) cannot have both small; so the chunks TAPER: with u = Dtot / 128 rounded up, the first seven
+  // eighths of the offsets go in chunks of 2 u rounds and the last eighth -- the highest chunk numbers, which every XCD
+  // dispatches last -- in chunks of u / 4 (at least 1) rounds.  A function of the vortex count alone, like everything
+  // about the partition.  ludvm_set_tuning(.., k > 0) asks for k uniform chunks instead (measurements).
+  if (tune_split > 0) {
+    unsigned ys = (unsigned)tune_split;
+    if (ys > (unsigned)kSymMaxSplitTuned) ys = (unsigned)kSymMaxSplitTuned;
+    if (ys > g.Dtot) ys = g.Dtot;
+    if (ys < 1) ys = 1;
+    g.per = (int)((g.Dtot + ys - 1) / ys);
+    g.ysplit = (int)((g.Dtot + (unsigned)g.per - 1) / (unsigned)g.per);     // (no empty chunk at the end)
+    g.nlong = g.ysplit;
+    g.pshort = g.per;
+    return g;
+  }
+  const unsigned u = (g.Dtot + kQuadSplit - 1) / kQuadSplit;
+  const unsigned P = 2 * (u > 0 ? u : 1), ps = u / 4 > 0 ? u / 4 : 1;
+  const unsigned nlong = (g.Dtot - g.Dtot / 8) / P;
+  const unsigned rest = g.Dtot - nlong * P;
+  g.per = (int)P;
+  g.pshort = (int)ps;
+  g.nlong = (int)nlong;
+  g.ysplit = (int)(nlong + (rest + ps - 1) / ps);
+  if (g.ysplit < 1) g.ysplit = 1;
   return g;
+}
+// ring offsets D in [lo, hi) of d-chunk yq of a quad
+__host__ __device__ inline void quad_chunk(const QuadGeom& g, unsigned yq, int& lo, int& hi) {
+  const bool lg = (int)yq < g.nlong;
+  lo = 1 + (lg ? (int)yq * g.per : g.nlong * g.per + ((int)yq - g.nlong) * g.pshort);
+  hi = lo + (lg ? g.per : g.pshort);
+  if (hi > (int)g.Dtot + 1) hi = (int)g.Dtot + 1;
 }
 // workgroups of a quad launch over I tiles [i_first, i_first + i_count) (i_first a multiple of 4): one per (quad, d-chunk),
 // the same number for each XCD
@@ -761,7 +785,7 @@ pair_sym_quad_f32(SymArgs a) {
   }
   const QuadGeom gm = quad_geometry<unsigned>(n, T, a.tune_split);
   const unsigned ntiles = gm.ntiles, dmax = gm.dmax;
-  const int dtot = (int)gm.dtot, per = gm.per;
+  const int dtot = (int)gm.dtot;
   const bool even = (ntiles % 2 == 0) && ntiles > 1;
 
   const int lane = threadIdx.x & 63;
@@ -775,9 +799,9 @@ pair_sym_quad_f32(SymArgs a) {
   const unsigned I0 = i_first + kQuad * (x_lo + (qb - yq * x_n));
   const unsigned I = I0 + (unsigned)wv;
   const bool mine = I < i_first + i_count && I < ntiles;       // this wave's tile exists and is this owner's
-  const int D_lo = 1 + (int)yq * per;
-  int D_hi = D_lo + per;
-  if (D_hi > (int)gm.Dtot + 1) D_hi = (int)gm.Dtot + 1;
+  int D_lo, D_hi;
+  quad_chunk(gm, yq, D_lo, D_hi);
+  const int per = D_hi - D_lo;                                 // this workgroup's rounds
 
   float* const lx = slab[0];
   float* const lz = slab[1];
