@@ -91,7 +91,7 @@ int ludvm_set_symmetric(ludvm_ctx* ctx, int mode);
  * rotation steps of one tile pair -- 0 (default): one number per launch, chosen from its size; -1: mixed granularity, the
  * work items dispatched last by four wavefronts each and the bulk by one (environment LUDVM_SYM_MIXED=1 makes it the
  * default; measured, it does not pay); -4 (with 8 vortices per lane, from 16 tiles on): the quad variant -- four I tiles
- * per workgroup share each partner tile, one atomic per J vortex and workgroup -- which the default takes from 1024 tiles
+ * per workgroup share each partner tile, one atomic per J vortex and workgroup -- which the default takes from 448 tiles
  * on.  Results change only through the partition into fp32 partial sums. */
 int ludvm_set_sym_tuning(ludvm_ctx* ctx, int vortices_per_lane, int rotation_split);
 

@@ -50,7 +50,7 @@ struct ludvm_ctx {
                                              // 4 x 4 from 2^20 grid points and 2 x 4 below; 3 / 4 = always the 2 x 4 / 4 x 4 patch
   long long small_tile_max = 14000;          // direct fp32 launches with at most this many sources use 256-source tiles
   bool sym_quad = true;                      // large symmetric launches: four I tiles per workgroup share each partner tile (LUDVM_SYM_QUAD=0: off)
-  long long sym_quad_min_tiles = 1024;       //   ... from this many 512-vortex tiles on (LUDVM_SYM_QUAD_MIN_TILES)
+  long long sym_quad_min_tiles = 448;        //   ... from this many 512-vortex tiles on (LUDVM_SYM_QUAD_MIN_TILES)
   bool few_packed = true;                    // fp64 launches with <= 128 targets: several source splits per workgroup (LUDVM_FEW_PACKED=0: off)
   long long small_tile_max_f64 = 12000;      // fp64 launches with at most this many sources use 128-source tiles
                                              // (roll-up step 52 -> 26 us at 2400 vortices, 87 -> 72 at 8192 [MI355X])

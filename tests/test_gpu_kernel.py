@@ -529,8 +529,8 @@ def test_symmetric_kernel_tile_edges(eng, n):
 def test_symmetric_tile_ring_partition(eng, ranks, n):
     """Multi-GPU building block on one GPU: the owners of the tile ring, run one after the other with
     separate accumulators, add up (integer sums: what the all-reduce does) to BIT FOR BIT the self-interaction
-    one owner of all tiles computes, and one owner's block step equals the direct advection of that block.  The two
-    largest sizes run the quad variant of the kernel (from 1024 tiles: four I tiles per workgroup share each partner tile,
+    one owner of all tiles computes, and one owner's block step equals the direct advection of that block.  The three
+    largest sizes run the quad variant of the kernel (from 448 tiles: four I tiles per workgroup share each partner tile,
     J-side sums added in LDS before one atomic): owners own whole quads (LUDVM_SYM_OWNER_ALIGN)."""
     import torch
     from ludvm_amd._ffi import SYM_OWNER_ALIGN, SYM_TILE
