@@ -75,7 +75,11 @@ int ludvm_device_info(ludvm_ctx* ctx, int* cu_count, int* clock_khz, long long* 
  * torch's default stream is.  external == 0: go back to the context's own stream. */
 int ludvm_set_stream(ludvm_ctx* ctx, void* hip_stream, int external);
 int ludvm_synchronize(ludvm_ctx* ctx);
-/* Launch shape knobs (0 keeps the built-in heuristic): targets per lane {1,2,4}, source splits. */
+/* Launch shape knobs (0 keeps the built-in heuristic): targets per lane {1,2,4}, source splits.  For the symmetric
+ * kernels the second number is the count of d-chunks (work items) per tile -- the rule gives at most 64 -- or, in the quad
+ * variant, per quad of tiles, where k > 0 asks for k uniform chunks instead of the rule's tapered ones (long items
+ * first, the last eighth of the ring offsets in short ones).  Results change only through the partition into fp32
+ * partial sums. */
 int ludvm_set_tuning(ludvm_ctx* ctx, int targets_per_lane, int source_splits);
 
 /* Self-interaction launches (targets are exactly the sources: wake roll-up, all-pairs calls on one
