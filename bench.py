@@ -325,7 +325,7 @@ def main():
         ns_l = n if workload == "cfg3" else wake.n_pad
         nt_l = n if workload == "cfg3" else (wake.n_pad if symmetric else wake.n_loc)
         alg_bytes = 12.0 * ns_l + 16.0 * nt_l
-        quad = symmetric and ns_l > 447 * 512 and os.environ.get("LUDVM_SYM_QUAD", "1") != "0"     # (the library's rule)
+        quad = symmetric and ns_l > 639 * 512 and os.environ.get("LUDVM_SYM_QUAD", "1") != "0"     # (the library's rule)
         kernel_name = (("ludvm::pair_sym_quad_f32<8> (+ pair_sym_f32<8> on the diagonal tiles), fixed-point accumulation" if quad
                         else "ludvm::pair_sym_f32<8> fixed-point accumulation") if symmetric
                        else "ludvm::pair_f32<2,1024> direct, partial slabs")

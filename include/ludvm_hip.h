@@ -92,11 +92,12 @@ int ludvm_set_tuning(ludvm_ctx* ctx, int targets_per_lane, int source_splits);
 int ludvm_set_symmetric(ludvm_ctx* ctx, int mode);
 /* Tuning of the symmetric kernel (tools and tests; 0 = the library's heuristics): vortices per lane (4: 256-vortex
  * tiles, 8: 512-vortex tiles; plain fp32 positions only) and the number of wavefronts (1, 2, 4) that share the 64
- * rotation steps of one tile pair -- 0 (default): one number per launch, chosen from its size; -1: mixed granularity, the
- * work items dispatched last by four wavefronts each and the bulk by one (environment LUDVM_SYM_MIXED=1 makes it the
- * default; measured, it does not pay); -4 (with 8 vortices per lane, from 16 tiles on): the quad variant -- four I tiles
- * per workgroup share each partner tile, one atomic per J vortex and workgroup -- which the default takes from 448 tiles
- * on.  Results change only through the partition into fp32 partial sums. */
+ * rotation steps of one tile pair -- 0 (default): chosen from the launch's size, with the work items dispatched last
+ * by four wavefronts each where the size gives fewer for the bulk (mixed granularity: the end of a launch is then made of
+ * short items); -1: the mixed form at every size; -2: one number per launch, as until round 3 (environment
+ * LUDVM_SYM_MIXED=1 / 0 selects -1 / -2); -4 (with 8 vortices per lane, from 16 tiles on): the quad variant -- four I
+ * tiles per workgroup share each partner tile, one atomic per J vortex and workgroup -- which the default takes from 640
+ * tiles on.  Results change only through the partition into fp32 partial sums. */
 int ludvm_set_sym_tuning(ludvm_ctx* ctx, int vortices_per_lane, int rotation_split);
 
 /* Sharding ONE simulation's roll-up over several GPUs (LUDVM.time_loop, LUDVM.py:1095-1127, with a wake too large

@@ -50,7 +50,7 @@ struct ludvm_ctx {
                                              // 4 x 4 from 2^20 grid points and 2 x 4 below; 3 / 4 = always the 2 x 4 / 4 x 4 patch
   long long small_tile_max = 14000;          // direct fp32 launches with at most this many sources use 256-source tiles
   bool sym_quad = true;                      // large symmetric launches: four I tiles per workgroup share each partner tile (LUDVM_SYM_QUAD=0: off)
-  long long sym_quad_min_tiles = 448;        //   ... from this many 512-vortex tiles on (LUDVM_SYM_QUAD_MIN_TILES)
+  long long sym_quad_min_tiles = 640;        //   ... from this many 512-vortex tiles on (LUDVM_SYM_QUAD_MIN_TILES)
   bool few_packed = true;                    // fp64 launches with <= 128 targets: several source splits per workgroup (LUDVM_FEW_PACKED=0: off)
   long long small_tile_max_f64 = 12000;      // fp64 launches with at most this many sources use 128-source tiles
                                              // (roll-up step 52 -> 26 us at 2400 vortices, 87 -> 72 at 8192 [MI355X])
@@ -477,7 +477,8 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   const bool hilo = o.xl && o.zl;
   if (hilo) T = 4;
   a.tune_split = c->tune_split;
-  a.tune_rsplit = c->tune_sym_rsplit;
+  // (hi+lo positions keep one granularity per launch: the mixed form was measured on plain fp32 positions only)
+  a.tune_rsplit = (hilo && c->tune_sym_rsplit == 0) ? -2 : c->tune_sym_rsplit;
   a.shard_rank = (n_dev && sharded) ? c->shard_rank : 0;       // (host-sized launches get their tile block as arguments)
   a.shard_world = (n_dev && sharded) ? c->shard_world : 1;
   a.tail_items = c->sym_tail_items;
@@ -489,18 +490,19 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   a.ysplit = gm.ysplit;
   a.rsplit = gm.rsplit;
   a.ytail = gm.ytail;
+  a.rbulk = gm.rbulk;
   a.acc_u = o.acc_u;
   a.acc_w = o.acc_w;
   a.scale = o.scale;
   a.bad = o.bad;
   a.vc4 = (float)vc4;
   // workgroups: 4 / rsplit items (tile, d-chunk) each
-  long long blocks = sym_blocks(i_count, gm.ysplit, gm.rsplit, gm.ytail);
+  long long blocks = sym_blocks(i_count, gm.ysplit, gm.rsplit, gm.ytail, gm.rbulk);
   if (n_dev) {
     const long long W = 64LL * T;
     for (long long nt = std::max<long long>(1, (std::max<long long>(n_lo, 1) + W - 1) / W); nt <= gm.ntiles; ++nt) {
       const SymGeom q = sym_geometry(nt * W, T, a.tune_split, gm.rsplit == 0 ? -1 : gm.rsplit, a.tail_items);    // the waves-per-item rule fixed by the bound: it picks the kernel
-      blocks = std::max(blocks, sym_blocks(q.ntiles, q.ysplit, gm.rsplit, q.ytail));
+      blocks = std::max(blocks, sym_blocks(q.ntiles, q.ysplit, gm.rsplit, q.ytail, q.rbulk));
     }
   }
   if (!n_dev && i_count == 0) return LUDVM_OK;     // an owner without tiles (fewer tiles than owners)
@@ -508,8 +510,9 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   // Large launches: the quad variant (four I tiles of a workgroup share each partner tile: a quarter of the atomics) plus a
   // launch of the plain kernel restricted to the diagonal tiles.  The choice is a function of the vortex count (the march's
   // bound) alone, so every owner of a sharded ring makes the same one; owners must own whole quads.
+  const bool one_wave_items = gm.rsplit == 1 || (gm.rsplit == 0 && gm.rbulk == 1);      // what the size rule gives at this size
   const bool quad = T == 8 && !hilo && gm.ntiles >= 16 &&
-                    (c->tune_sym_rsplit == -4 || (c->sym_quad && gm.rsplit == 1 && c->tune_sym_rsplit == 0 && gm.ntiles >= c->sym_quad_min_tiles));
+                    (c->tune_sym_rsplit == -4 || (c->sym_quad && one_wave_items && c->tune_sym_rsplit == 0 && gm.ntiles >= c->sym_quad_min_tiles));
   if (quad) {
     if (i_first % 4 != 0 || (i_count % 4 != 0 && i_first + i_count != gm.ntiles))
       return fail(c, LUDVM_E_ARG, "symmetric kernel, quad variant: an owner's tile block must start and end on multiples of 4 tiles");
@@ -788,8 +791,9 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
   if (const char* sq = std::getenv("LUDVM_SYM_QUAD")) c->sym_quad = !(sq[0] == '0');
   if (const char* sq = std::getenv("LUDVM_SYM_QUAD_MIN_TILES")) c->sym_quad_min_tiles = std::max<long long>(16, std::atoll(sq));
   if (const char* ti = std::getenv("LUDVM_SYM_TAIL_ITEMS")) c->sym_tail_items = std::max<long long>(0, std::atoll(ti));
-  if (const char* mx = std::getenv("LUDVM_SYM_MIXED")) {        // 1: mixed granularity within a launch (measured: does not pay)
+  if (const char* mx = std::getenv("LUDVM_SYM_MIXED")) {        // 1: mixed granularity at every size; 0: at none (A/B measurements)
     if (mx[0] == '1') c->tune_sym_rsplit = -1;
+    if (mx[0] == '0') c->tune_sym_rsplit = -2;
   }
   if (small_env) { c->small_tile_max = std::atoll(small_env); c->small_tile_max_f64 = std::min<long long>(c->small_tile_max, 12000); }
   const char* small64_env = std::getenv("LUDVM_SMALL_TILE_MAX_F64");
@@ -868,8 +872,9 @@ int ludvm_set_sym_tuning(ludvm_ctx* c, int vortices_per_lane, int rotation_split
   if (!c) return LUDVM_E_ARG;
   if (vortices_per_lane != 0 && vortices_per_lane != 4 && vortices_per_lane != 8)
     return fail(c, LUDVM_E_ARG, "vortices_per_lane must be 0 (heuristic), 4 or 8");
-  if (rotation_split != 0 && rotation_split != -1 && rotation_split != -4 && rotation_split != 1 && rotation_split != 2 && rotation_split != 4)
-    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (by size), -1 (mixed granularity), -4 (quad variant), 1, 2 or 4");
+  if (rotation_split != 0 && rotation_split != -1 && rotation_split != -2 && rotation_split != -4 && rotation_split != 1 && rotation_split != 2 &&
+      rotation_split != 4)
+    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (by size), -1 (mixed granularity), -2 (one granularity), -4 (quad variant), 1, 2 or 4");
   c->tune_sym_t = vortices_per_lane;
   c->tune_sym_rsplit = rotation_split;
   return LUDVM_OK;

@@ -51,7 +51,8 @@ struct SymArgs {
   long long i_count;     //   global tile ring (multi-GPU), or all tiles
   int ysplit;            // number of d-chunks
   int rsplit;            // 1, 2 or 4: the 64 rotation steps of a tile pair are shared by this many waves; 0: mixed --
-  int ytail;             //   the items of the last `ytail` d-chunks by 4 waves, the others by one (sym_geometry)
+  int ytail;             //   the items of the last `ytail` d-chunks by 4 waves, the others by `rbulk` (sym_geometry)
+  int rbulk;
   long long tail_items;  //   (how many single-wave items' worth of work that fine-grained end should hold)
   int diag_only;         // != 0: only the diagonal tiles (round -1 of the d-chunk-0 items): the quad variant's companion launch
   int tune_split, tune_rsplit;   // ludvm_set_tuning / ludvm_set_sym_tuning overrides (0 = heuristics), for n_dev launches
@@ -78,34 +79,36 @@ constexpr long long kSymMaxSplitTuned = 1024;      // what ludvm_set_tuning may 
 constexpr long long kXcds = 8;                        // XCDs of an MI355X: workgroup b is dispatched to XCD b % 8
 constexpr long long kSymMaxRsplit = 4;
 constexpr long long kSymMinItems = 10500;          // measured (profiles/r02_atomics_cost_and_lds_reduction.txt, table 4)
-// Mixed granularity (rsplit = 0; ludvm_set_sym_tuning(.., -1) or LUDVM_SYM_MIXED=1 -- NOT the default): a launch ends when
-// its last waves do, and with every workgroup the same size the chip drains over about one workgroup lifetime.  So the
-// items that are dispatched LAST -- those of the highest d-chunks, in every owner's order -- are worked by four waves each
-// (a quarter of the rotation steps per wave, partial sums added through LDS), the bulk before them by one wave each with
-// no barrier at all: about one chip-load of wave slots (kSymTailItems single-wave items) is kept for the fine-grained
-// end.  Which items those are is a function of the vortex count alone (their d-chunk), so the partition into partial sums
-// is the same for every owner of a sharded ring.  Measured [MI355X] (profiles/r03_mixed_granularity_negative_result.txt,
-// same box, alternating): +2-3 % at 32 768, 49 152 and 65 536 vortices, -3 % at 40 960 and 98 304, nothing from 262 144
-// up, and BASELINE config 2 as a whole 1 % SLOWER (11.03 s against 10.92 s): a four-wave item pays the partner tile's
-// load latency, two workgroup barriers and the LDS reduction for a quarter of the arithmetic, which costs what the
-// shorter drain brings.  The size-dependent one-number-per-launch rule below therefore stays the default.
-constexpr long long kSymTailItems = 3072;          // 256 CUs x 4 SIMDs x 3 waves
-struct SymGeom { long long ntiles, dmax, dtot; int ysplit, rsplit, ytail; };
+// Mixed granularity (rsplit = 0): a launch ends when its last waves do, and a launch of equal work items drains over about
+// half an item's lifetime.  So the items that are dispatched LAST -- those of the highest d-chunks, in every owner's order
+// -- are worked by four waves each (a quarter of the rotation steps per wave, partial sums added through LDS), the bulk
+// before them by as many waves per item as the size rule gives (`rbulk` = 1 or 2; where the rule gives four there is
+// nothing finer and the launch keeps one granularity).  Which items those are is a function of the vortex count alone (their
+// d-chunk), so the partition into partial sums is the same for every owner of a sharded ring.  History [MI355X]: the first
+// form (bulk always by single waves, 3072 items for the end, chunk counts that could leave the end empty) lost as often
+// as it won (profiles/r03_mixed_granularity_negative_result.txt) and was shelved; with the bulk following the rule, no empty
+// chunks and 1536 items for the end it is never slower than one granularity under sustained load and 1-5 % faster from
+// 57 000 vortices up to the quad variant's range (profiles/r03_mixed_granularity_by_rule.txt), and is the default there.
+// ludvm_set_sym_tuning(.., -1) / LUDVM_SYM_MIXED=1: at every size; -2 / LUDVM_SYM_MIXED=0: nowhere.
+constexpr long long kSymTailItems = 1536;          // (half of 256 CUs x 4 SIMDs x 3 waves: measured, see above)
+struct SymGeom { long long ntiles, dmax, dtot; int ysplit, rsplit, ytail, rbulk; };
 // XCD-local block layout of a launch over i_count I tiles: every XCD gets the same number of workgroups, sized for the
 // largest eighth; with rsplit = 0 the first nb1 workgroups of an XCD hold four single-wave items each (d-chunks below
 // ysplit - ytail), the rest one four-wave item each
 struct SymBlocks { long long nb1, total; };
-__host__ __device__ inline SymBlocks sym_blocks_xcd(long long i_count, long long ysplit, int rsplit, long long ytail) {
+__host__ __device__ inline SymBlocks sym_blocks_xcd(long long i_count, long long ysplit, int rsplit, long long ytail,
+                                                    int rbulk = 1) {
   const long long per_xcd = (i_count + kXcds - 1) / kXcds;
   if (rsplit == 0) {
-    const long long nb1 = (per_xcd * (ysplit - ytail) + 3) / 4;
+    const long long nb1 = (per_xcd * (ysplit - ytail) * rbulk + 3) / 4;     // 4 / rbulk bulk items per workgroup
     return SymBlocks{nb1, nb1 + per_xcd * ytail};
   }
   const long long ipb = 4 / rsplit;
   return SymBlocks{0, (per_xcd * ysplit + ipb - 1) / ipb};
 }
-__host__ __device__ inline long long sym_blocks(long long i_count, long long ysplit, int rsplit, long long ytail = 0) {
-  return kXcds * sym_blocks_xcd(i_count, ysplit, rsplit, ytail).total;
+__host__ __device__ inline long long sym_blocks(long long i_count, long long ysplit, int rsplit, long long ytail = 0,
+                                                int rbulk = 1) {
+  return kXcds * sym_blocks_xcd(i_count, ysplit, rsplit, ytail, rbulk).total;
 }
 
 // Tile block of owner `rank` of `world` on a ring of ntiles tiles: whole quads of 4 consecutive tiles (the quad variant of
@@ -126,7 +129,7 @@ __host__ __device__ inline void shard_block(unsigned long long ntiles, int rank,
 // costs ~100 instructions there; both give the same numbers for n < 2^31)
 template <typename I>
 __host__ __device__ inline void sym_geometry_t(I n, int T, int tune_split, int tune_rsplit, I tail_items, I& ntiles, I& dmax,
-                                               I& dtot, int& ysplit, int& rsplit, int& ytail) {
+                                               I& dtot, int& ysplit, int& rsplit, int& ytail, int& rbulk) {
   const I W = (I)(64 * T);
   ntiles = (n + W - 1) / W;
   dmax = ntiles > 0 ? (ntiles - 1) / 2 : 0;
@@ -139,8 +142,15 @@ __host__ __device__ inline void sym_geometry_t(I n, int T, int tune_split, int t
   if (ys > (I)kSymMaxSplitTuned) ys = (I)kSymMaxSplitTuned;
   if (ys > dtot) ys = dtot;
   if (ys < 1) ys = 1;
+  // no empty chunks: with `per` offsets per chunk, ceil(dtot / per) chunks cover the ring (96 offsets in 64 chunks would be 48
+  // chunks of 2 and 16 empty ones -- waves that leave at once, and a mixed launch's fine-grained end without any work)
+  if (dtot > 0) {
+    const I per0 = (dtot + ys - 1) / ys;
+    ys = (dtot + per0 - 1) / per0;
+  }
   I rs = 1;
   ytail = 0;
+  rbulk = 1;
   if (tune_rsplit == -4) {                     // the quad variant, whatever the size: single-wave geometry
     rs = 1;
   } else if (tune_rsplit == 1 || tune_rsplit == 2 || tune_rsplit == 4) {
@@ -149,8 +159,19 @@ __host__ __device__ inline void sym_geometry_t(I n, int T, int tune_split, int t
     rs = 0;
     const I yt = (tail_items + nt1 - 1) / nt1;
     ytail = (int)(yt > ys ? ys : yt);
-  } else {                                     // one granularity per launch: the smallest that gives enough work items
+    I rb = 1;                                  // the bulk before them by as many waves per item as the size rule gives
+    while (rb < (I)kSymMaxRsplit && nt1 * ys * rb < (I)kSymMinItems) rb *= 2;
+    rbulk = (int)rb;
+  } else {                                     // by size: the smallest number of waves per item that gives enough work items
     while (rs < (I)kSymMaxRsplit && nt1 * ys * rs < (I)kSymMinItems) rs *= 2;
+    // ... and, where that leaves room below four waves per item, the items dispatched last finer than the bulk (mixed
+    // granularity).  tune_rsplit = -2: one granularity per launch, as until round 3
+    if (tune_rsplit != -2 && rs < (I)kSymMaxRsplit) {
+      rbulk = (int)rs;
+      rs = 0;
+      const I yt = (tail_items + nt1 - 1) / nt1;
+      ytail = (int)(yt > ys ? ys : yt);
+    }
   }
   ysplit = (int)ys;
   rsplit = (int)rs;
@@ -158,7 +179,8 @@ __host__ __device__ inline void sym_geometry_t(I n, int T, int tune_split, int t
 __host__ __device__ inline SymGeom sym_geometry(long long n, int T, int tune_split, int tune_rsplit,
                                                  long long tail_items = kSymTailItems) {
   SymGeom g;
-  sym_geometry_t<long long>(n, T, tune_split, tune_rsplit, tail_items, g.ntiles, g.dmax, g.dtot, g.ysplit, g.rsplit, g.ytail);
+  sym_geometry_t<long long>(n, T, tune_split, tune_rsplit, tail_items, g.ntiles, g.dmax, g.dtot, g.ysplit, g.rsplit, g.ytail,
+                            g.rbulk);
   return g;
 }
 
@@ -318,13 +340,14 @@ pair_sym_f32(SymArgs a) {
   // 32 rotation steps only -- needs two 32-bit divisions instead of a dozen 64-bit ones
   unsigned n = (unsigned)a.n, ntiles = (unsigned)a.ntiles, dmax = (unsigned)a.dmax, i_first = (unsigned)a.i_first,
            i_count = (unsigned)a.i_count;
-  int ysplit = a.diag_only ? 1 : a.ysplit, ytail = a.ytail;
+  int ysplit = a.diag_only ? 1 : a.ysplit, ytail = a.ytail, rbulk = a.rbulk;
   if (a.n_dev) {
     // (the instantiation -- tile and waves-per-item rule -- is what the host chose from its bound on n)
     n = (unsigned)*a.n_dev;
     unsigned dtot_;
     int rs_;
-    sym_geometry_t<unsigned>(n, T, a.tune_split, R == 0 ? -1 : R, (unsigned)a.tail_items, ntiles, dmax, dtot_, ysplit, rs_, ytail);
+    sym_geometry_t<unsigned>(n, T, a.tune_split, R == 0 ? -1 : R, (unsigned)a.tail_items, ntiles, dmax, dtot_, ysplit, rs_, ytail,
+                             rbulk);
     i_first = 0;
     i_count = ntiles;
     if (a.shard_world > 1) {
@@ -362,28 +385,37 @@ pair_sym_f32(SymArgs a) {
   // item within the XCD, and whether this workgroup's waves share one item (wave-uniform, workgroup-uniform)
   unsigned q;
   bool active, shared;
+  int rr = RR;                             // waves of this workgroup's items
   if constexpr (R == 0) {
-    const unsigned y1 = (unsigned)(ysplit - ytail);                // d-chunks worked by single waves
-    const unsigned nb1 = (((i_count + (unsigned)kXcds - 1) / (unsigned)kXcds) * y1 + 3) / 4;      // (= sym_blocks_xcd(...).nb1)
-    shared = qb >= nb1;
-    q = shared ? x_n * y1 + (qb - nb1) : qb * kWaves + wv;
-    active = shared ? q < x_n * (unsigned)ysplit : q < x_n * y1;
+    // bulk workgroups hold 4 / rbulk items of rbulk waves each (d-chunks below ysplit - ytail), the rest one four-wave item
+    const unsigned y1 = (unsigned)(ysplit - ytail);
+    const unsigned rb = (unsigned)rbulk, ipb = (unsigned)kWaves / rb;
+    const unsigned nb1 = (((i_count + (unsigned)kXcds - 1) / (unsigned)kXcds) * y1 * rb + 3) / 4;      // (= sym_blocks_xcd(...).nb1)
+    const bool tail = qb >= nb1;
+    rr = tail ? 4 : (int)rb;
+    shared = rr > 1;
+    q = tail ? x_n * y1 + (qb - nb1) : qb * ipb + (unsigned)wv / rb;
+    active = tail ? q < x_n * (unsigned)ysplit : q < x_n * y1;
+    // a workgroup without any item leaves as a whole; so do idle single-wave items (they meet no barrier); the idle waves
+    // of a workgroup that shares items stay for its barriers
+    const bool wg_active = tail ? active : qb * ipb < x_n * y1;
+    if (!wg_active || (!shared && !active)) return;
   } else {
     shared = R > 1;
     q = qb * (kWaves / R) + wv / R;
     active = q < x_n * (unsigned)ysplit;
   }
-  const int r = shared ? wv % RR : 0;      // this wave's share of the rotation steps
+  const int r = shared ? wv % rr : 0;      // this wave's share of the rotation steps
   const int w0 = wv - r;                   // first wave of the item in the workgroup
-  // single-wave items meet no barrier, and the four waves of a shared item are active or not together: idle waves leave
-  if ((R == 0 || !RED) && !active) return;
+  // single-wave items meet no barrier: idle waves leave
+  if (R == 1 && !active) return;
   // item q of the XCD's list (d-chunk-major): d-chunk y = q / x_n of I tile x_lo + q % x_n
   const unsigned yq = active ? q / x_n : 0;
   const unsigned I = i_first + (active ? x_lo + (q - yq * x_n) : 0);
   const int y = (int)yq;
   // This wave does rotation steps [k_lo, k_hi) of every tile pair.  A J accumulator set that starts in lane l at step
   // k_lo belongs to home lane (l + k_lo) and, one lane per step, sits in lane (home - k_hi) after the last step.
-  const int ksteps = shared ? 64 / RR : 64;
+  const int ksteps = shared ? 64 / rr : 64;
   const int k_lo = r * ksteps;
   const int k_hi = k_lo + ksteps;
   constexpr unsigned W = 64u * T;
@@ -643,10 +675,11 @@ pair_sym_f32(SymArgs a) {
       if (valid) {
         // the R waves of the item share the 2 T components; each adds the R partials in wave order
 #pragma unroll 1
-        for (int c = r; c < 2 * T; c += RR) {
+        for (int c = r; c < 2 * T; c += rr) {
           float v = 0.0f;
 #pragma unroll
-          for (int q = 0; q < RR; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
+          for (int q = 0; q < RR; ++q)
+            if (R != 0 || q < rr) v += (&slab[w0 + q][0][0])[c * 64 + lane];
           const unsigned j = J * W + lane + 64u * (2 * (c / 4) + (c & 1));
           if (j < n) fx_add((c & 2) ? &a.acc_w[j] : &a.acc_u[j], -v, fxs);
         }
@@ -672,10 +705,11 @@ pair_sym_f32(SymArgs a) {
     __syncthreads();
     if (active) {
 #pragma unroll 1
-      for (int c = r; c < 2 * T; c += RR) {
+      for (int c = r; c < 2 * T; c += rr) {
         float v = 0.0f;
 #pragma unroll
-        for (int q = 0; q < RR; ++q) v += (&slab[w0 + q][0][0])[c * 64 + lane];
+        for (int q = 0; q < RR; ++q)
+          if (R != 0 || q < rr) v += (&slab[w0 + q][0][0])[c * 64 + lane];
         const unsigned i = I * W + lane + 64u * (c / 2);
         if (i < n) { fx_add((c & 1) ? &a.acc_w[i] : &a.acc_u[i], v, fxs); chk += v; }
       }

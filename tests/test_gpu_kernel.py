@@ -529,8 +529,8 @@ def test_symmetric_kernel_tile_edges(eng, n):
 def test_symmetric_tile_ring_partition(eng, ranks, n):
     """Multi-GPU building block on one GPU: the owners of the tile ring, run one after the other with
     separate accumulators, add up (integer sums: what the all-reduce does) to BIT FOR BIT the self-interaction
-    one owner of all tiles computes, and one owner's block step equals the direct advection of that block.  The three
-    largest sizes run the quad variant of the kernel (from 448 tiles: four I tiles per workgroup share each partner tile,
+    one owner of all tiles computes, and one owner's block step equals the direct advection of that block.  The two
+    largest sizes run the quad variant of the kernel (from 640 tiles: four I tiles per workgroup share each partner tile,
     J-side sums added in LDS before one atomic): owners own whole quads (LUDVM_SYM_OWNER_ALIGN)."""
     import torch
     from ludvm_amd._ffi import SYM_OWNER_ALIGN, SYM_TILE
@@ -797,9 +797,10 @@ def test_full_size_config4_self_advection_step(eng):
 @pytest.mark.parametrize("n", [16384 + 77, 50000, 150001])
 def test_symmetric_kernel_rotation_split_variants(eng, n):
     """Every tiling of the symmetric kernel (256 / 512-vortex tiles) with a tile pair's 64 rotation steps done by
-    1, 2 or 4 wavefronts, by the size rule (0, the default), or by four for the work items dispatched last and one for
-    the rest (-1: mixed granularity) (ludvm_set_sym_tuning): sampled targets against the C oracle, all vortices against
-    the direct kernel; every variant repeats bit for bit."""
+    1, 2 or 4 wavefronts, by the size rule (0, the default: the rule's number for the bulk and four for the work items
+    dispatched last -- mixed granularity -- where the rule gives fewer than four), with the mixed form at every size (-1) or
+    at none (-2) (ludvm_set_sym_tuning): sampled targets against the C oracle, all vortices against the direct kernel; every
+    variant repeats bit for bit."""
     import torch
     from ludvm_amd import LudvmHipError
     rng = np.random.default_rng(n)
@@ -826,7 +827,7 @@ def test_symmetric_kernel_rotation_split_variants(eng, n):
         ud, wd = velocities()
         eng.set_symmetric(2)
         for t in (4, 8):
-            for r in (0, -1, 1, 2, 4):
+            for r in (0, -1, -2, 1, 2, 4):
                 eng.set_sym_tuning(t, r)
                 u, w = velocities()
                 assert _rel(u[sel], w[sel], ur, wr) < 1e-5, (t, r)

@@ -11,7 +11,7 @@ rng = np.random.default_rng(12345)
 worst = 0.0
 sizes = ([16384, 16385, 16639, 16640, 40959, 40960, 40961, 41471, 41472, 98303, 98304, 98305, 98815, 98816, 99328]
          + [int(v) for v in rng.integers(16384, 100000, 40)] + [int(v) for v in rng.integers(100000, 400000, 20)])
-variants = [(0, 0), (4, -1), (8, -1), (8, -4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4)]     # (tile, waves per item; 0: size rule, -1: mixed granularity, -4: quad variant)
+variants = [(0, 0), (0, -2), (4, -1), (8, -1), (8, -4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4)]     # (tile, waves per item; 0: size rule, -1: mixed granularity at every size, -2: at none, -4: quad variant)
 worst_by = {v: 0.0 for v in variants}
 for k, n in enumerate(sizes):
     x = torch.from_numpy(rng.uniform(-10, 0, n).astype(np.float32)).to(dev)
