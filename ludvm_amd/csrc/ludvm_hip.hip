@@ -218,7 +218,8 @@ constexpr int kMaxSplit = 2048;
 // plan_nt: the target count that DECIDES the plan -- tile size, targets per lane and the split of the sources into
 // partial sums, i.e. everything the rounding of a result depends on -- when the launch itself covers only a part of a
 // larger target set (a block of rows of a flow-field grid: the block then carries the whole grid's bits); 0 = nt.
-Plan make_plan(const ludvm_ctx* c, long long nt_launch, long long ns, int precision, bool small_ok = true, long long plan_nt = 0) {
+Plan make_plan(const ludvm_ctx* c, long long nt_launch, long long ns, int precision, bool small_ok = true, long long plan_nt = 0,
+               bool grid_patch = false) {
   Plan p{};
   const long long nt = plan_nt > 0 ? plan_nt : nt_launch;
   const bool f64 = precision == LUDVM_PREC_F64;
@@ -233,7 +234,12 @@ Plan make_plan(const ludvm_ctx* c, long long nt_launch, long long ns, int precis
   }
   // the small tile exists for TPL = 1 (and for the 4-points-per-lane grid kernel, whose TPL the launch fixes itself)
   if (p.tile == kTileF32Small && (p.tpl != 1 || nt > 65536)) p.tile = kTileF32;
-  const long long ttiles = std::max<long long>(1, (nt + (long long)kBlock * p.tpl - 1) / ((long long)kBlock * p.tpl));
+  // target tiles = workgroups per source split.  The flow-field patch kernels hold 8 or 16 grid points per lane, not tpl:
+  // counted with tpl, a 4096 x 4096 grid looked like 32 768 workgroups and got ONE source split -- 4096 workgroups that
+  // each walk all the sources for a quarter of a second, and a launch that ends over half such a lifetime (config 5:
+  // 8.05e12 pairs/s with one split, 8.13e12 with four, 8.15e12 with eight [MI355X])
+  const long long per_wg = grid_patch ? (long long)kBlock * 4 * (nt >= (1LL << 20) ? 4 : 2) : (long long)kBlock * p.tpl;
+  const long long ttiles = std::max<long long>(1, (nt + per_wg - 1) / per_wg);
   const long long max_split = std::max<long long>(1, (ns + p.tile - 1) / p.tile);
   long long nsplit = c->tune_split > 0 ? c->tune_split : (kTargetBlocks + ttiles - 1) / ttiles;
   nsplit = std::max<long long>(1, std::min<long long>(std::min<long long>(nsplit, max_split), kMaxSplit));
@@ -409,7 +415,9 @@ int induce_device(ludvm_ctx* c, const PairArgs& a, long long nt, long long ns, i
     return LUDVM_OK;
   }
   const bool grid_generic = a.grid_nz > 0 && !(a.grid_nz % 4 == 0 && c->tune_tpl == 0);
-  Plan p = make_plan(c, nt, ns, precision, !grid_generic, plan_nt);
+  // (whatever form of the grid kernel runs -- LUDVM_GRID_KERNEL can force one --: the plan, and with it the bits, stays the same)
+  const bool grid_patch = a.grid_nz > 0 && !grid_generic && precision == LUDVM_PREC_F32;
+  Plan p = make_plan(c, nt, ns, precision, !grid_generic, plan_nt, grid_patch);
   CHK(launch_pair(c, a, p, precision, u, w));
   if (p.nsplit > 1) {
     if (precision == LUDVM_PREC_F64)

@@ -28,7 +28,7 @@ def cfg5(args):
     dev = torch.device("cuda", 0)
     eng = Engine(0)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.set_tuning(args.tpl, 0)      # tpl != 0 forces the generic kernel (no shared-dx grid variant)
+    eng.set_tuning(args.tpl, args.splits)      # tpl != 0 forces the generic kernel (no shared-dx grid variant); splits: source splits
     dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
     du = torch.empty(nx * nz, dtype=torch.float32, device=dev)
     dw = torch.empty_like(du)
@@ -90,6 +90,7 @@ if __name__ == "__main__":
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--tpl", type=int, default=0)
+    ap.add_argument("--splits", type=int, default=0, help="cfg5: source splits (0 = the library's rule)")
     ap.add_argument("--tf", type=float, default=50.0)
     ap.add_argument("--dt", type=float, default=1e-3, help="cfg2: time step (BASELINE config 2 uses 1e-3)")
     ap.add_argument("--precision", default="f32")
