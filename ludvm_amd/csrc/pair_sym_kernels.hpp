@@ -92,23 +92,64 @@ constexpr long long kSymMinItems = 10500;          // measured (profiles/r02_ato
 // ludvm_set_sym_tuning(.., -1) / LUDVM_SYM_MIXED=1: at every size; -2 / LUDVM_SYM_MIXED=0: nowhere.
 constexpr long long kSymTailItems = 1536;          // (half of 256 CUs x 4 SIMDs x 3 waves: measured, see above)
 struct SymGeom { long long ntiles, dmax, dtot; int ysplit, rsplit, ytail, rbulk; };
-// XCD-local block layout of a launch over i_count I tiles: every XCD gets the same number of workgroups, sized for the
-// largest eighth; with rsplit = 0 the first nb1 workgroups of an XCD hold four single-wave items each (d-chunks below
-// ysplit - ytail), the rest one four-wave item each
-struct SymBlocks { long long nb1, total; };
-__host__ __device__ inline SymBlocks sym_blocks_xcd(long long i_count, long long ysplit, int rsplit, long long ytail,
-                                                    int rbulk = 1) {
-  const long long per_xcd = (i_count + kXcds - 1) / kXcds;
-  if (rsplit == 0) {
-    const long long nb1 = (per_xcd * (ysplit - ytail) * rbulk + 3) / 4;     // 4 / rbulk bulk items per workgroup
-    return SymBlocks{nb1, nb1 + per_xcd * ytail};
+// Placement of a launch's (unit, d-chunk) work items on the 8 XCDs (unit = I tile, or quad of I tiles): workgroup b runs
+// on XCD b % 8, and for d-chunk y XCD x takes eighth (x + y) % 8 of the units.  Within a chunk an XCD works on
+// neighbouring units with the same ring offsets, i.e. overlapping partner tiles, which its L2 serves; and because the
+// eighths ROTATE with the chunk, every XCD gets the same number of items to within one unit per chunk -- with a fixed
+// eighth per XCD (rounds 2 and 3 until this) a unit count that is not a multiple of 8 left seven XCDs waiting for the
+// eighth one: 129 tiles = 7 x 16 + 17, 6 % of the launch; 489 quads (N = 1e6) = 7 x 61 + 62, 1.4 % [MI355X].
+struct XcdShare { unsigned lo, n; };
+__host__ __device__ inline XcdShare xcd_share(unsigned units, unsigned e) {
+  const unsigned lo = (unsigned)((unsigned long long)units * e / (unsigned)kXcds);
+  return XcdShare{lo, (unsigned)((unsigned long long)units * (e + 1) / (unsigned)kXcds) - lo};
+}
+// items of XCD x in chunks [y0, y0 + ny): every 8 consecutive chunks hold each unit once
+__host__ __device__ inline unsigned long long xcd_items(unsigned units, unsigned x, unsigned y0, unsigned ny) {
+  unsigned long long t = (unsigned long long)(ny / (unsigned)kXcds) * units;
+  for (unsigned j = 0; j < ny % (unsigned)kXcds; ++j) t += xcd_share(units, (x + y0 + j) % (unsigned)kXcds).n;
+  return t;
+}
+// item q of XCD x's list over chunks [y0, y0 + ny) (chunk-major): its chunk and unit; false beyond the list
+__host__ __device__ inline bool xcd_item(unsigned units, unsigned x, unsigned y0, unsigned ny, unsigned q, unsigned& y,
+                                         unsigned& unit) {
+  y = y0; unit = 0;
+  if (units == 0) return false;
+  const unsigned blk = q / units;
+  unsigned rem = q - blk * units;
+  for (unsigned j = 0; j < (unsigned)kXcds; ++j) {
+    const XcdShare s = xcd_share(units, (x + y0 + j) % (unsigned)kXcds);
+    if (rem < s.n) {
+      y = y0 + (unsigned)kXcds * blk + j;
+      unit = s.lo + rem;
+      return y < y0 + ny;
+    }
+    rem -= s.n;
   }
-  const long long ipb = 4 / rsplit;
-  return SymBlocks{0, (per_xcd * ysplit + ipb - 1) / ipb};
+  return false;
+}
+// Workgroups per XCD of a launch over i_count I tiles (the largest XCD's; surplus workgroups leave at once).  With
+// rsplit = 0 an XCD's first workgroups hold 4 / rbulk bulk items each (d-chunks below ysplit - ytail), the rest one
+// four-wave item each.
+__host__ __device__ inline long long sym_blocks_xcd(long long i_count, long long ysplit, int rsplit, long long ytail,
+                                                    int rbulk = 1) {
+  long long most = 0;
+  for (unsigned x = 0; x < (unsigned)kXcds; ++x) {
+    long long wg;
+    if (rsplit == 0) {
+      const unsigned y1 = (unsigned)(ysplit - ytail);
+      wg = ((long long)xcd_items((unsigned)i_count, x, 0, y1) * rbulk + 3) / 4 +
+           (long long)xcd_items((unsigned)i_count, x, y1, (unsigned)ytail);
+    } else {
+      const long long ipb = 4 / rsplit;
+      wg = ((long long)xcd_items((unsigned)i_count, x, 0, (unsigned)ysplit) + ipb - 1) / ipb;
+    }
+    most = wg > most ? wg : most;
+  }
+  return most;
 }
 __host__ __device__ inline long long sym_blocks(long long i_count, long long ysplit, int rsplit, long long ytail = 0,
                                                 int rbulk = 1) {
-  return kXcds * sym_blocks_xcd(i_count, ysplit, rsplit, ytail, rbulk).total;
+  return kXcds * sym_blocks_xcd(i_count, ysplit, rsplit, ytail, rbulk);
 }
 
 // Tile block of owner `rank` of `world` on a ring of ntiles tiles: whole quads of 4 consecutive tiles (the quad variant of
@@ -374,44 +415,43 @@ pair_sym_f32(SymArgs a) {
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: tile indices stay scalar
-  // XCD-aware placement.  Workgroups are dispatched to the 8 XCDs round-robin (workgroup b runs on XCD b % 8, each with its
-  // own L2): XCD x takes the x-th eighth of the launch's I tiles, for every d-chunk y, and works through its items
-  // (y-major: the diagonal-tile items first) in the order of its workgroups.  Waves that run on an XCD at the same time
-  // then hold neighbouring I tiles with the same offsets d, i.e. overlapping partner tiles J, and the L2 serves them:
-  // memory-side fetches of an N = 2^20 launch 2.04 GB -> 0.03 GB at unchanged speed (the kernel is ALU-bound;
-  // profiles/r02_xcd_aware_mapping.txt).  The items, and with them the partial sums, are the same whatever the placement.
+  // XCD-aware placement (xcd_share / xcd_item above): XCD x works through its items chunk by chunk (the diagonal-tile items
+  // first) in the order of its workgroups; waves that run on an XCD at the same time hold neighbouring I tiles with the same
+  // offsets d, i.e. overlapping partner tiles J, and the L2 serves them: memory-side fetches of an N = 2^20 launch 2.04 GB ->
+  // 0.03 GB at unchanged speed (the kernel is ALU-bound; profiles/r02_xcd_aware_mapping.txt).  The items, and with them the
+  // partial sums, are the same whatever the placement.
   const unsigned xcd = blockIdx.x % (unsigned)kXcds, qb = blockIdx.x / (unsigned)kXcds;
-  const unsigned x_lo = i_count * xcd / (unsigned)kXcds, x_n = i_count * (xcd + 1) / (unsigned)kXcds - x_lo;   // this XCD's I tiles
   // item within the XCD, and whether this workgroup's waves share one item (wave-uniform, workgroup-uniform)
-  unsigned q;
+  unsigned yq = 0, unit = 0;
   bool active, shared;
   int rr = RR;                             // waves of this workgroup's items
   if constexpr (R == 0) {
     // bulk workgroups hold 4 / rbulk items of rbulk waves each (d-chunks below ysplit - ytail), the rest one four-wave item
     const unsigned y1 = (unsigned)(ysplit - ytail);
     const unsigned rb = (unsigned)rbulk, ipb = (unsigned)kWaves / rb;
-    const unsigned nb1 = (((i_count + (unsigned)kXcds - 1) / (unsigned)kXcds) * y1 * rb + 3) / 4;      // (= sym_blocks_xcd(...).nb1)
+    const unsigned n_bulk = (unsigned)xcd_items(i_count, xcd, 0, y1);
+    const unsigned nb1 = (n_bulk * rb + 3) / 4;                    // this XCD's bulk workgroups
     const bool tail = qb >= nb1;
     rr = tail ? 4 : (int)rb;
     shared = rr > 1;
-    q = tail ? x_n * y1 + (qb - nb1) : qb * ipb + (unsigned)wv / rb;
-    active = tail ? q < x_n * (unsigned)ysplit : q < x_n * y1;
+    const unsigned q = tail ? qb - nb1 : qb * ipb + (unsigned)wv / rb;
+    active = tail ? xcd_item(i_count, xcd, y1, (unsigned)ytail, q, yq, unit)
+                  : (q < n_bulk && xcd_item(i_count, xcd, 0, y1, q, yq, unit));
     // a workgroup without any item leaves as a whole; so do idle single-wave items (they meet no barrier); the idle waves
     // of a workgroup that shares items stay for its barriers
-    const bool wg_active = tail ? active : qb * ipb < x_n * y1;
+    const bool wg_active = tail ? active : qb * ipb < n_bulk;
     if (!wg_active || (!shared && !active)) return;
   } else {
     shared = R > 1;
-    q = qb * (kWaves / R) + wv / R;
-    active = q < x_n * (unsigned)ysplit;
+    const unsigned q = qb * (kWaves / R) + wv / R;
+    active = xcd_item(i_count, xcd, 0, (unsigned)ysplit, q, yq, unit);
   }
   const int r = shared ? wv % rr : 0;      // this wave's share of the rotation steps
   const int w0 = wv - r;                   // first wave of the item in the workgroup
   // single-wave items meet no barrier: idle waves leave
   if (R == 1 && !active) return;
-  // item q of the XCD's list (d-chunk-major): d-chunk y = q / x_n of I tile x_lo + q % x_n
-  const unsigned yq = active ? q / x_n : 0;
-  const unsigned I = i_first + (active ? x_lo + (q - yq * x_n) : 0);
+  if (!active) { yq = 0; unit = 0; }
+  const unsigned I = i_first + unit;
   const int y = (int)yq;
   // This wave does rotation steps [k_lo, k_hi) of every tile pair.  A J accumulator set that starts in lane l at step
   // k_lo belongs to home lane (l + k_lo) and, one lane per step, sits in lane (home - k_hi) after the last step.
@@ -788,8 +828,13 @@ __host__ __device__ inline void quad_chunk(const QuadGeom& g, unsigned yq, int& 
 // workgroups of a quad launch over I tiles [i_first, i_first + i_count) (i_first a multiple of 4): one per (quad, d-chunk),
 // the same number for each XCD
 __host__ __device__ inline long long quad_blocks(long long i_count, int ysplit) {
-  const long long quads = (i_count + kQuad - 1) / kQuad, per_xcd = (quads + kXcds - 1) / kXcds;
-  return kXcds * per_xcd * ysplit;
+  const unsigned quads = (unsigned)((i_count + kQuad - 1) / kQuad);
+  long long most = 0;
+  for (unsigned x = 0; x < (unsigned)kXcds; ++x) {
+    const long long wg = (long long)xcd_items(quads, x, 0, (unsigned)ysplit);
+    most = wg > most ? wg : most;
+  }
+  return kXcds * most;
 }
 
 template <int T>
@@ -827,10 +872,9 @@ pair_sym_quad_f32(SymArgs a) {
   // XCD-aware placement over quads (as pair_sym_f32 over tiles): one workgroup per (quad, d-chunk)
   const unsigned xcd = blockIdx.x % (unsigned)kXcds, qb = blockIdx.x / (unsigned)kXcds;
   const unsigned quads = (i_count + kQuad - 1) / kQuad;
-  const unsigned x_lo = quads * xcd / (unsigned)kXcds, x_n = quads * (xcd + 1) / (unsigned)kXcds - x_lo;
-  if (qb >= x_n * (unsigned)gm.ysplit) return;                 // (the whole workgroup)
-  const unsigned yq = qb / x_n;
-  const unsigned I0 = i_first + kQuad * (x_lo + (qb - yq * x_n));
+  unsigned yq, quad;
+  if (!xcd_item(quads, xcd, 0, (unsigned)gm.ysplit, qb, yq, quad)) return;     // (the whole workgroup)
+  const unsigned I0 = i_first + kQuad * quad;
   const unsigned I = I0 + (unsigned)wv;
   const bool mine = I < i_first + i_count && I < ntiles;       // this wave's tile exists and is this owner's
   int D_lo, D_hi;
