@@ -45,6 +45,7 @@ struct ludvm_ctx {
   int tune_split = 0;
   int sym_mode = 1;
   int tune_sym_t = 0, tune_sym_rsplit = 0;   // ludvm_set_sym_tuning (0 = heuristics)
+  int xcd_run = 0;                           // chunks per run of the XCD placement (LUDVM_XCD_RUN; 0 = a launch's chunks / 8)
   long long sym_tail_items = kSymTailItems;  // mixed granularity: work kept for the fine-grained end (LUDVM_SYM_TAIL_ITEMS)
   int grid_kernel = 2;                       // flow-field grids (LUDVM_GRID_KERNEL): 1 = 4 points of a row per lane; 2 = patch,
                                              // 4 x 4 from 2^20 grid points and 2 x 4 below; 3 / 4 = always the 2 x 4 / 4 x 4 patch
@@ -499,18 +500,19 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
   a.rsplit = gm.rsplit;
   a.ytail = gm.ytail;
   a.rbulk = gm.rbulk;
+  a.xcd_run = c->xcd_run;
   a.acc_u = o.acc_u;
   a.acc_w = o.acc_w;
   a.scale = o.scale;
   a.bad = o.bad;
   a.vc4 = (float)vc4;
   // workgroups: 4 / rsplit items (tile, d-chunk) each
-  long long blocks = sym_blocks(i_count, gm.ysplit, gm.rsplit, gm.ytail, gm.rbulk);
+  long long blocks = sym_blocks(i_count, gm.ysplit, gm.rsplit, gm.ytail, gm.rbulk, c->xcd_run);
   if (n_dev) {
     const long long W = 64LL * T;
     for (long long nt = std::max<long long>(1, (std::max<long long>(n_lo, 1) + W - 1) / W); nt <= gm.ntiles; ++nt) {
       const SymGeom q = sym_geometry(nt * W, T, a.tune_split, gm.rsplit == 0 ? -1 : gm.rsplit, a.tail_items);    // the waves-per-item rule fixed by the bound: it picks the kernel
-      blocks = std::max(blocks, sym_blocks(q.ntiles, q.ysplit, gm.rsplit, q.ytail, q.rbulk));
+      blocks = std::max(blocks, sym_blocks(q.ntiles, q.ysplit, gm.rsplit, q.ytail, q.rbulk, c->xcd_run));
     }
   }
   if (!n_dev && i_count == 0) return LUDVM_OK;     // an owner without tiles (fewer tiles than owners)
@@ -529,14 +531,14 @@ int launch_sym_tiles(ludvm_ctx* c, int T, const SymOperands& o, long long n, lon
     CHK(timed_begin(c, tq, act));
     SymArgs d = a;
     d.diag_only = 1;
-    const long long dblocks = std::max<long long>(1, sym_blocks(n_dev ? gm.ntiles : i_count, 1, 1));
+    const long long dblocks = std::max<long long>(1, sym_blocks(n_dev ? gm.ntiles : i_count, 1, 1, 0, 1, c->xcd_run));
     hipLaunchKernelGGL((pair_sym_f32<8, false, 1>), dim3((unsigned)dblocks), dim3(kBlock), 0, c->stream, d);
     const QuadGeom qg = quad_geometry<long long>(n, 8, a.tune_split);
-    long long qblocks = quad_blocks(n_dev ? gm.ntiles : i_count, qg.ysplit);
+    long long qblocks = quad_blocks(n_dev ? gm.ntiles : i_count, qg.ysplit, c->xcd_run);
     if (n_dev) {      // the device derives the chunks from its own vortex count: cover every count the bounds allow
       const long long W = 64LL * 8;
       for (long long nt = std::max<long long>(1, (std::max<long long>(n_lo, 1) + W - 1) / W); nt < gm.ntiles; ++nt)
-        qblocks = std::max(qblocks, quad_blocks(nt, quad_geometry<long long>(nt * W, 8, a.tune_split).ysplit));
+        qblocks = std::max(qblocks, quad_blocks(nt, quad_geometry<long long>(nt * W, 8, a.tune_split).ysplit, c->xcd_run));
     }
     hipLaunchKernelGGL((pair_sym_quad_f32<8>), dim3((unsigned)std::max<long long>(qblocks, 1)), dim3(kBlock), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
@@ -798,6 +800,7 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
   if (const char* fp = std::getenv("LUDVM_FEW_PACKED")) c->few_packed = !(fp[0] == '0');
   if (const char* sq = std::getenv("LUDVM_SYM_QUAD")) c->sym_quad = !(sq[0] == '0');
   if (const char* sq = std::getenv("LUDVM_SYM_QUAD_MIN_TILES")) c->sym_quad_min_tiles = std::max<long long>(16, std::atoll(sq));
+  if (const char* xr = std::getenv("LUDVM_XCD_RUN")) c->xcd_run = std::max(0, std::atoi(xr));
   if (const char* ti = std::getenv("LUDVM_SYM_TAIL_ITEMS")) c->sym_tail_items = std::max<long long>(0, std::atoll(ti));
   if (const char* mx = std::getenv("LUDVM_SYM_MIXED")) {        // 1: mixed granularity at every size; 0: at none (A/B measurements)
     if (mx[0] == '1') c->tune_sym_rsplit = -1;

@@ -53,6 +53,7 @@ struct SymArgs {
   int rsplit;            // 1, 2 or 4: the 64 rotation steps of a tile pair are shared by this many waves; 0: mixed --
   int ytail;             //   the items of the last `ytail` d-chunks by 4 waves, the others by `rbulk` (sym_geometry)
   int rbulk;
+  int xcd_run;           // chunks per run of the XCD placement (0: ceil(chunks / 8); xcd_share / xcd_item)
   long long tail_items;  //   (how many single-wave items' worth of work that fine-grained end should hold)
   int diag_only;         // != 0: only the diagonal tiles (round -1 of the d-chunk-0 items): the quad variant's companion launch
   int tune_split, tune_rsplit;   // ludvm_set_tuning / ludvm_set_sym_tuning overrides (0 = heuristics), for n_dev launches
@@ -93,37 +94,52 @@ constexpr long long kSymMinItems = 10500;          // measured (profiles/r02_ato
 constexpr long long kSymTailItems = 1536;          // (half of 256 CUs x 4 SIMDs x 3 waves: measured, see above)
 struct SymGeom { long long ntiles, dmax, dtot; int ysplit, rsplit, ytail, rbulk; };
 // Placement of a launch's (unit, d-chunk) work items on the 8 XCDs (unit = I tile, or quad of I tiles): workgroup b runs
-// on XCD b % 8, and for d-chunk y XCD x takes eighth (x + y) % 8 of the units.  Within a chunk an XCD works on
-// neighbouring units with the same ring offsets, i.e. overlapping partner tiles, which its L2 serves; and because the
-// eighths ROTATE with the chunk, every XCD gets the same number of items to within one unit per chunk -- with a fixed
-// eighth per XCD (rounds 2 and 3 until this) a unit count that is not a multiple of 8 left seven XCDs waiting for the
-// eighth one: 129 tiles = 7 x 16 + 17, 6 % of the launch; 489 quads (N = 1e6) = 7 x 61 + 62, 1.4 % [MI355X].
+// on XCD b % 8.  The launch's `ys` d-chunks are cut into at most 8 RUNS of K = ceil(ys / 8) consecutive chunks, and in run r
+// XCD x takes eighth (x + r) % 8 of the units.  Within a run an XCD works on neighbouring units whose ring offsets grow
+// chunk by chunk, i.e. on overlapping partner tiles, which its L2 serves (round 2's point: memory-side fetches 2 GB ->
+// 0.03 GB per N = 2^20 launch); and because the eighths ROTATE from run to run, every XCD meets every eighth once: all get
+// the same number of items to within K - 1.  With a fixed eighth per XCD (rounds 2 and 3 until this) a unit count that is
+// not a multiple of 8 left seven XCDs waiting for the eighth one: 129 tiles = 7 x 16 + 17, 6 % of the launch; 489 quads
+// (N = 1e6) = 7 x 61 + 62, 1.4 % [MI355X].  (Rotating with EVERY chunk balances to within one item, and was measured
+// first: same speed, but every chunk then meets new partner tiles: 1.0 GB of fetches per N = 1e6 launch instead of 0.03.)
 struct XcdShare { unsigned lo, n; };
 __host__ __device__ inline XcdShare xcd_share(unsigned units, unsigned e) {
   const unsigned lo = (unsigned)((unsigned long long)units * e / (unsigned)kXcds);
   return XcdShare{lo, (unsigned)((unsigned long long)units * (e + 1) / (unsigned)kXcds) - lo};
 }
-// items of XCD x in chunks [y0, y0 + ny): every 8 consecutive chunks hold each unit once
-__host__ __device__ inline unsigned long long xcd_items(unsigned units, unsigned x, unsigned y0, unsigned ny) {
-  unsigned long long t = (unsigned long long)(ny / (unsigned)kXcds) * units;
-  for (unsigned j = 0; j < ny % (unsigned)kXcds; ++j) t += xcd_share(units, (x + y0 + j) % (unsigned)kXcds).n;
+__host__ __device__ inline unsigned xcd_run(unsigned ys, int k) {
+  return k > 0 ? (unsigned)k : (ys > 0 ? (ys + (unsigned)kXcds - 1) / (unsigned)kXcds : 1);
+}
+// items of XCD x in chunks [y0, y0 + ny) of a launch of ys chunks
+__host__ __device__ inline unsigned long long xcd_items(unsigned units, unsigned ys, unsigned x, unsigned y0, unsigned ny,
+                                                         int k = 0) {
+  const unsigned K = xcd_run(ys, k);
+  unsigned long long t = 0;
+  for (unsigned y = y0; y < y0 + ny;) {
+    const unsigned r = y / K, y_end = (r + 1) * K < y0 + ny ? (r + 1) * K : y0 + ny;
+    t += (unsigned long long)xcd_share(units, (x + r) % (unsigned)kXcds).n * (y_end - y);
+    y = y_end;
+  }
   return t;
 }
-// item q of XCD x's list over chunks [y0, y0 + ny) (chunk-major): its chunk and unit; false beyond the list
-__host__ __device__ inline bool xcd_item(unsigned units, unsigned x, unsigned y0, unsigned ny, unsigned q, unsigned& y,
-                                         unsigned& unit) {
-  y = y0; unit = 0;
-  if (units == 0) return false;
-  const unsigned blk = q / units;
-  unsigned rem = q - blk * units;
-  for (unsigned j = 0; j < (unsigned)kXcds; ++j) {
-    const XcdShare s = xcd_share(units, (x + y0 + j) % (unsigned)kXcds);
-    if (rem < s.n) {
-      y = y0 + (unsigned)kXcds * blk + j;
-      unit = s.lo + rem;
-      return y < y0 + ny;
+// item q of XCD x's list over chunks [y0, y0 + ny) (run by run, chunk-major within a run): its chunk and unit; false
+// beyond the list
+__host__ __device__ inline bool xcd_item(unsigned units, unsigned ys, unsigned x, unsigned y0, unsigned ny, unsigned q,
+                                         unsigned& y_out, unsigned& unit, int k = 0) {
+  const unsigned K = xcd_run(ys, k);
+  y_out = y0; unit = 0;
+  for (unsigned y = y0; y < y0 + ny;) {
+    const unsigned r = y / K, y_end = (r + 1) * K < y0 + ny ? (r + 1) * K : y0 + ny;
+    const XcdShare s = xcd_share(units, (x + r) % (unsigned)kXcds);
+    const unsigned cnt = s.n * (y_end - y);
+    if (q < cnt) {               // (s.n > 0 here)
+      const unsigned c = q / s.n;
+      y_out = y + c;
+      unit = s.lo + (q - c * s.n);
+      return true;
     }
-    rem -= s.n;
+    q -= cnt;
+    y = y_end;
   }
   return false;
 }
@@ -131,25 +147,25 @@ __host__ __device__ inline bool xcd_item(unsigned units, unsigned x, unsigned y0
 // rsplit = 0 an XCD's first workgroups hold 4 / rbulk bulk items each (d-chunks below ysplit - ytail), the rest one
 // four-wave item each.
 __host__ __device__ inline long long sym_blocks_xcd(long long i_count, long long ysplit, int rsplit, long long ytail,
-                                                    int rbulk = 1) {
+                                                    int rbulk = 1, int k = 0) {
   long long most = 0;
   for (unsigned x = 0; x < (unsigned)kXcds; ++x) {
     long long wg;
     if (rsplit == 0) {
       const unsigned y1 = (unsigned)(ysplit - ytail);
-      wg = ((long long)xcd_items((unsigned)i_count, x, 0, y1) * rbulk + 3) / 4 +
-           (long long)xcd_items((unsigned)i_count, x, y1, (unsigned)ytail);
+      wg = ((long long)xcd_items((unsigned)i_count, (unsigned)ysplit, x, 0, y1, k) * rbulk + 3) / 4 +
+           (long long)xcd_items((unsigned)i_count, (unsigned)ysplit, x, y1, (unsigned)ytail, k);
     } else {
       const long long ipb = 4 / rsplit;
-      wg = ((long long)xcd_items((unsigned)i_count, x, 0, (unsigned)ysplit) + ipb - 1) / ipb;
+      wg = ((long long)xcd_items((unsigned)i_count, (unsigned)ysplit, x, 0, (unsigned)ysplit, k) + ipb - 1) / ipb;
     }
     most = wg > most ? wg : most;
   }
   return most;
 }
 __host__ __device__ inline long long sym_blocks(long long i_count, long long ysplit, int rsplit, long long ytail = 0,
-                                                int rbulk = 1) {
-  return kXcds * sym_blocks_xcd(i_count, ysplit, rsplit, ytail, rbulk);
+                                                int rbulk = 1, int k = 0) {
+  return kXcds * sym_blocks_xcd(i_count, ysplit, rsplit, ytail, rbulk, k);
 }
 
 // Tile block of owner `rank` of `world` on a ring of ntiles tiles: whole quads of 4 consecutive tiles (the quad variant of
@@ -429,14 +445,14 @@ pair_sym_f32(SymArgs a) {
     // bulk workgroups hold 4 / rbulk items of rbulk waves each (d-chunks below ysplit - ytail), the rest one four-wave item
     const unsigned y1 = (unsigned)(ysplit - ytail);
     const unsigned rb = (unsigned)rbulk, ipb = (unsigned)kWaves / rb;
-    const unsigned n_bulk = (unsigned)xcd_items(i_count, xcd, 0, y1);
+    const unsigned n_bulk = (unsigned)xcd_items(i_count, (unsigned)ysplit, xcd, 0, y1, a.xcd_run);
     const unsigned nb1 = (n_bulk * rb + 3) / 4;                    // this XCD's bulk workgroups
     const bool tail = qb >= nb1;
     rr = tail ? 4 : (int)rb;
     shared = rr > 1;
     const unsigned q = tail ? qb - nb1 : qb * ipb + (unsigned)wv / rb;
-    active = tail ? xcd_item(i_count, xcd, y1, (unsigned)ytail, q, yq, unit)
-                  : (q < n_bulk && xcd_item(i_count, xcd, 0, y1, q, yq, unit));
+    active = tail ? xcd_item(i_count, (unsigned)ysplit, xcd, y1, (unsigned)ytail, q, yq, unit, a.xcd_run)
+                  : (q < n_bulk && xcd_item(i_count, (unsigned)ysplit, xcd, 0, y1, q, yq, unit, a.xcd_run));
     // a workgroup without any item leaves as a whole; so do idle single-wave items (they meet no barrier); the idle waves
     // of a workgroup that shares items stay for its barriers
     const bool wg_active = tail ? active : qb * ipb < n_bulk;
@@ -444,7 +460,7 @@ pair_sym_f32(SymArgs a) {
   } else {
     shared = R > 1;
     const unsigned q = qb * (kWaves / R) + wv / R;
-    active = xcd_item(i_count, xcd, 0, (unsigned)ysplit, q, yq, unit);
+    active = xcd_item(i_count, (unsigned)ysplit, xcd, 0, (unsigned)ysplit, q, yq, unit, a.xcd_run);
   }
   const int r = shared ? wv % rr : 0;      // this wave's share of the rotation steps
   const int w0 = wv - r;                   // first wave of the item in the workgroup
@@ -827,11 +843,11 @@ __host__ __device__ inline void quad_chunk(const QuadGeom& g, unsigned yq, int& 
 }
 // workgroups of a quad launch over I tiles [i_first, i_first + i_count) (i_first a multiple of 4): one per (quad, d-chunk),
 // the same number for each XCD
-__host__ __device__ inline long long quad_blocks(long long i_count, int ysplit) {
+__host__ __device__ inline long long quad_blocks(long long i_count, int ysplit, int k = 0) {
   const unsigned quads = (unsigned)((i_count + kQuad - 1) / kQuad);
   long long most = 0;
   for (unsigned x = 0; x < (unsigned)kXcds; ++x) {
-    const long long wg = (long long)xcd_items(quads, x, 0, (unsigned)ysplit);
+    const long long wg = (long long)xcd_items(quads, (unsigned)ysplit, x, 0, (unsigned)ysplit, k);
     most = wg > most ? wg : most;
   }
   return kXcds * most;
@@ -873,7 +889,7 @@ pair_sym_quad_f32(SymArgs a) {
   const unsigned xcd = blockIdx.x % (unsigned)kXcds, qb = blockIdx.x / (unsigned)kXcds;
   const unsigned quads = (i_count + kQuad - 1) / kQuad;
   unsigned yq, quad;
-  if (!xcd_item(quads, xcd, 0, (unsigned)gm.ysplit, qb, yq, quad)) return;     // (the whole workgroup)
+  if (!xcd_item(quads, (unsigned)gm.ysplit, xcd, 0, (unsigned)gm.ysplit, qb, yq, quad, a.xcd_run)) return;     // (the whole workgroup)
   const unsigned I0 = i_first + kQuad * quad;
   const unsigned I = I0 + (unsigned)wv;
   const bool mine = I < i_first + i_count && I < ntiles;       // this wave's tile exists and is this owner's
