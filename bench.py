@@ -55,12 +55,12 @@ PMC_TRAFFIC_CFG3 = {
                                                       "source": "profiles/r01_bench_cfg3_direct_pmc_{fetch,write}.csv"},
     # Round 3's kernel at this size: the quad variant (four I tiles of a workgroup share each partner tile: one fixed-point
     # atomic per J vortex and workgroup instead of one per wave) + a launch of the plain kernel for the diagonal tiles.
-    # 2 x FETCH_SIZE (29 455 + 5 999) KB (gfx950 tallies the 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section)
+    # 2 x FETCH_SIZE (105 633 + 6 009) KB (gfx950 tallies the 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section)
     # + WRITE_SIZE (6.045e6 + 16 602) KB (exact for stores and 8-byte atomics: 1.024e8 + 2.8e5 64-B atomic requests,
     # memory-side, mostly Infinity-Cache resident: the accumulators are 16 MB); round 2 / early round 3 (one atomic per
     # wave and tile pair): 2 x 29 474 + 1.727e7 KB.
     "ludvm::pair_sym_quad_f32<8> (+ pair_sym_f32<8> on the diagonal tiles), fixed-point accumulation": {
-        "bytes": (2 * (29455.0 + 5999.0) + 6045034.0 + 16602.0) * 1024,
+        "bytes": (2 * (105633.0 + 6009.0) + 6045034.0 + 16602.0) * 1024,
         "source": "profiles/r03_final_bench_cfg3_sym_pmc_{fetch,write}.csv"},
 }
 V_CORE = 0.065
