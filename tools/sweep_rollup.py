@@ -22,6 +22,8 @@ fx, fz, fg = np.linspace(-30.9, -30.0, 80), np.zeros(80), rng.standard_normal(80
 for n in sizes:
     x = -30.0 + np.sort(rng.uniform(0, 1e-3 * n, n))
     z = 0.3 * np.sin(0.7 * x) + 1e-3 * rng.standard_normal(n)
+    if os.environ.get("SWEEP_CLOUD"):          # a random cloud instead of a sheet (same arithmetic, other operand bits)
+        x, z = rng.uniform(2.0, 12.0, n), rng.uniform(-1.5, 1.5, n)
     g = rng.standard_normal(n) * 1e-3
     res = {"n": n}
     for mode, mname in ((2, "sym"),) + (() if os.environ.get("SWEEP_SYM_ONLY") else ((0, "direct"),)):
