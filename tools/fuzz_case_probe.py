@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """One configuration of tools/fuzz_march.py looked at closely: distance of every fp32 path from the float64 run per window of
 steps (march overlapped / march serial / per-step path, fp32 on local origins and hi+lo).  Run on the GPU box.
-    python tools/fuzz_case_probe.py   (the seed-9 / case-0 configuration of profiles/r02_fuzz_final_code.txt)"""
+    python tools/fuzz_case_probe.py   (the seed-9 / case-0 configuration of profiles/r02_fuzz_final_code.txt)
+    FUZZ_CASE_KW="$(cat tests/tools/cases/fuzz_march_seed4_case4.json)" python tools/fuzz_case_probe.py   (another configuration:
+    the one analysed in profiles/r03_fuzz_final_code.txt)"""
 import json
 import os
 import subprocess
