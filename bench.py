@@ -20,6 +20,19 @@ run-to-run spread; they also keep the GPU busy long enough for a 5-second utilis
 N = 1, --cfg4-steps steps of config 4's workload (N = 8e6) on the one GPU, reported as `config4_one_gpu`: the
 same-work reference point for the N = 2, 4, 8 lines (`value` stays config 3's).
 
+Config 4 (every N > 1 run) is a self-checking measurement, because nobody gets to debug it on the 8-GPU node:
+  * `config.collective_ms_per_rank` beside `config.pair_kernel_ms_per_rank` (HIP events on the launch stream around the
+    collective alone: transfer + wait for the slowest rank's kernel), with max / mean of both;
+  * after the timed region the OTHER step variant runs too -- `symmetric_variant` (one all-reduce of the fixed-point sums,
+    the default) and `direct_variant` (the north star's wording: targets in blocks + one all-gather of the positions) are
+    both in the one line, each with value / ms_per_step / kernel and collective ms per rank;
+  * `result_check` (outside every timed region), per variant: one more step with a power-of-two dt of 2^16, so that the
+    displacement IS the velocity to 1e-7 -- (a) every rank's positions reduced to a 64-bit checksum and compared across
+    ranks (`ranks_agree`), (b) 256 sampled displacements of rank 0 against the float64 C oracle on the positions before
+    that step (`gpu_vs_oracle_max_rel_err`, relative to max|u|).
+  * a time budget (--budget-s, default 300 s of wall time for the whole process): the repeats and the other variant's
+    step count shrink to fit (N = 2 steps take 3.5 s / 5.5 s each); what was run is stated (`steps`).
+
 The collective of the N > 1 step is issued INSIDE libludvm_hip.so on its own RCCL communicator (ludvm_comm_*;
 --collectives library, the default on the nccl backend; torch.distributed only ships the 128-byte identifier and does
 the barrier / max-over-ranks of the contract) or by torch.distributed (--collectives torch; gloo rehearsals).
@@ -96,6 +109,89 @@ def cpu_baseline(x, z, g, rows, budget_s):
     return rec, u[:done], w[:done]
 
 
+CHECK_DT = 65536.0     # 2^16: dt * u is exact, and |dt u| ~ 1 dwarfs the rounding of x + dt u (half an ulp of x ~ 5e-7)
+CHECK_SAMPLES = 256
+
+
+def check_wake(wake, g, rank, torch):
+    """Result check of a config-4 wake, outside every timed region (the oracle as the CHECKER, like the cpu_baseline leg's
+    gpu_vs_oracle_max_rel_err): one more step with dt = 2^16 -- u ~ 2e-5 at N = 8e6, so with the run's dt = 0.05 a
+    displacement is one ulp of x and says nothing; with 2^16 it is the velocity to 1e-7 of max|u| -- then
+      ranks_agree: every rank's positions as 64-bit checksums, before and after that step, equal on all ranks;
+      gpu_vs_oracle_max_rel_err (rank 0): 256 sampled displacements / dt against the float64 C oracle
+      (oracle/pair_oracle.c restating LUDVM.py:549-570) on the positions before the step, relative to max|u|."""
+    rec = {"check_dt": CHECK_DT, "samples": CHECK_SAMPLES}
+    try:
+        n = wake.n
+        before = wake.gather_checksums()
+        x0, z0 = wake.xs[:n].clone(), wake.zs[:n].clone()
+        dt_run, wake.dt = wake.dt, CHECK_DT
+        try:
+            wake.step()
+        finally:
+            wake.dt = dt_run
+        torch.cuda.synchronize()
+        after = wake.gather_checksums()
+        rec["ranks_agree"] = all(c == before[0] for c in before) and all(c == after[0] for c in after)
+        rec["checksum"] = [f"{v & 0xFFFFFFFFFFFFFFFF:016x}" for v in after[0]]
+        if rank == 0:
+            from oracle import c_oracle          # the checker; never the thing measured
+            idx = np.sort(np.random.default_rng(4).choice(n, size=min(CHECK_SAMPLES, n), replace=False))
+            ti = torch.from_numpy(idx).to(wake.xs.device)
+            x0h, z0h = x0.cpu().numpy().astype(np.float64), z0.cpu().numpy().astype(np.float64)
+            ug = (wake.xs[:n][ti].cpu().numpy().astype(np.float64) - x0h[idx]) / CHECK_DT
+            wg = (wake.zs[:n][ti].cpu().numpy().astype(np.float64) - z0h[idx]) / CHECK_DT
+            t0 = time.perf_counter()
+            uo, wo = c_oracle.induced_velocity(np.asarray(g, dtype=np.float64), x0h, z0h, x0h[idx], z0h[idx], wake.v_core)
+            scale = max(np.abs(uo).max(), np.abs(wo).max())
+            err = max(np.abs(ug - uo).max(), np.abs(wg - wo).max()) / scale
+            rec.update(gpu_vs_oracle_max_rel_err=float(err) if np.isfinite(err) else None, max_abs_u=float(scale),
+                       finite=bool(np.isfinite(ug).all() and np.isfinite(wg).all()),
+                       oracle_s=time.perf_counter() - t0, oracle_threads=c_oracle.threads())
+    except Exception as e:       # noqa: BLE001  (a failed check is reported, it does not take the measurement with it)
+        rec["error"] = f"{type(e).__name__}: {e}"
+    return rec
+
+
+def join_library_communicator(eng, rank, world, device, backend, dist, torch):
+    """The engine's own communicator: rank 0's identifier goes round through torch (any channel would do); its sharding of
+    resident-wake roll-ups is switched off (min_vortices), ShardedWake hands out the tile blocks itself.  If librccl cannot
+    be opened (every rank fails alike, before any collective), torch's collectives take over.  -> (collectives, note)"""
+    try:
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+    except Exception as e:       # noqa: BLE001
+        uid = [None]
+        note = f"library communicator unavailable on rank 0 ({e}); torch.distributed collectives used"
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0, device=device if backend == "nccl" else None)
+    if uid[0] is None:
+        return "torch", (note if rank == 0 else "library communicator unavailable on rank 0; torch.distributed collectives used")
+    # join, then prove the communicator on a known sum before the steps depend on it; the ranks agree on the outcome through
+    # torch (one rank falling back alone would leave the others inside a collective)
+    ok, why = 1, ""
+    try:
+        eng.comm_init(rank, world, uid[0], min_vortices=1 << 62)
+        chk = torch.arange(1, 9, dtype=torch.int64, device=device) * (rank + 1)
+        torch.cuda.synchronize()
+        eng.comm_allreduce_i64_dev(chk.data_ptr(), chk.numel())
+        torch.cuda.synchronize()
+        want = torch.arange(1, 9, dtype=torch.int64) * (world * (world + 1) // 2)
+        if not torch.equal(chk.cpu(), want):
+            ok, why = 0, "wrong sum from the library's all-reduce"
+    except Exception as e:       # noqa: BLE001
+        ok, why = 0, str(e)
+    flag = torch.tensor([ok], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        try:
+            eng.comm_destroy()
+        except Exception:       # noqa: BLE001
+            pass
+        return "torch", f"library communicator not usable ({why or 'another rank failed'}); torch.distributed collectives used"
+    return "library", None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,9 +208,16 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="further timed regions of --steps steps after the reported one")
     ap.add_argument("--collectives", choices=["auto", "torch", "library"], default="auto",
                     help="N > 1: who issues the step's collective -- the library's own RCCL communicator (default on nccl) or torch.distributed")
+    ap.add_argument("--budget-s", type=float, default=300.0,
+                    help="config 4: wall-time budget of the whole process; repeats and the other variant's steps shrink to fit")
+    ap.add_argument("--other-variant", type=int, choices=[0, 1], default=1,
+                    help="config 4: also time the other step variant (direct <-> symmetric) after the reported one")
+    ap.add_argument("--check", type=int, choices=[0, 1], default=1,
+                    help="config 4: result check after the timed regions (cross-rank checksum + sampled oracle check)")
     ap.add_argument("--cfg4-steps", type=int, default=2,
                     help="N = 1: steps of config 4's workload (N = 8e6, ~7 s each) timed on the one GPU after the config-3 run (0 = skip)")
     args = ap.parse_args()
+    t_process = time.perf_counter()
 
     # stdout carries exactly ONE line, the JSON.  Libraries write there too (RCCL prints a version banner when a
     # communicator is created, gloo likewise), so file descriptor 1 is pointed at stderr for the whole run and the
@@ -177,7 +280,62 @@ def main():
     # the symmetric kernel serves self-interaction launches (configs 3 and 4)
     symmetric = bool(args.symmetric) and n >= 16384
     variant = "symmetric" if symmetric else "direct"
-    coll = coll_note = None
+    scaling = "strong"
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def over_ranks(v, op="max"):
+        """One number agreed by all ranks (decisions about step counts must be the same everywhere)."""
+        if world == 1:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def per_rank(v):
+        if world == 1:
+            return [float(v)]
+        allv = torch.zeros([world], dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allv, torch.tensor([float(v)], dtype=torch.float64, device=device))
+        return [float(q) for q in allv.cpu()]
+
+    def timed_region(step_fn, steps, wake=None):
+        eng.kernel_timing(True)
+        eng.kernel_time_ms(reset=True)
+        if wake is not None:
+            wake.collective_timing(True)
+            wake.collective_time_ms(reset=True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        fence()
+        el = time.perf_counter() - t0
+        kms, nl = eng.kernel_time_ms(reset=True)
+        eng.kernel_timing(False)
+        cms, nc = (0.0, 0)
+        if wake is not None:
+            cms, nc = wake.collective_time_ms(reset=True)
+            wake.collective_timing(False)
+        return over_ranks(el), kms, nl, cms, nc
+
+    if world > 1:
+        # RCCL builds its communicators on the first collective of each kind: do that outside the measurement
+        # even when --warmup is 0
+        probe = torch.zeros(world * 4, dtype=torch.float32, device=device)
+        piece = torch.ones(4, dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(probe, piece)
+        dist.all_reduce(torch.ones(4, dtype=torch.int64, device=device))     # the symmetric variant's collective
+        torch.cuda.synchronize()
+
+    coll = coll_note = collective = None
+    cfg4_rec = None
+    cfg4_extra = {}
+    u_first = w_first = None
+    per_rank_ms = per_rank_coll_ms = None
     if workload == "cfg3":
         dx, dz, dg = (torch.from_numpy(a).to(device) for a in (x, z, g))
         du, dw = torch.empty_like(dx), torch.empty_like(dx)
@@ -188,148 +346,127 @@ def main():
         pairs_per_step = float(n) * float(n)
         pairs_per_launch = pairs_per_step
         desc = f"config 3: synthetic wake N={n}, one induced_velocity all-pairs call per step (targets = sources)"
-        collective = None
+        for _ in range(args.warmup):
+            step()
+        fence()
+        elapsed, kernel_ms, launches, _, _ = timed_region(step, args.steps)
+        if cpu_rec is not None:
+            u_first = du[: len(cpu_u)].cpu().numpy().astype(np.float64)
+            w_first = dw[: len(cpu_u)].cpu().numpy().astype(np.float64)
+        repeats = [timed_region(step, args.steps)[0] for _ in range(max(0, args.repeats))]
+        per_rank_ms = [kernel_ms]
+        ns_l = nt_l = n
+
+        # N = 1: config 4's workload (N = 8e6, what --gpus 2, 4, 8 run sharded) on this one GPU, so that "8 vs 1" compares the
+        # same work; not part of `value`
+        if world == 1 and args.cfg4_steps > 0 and not args.vortices:
+            n4 = 8_000_000
+            x4, z4, g4 = synthetic_wake(n4)
+            wake4 = ShardedWake(x4, z4, g4, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric)
+            torch.cuda.synchronize()
+            el4, k4, _, _, _ = timed_region(wake4.step, args.cfg4_steps)
+            cfg4_rec = {"workload": f"config 4 on ONE GPU: synthetic wake N={n4}, one self-advection step per step ({variant} kernel, "
+                                    "no collective)", "value": wake4.pairs_per_step * args.cfg4_steps / el4, "unit": "pairs/s",
+                        "steps": args.cfg4_steps, "warmup": 0, "ms_per_step": el4 / args.cfg4_steps * 1e3, "pair_kernel_ms": k4}
+            if args.check:
+                cfg4_rec["result_check"] = check_wake(wake4, g4, rank, torch)
+            del wake4
     else:
         coll = args.collectives if args.collectives != "auto" else ("library" if (backend == "nccl" and world > 1) else "torch")
         if coll == "library":
-            # the engine's own communicator: rank 0's identifier goes round through torch (any channel would do); its
-            # sharding of resident-wake roll-ups is switched off (min_vortices), ShardedWake hands out the tile blocks itself.
-            # If librccl cannot be opened (every rank fails alike, before any collective), torch's collectives take over.
-            try:
-                uid = [eng.comm_unique_id() if rank == 0 else None]
-            except Exception as e:       # noqa: BLE001
-                uid = [None]
-                coll_note = f"library communicator unavailable on rank 0 ({e}); torch.distributed collectives used"
-            if world > 1:
-                dist.broadcast_object_list(uid, src=0, device=device if backend == "nccl" else None)
-            if uid[0] is None:
-                coll = "torch"
-            else:
-                # join, then prove the communicator on a known sum before the steps depend on it; the ranks agree on
-                # the outcome through torch (one rank falling back alone would leave the others inside a collective)
-                ok, why = 1, ""
-                try:
-                    eng.comm_init(rank, world, uid[0], min_vortices=1 << 62)
-                    chk = torch.arange(1, 9, dtype=torch.int64, device=device) * (rank + 1)
-                    torch.cuda.synchronize()
-                    eng.comm_allreduce_i64_dev(chk.data_ptr(), chk.numel())
-                    torch.cuda.synchronize()
-                    want = torch.arange(1, 9, dtype=torch.int64) * (world * (world + 1) // 2)
-                    if not torch.equal(chk.cpu(), want):
-                        ok, why = 0, "wrong sum from the library's all-reduce"
-                except Exception as e:       # noqa: BLE001
-                    ok, why = 0, str(e)
-                flag = torch.tensor([ok], dtype=torch.int64, device=device)
-                if world > 1:
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 0:
-                    try:
-                        eng.comm_destroy()
-                    except Exception:       # noqa: BLE001
-                        pass
-                    coll = "torch"
-                    coll_note = f"library communicator not usable ({why or 'another rank failed'}); torch.distributed collectives used"
-        # (a one-rank run that asks for the library's collectives issues them all the same: identities on real RCCL)
-        wake = ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric, collectives=coll,
-                           force_collectives=(coll == "library" and world == 1))
-        step = wake.step
+            coll, coll_note = join_library_communicator(eng, rank, world, device, backend, dist, torch)
+        # a one-rank run issues its collectives all the same when it can (identities on the real RCCL): the library's
+        # communicator always can, torch's needs the process group (LUDVM_BENCH_FORCE_DIST=1)
+        force_coll = world == 1 and (coll == "library" or force_dist)
+
+        def make_wake(sym):
+            return ShardedWake(x, z, g, V_CORE, DT, HipShardKernel(eng), device, symmetric=sym, collectives=coll,
+                               force_collectives=force_coll)
+
+        def collective_words(sym):
+            return ("one all_reduce(sum) of int64[2 N + 1] fixed-point sums per step" if sym
+                    else "one all_gather of fp32[2, N / G] positions per step") + \
+                (" (ncclAllReduce / ncclAllGather issued inside libludvm_hip.so on its own communicator)" if coll == "library"
+                 else " (torch.distributed)")
+
+        def run_variant(sym, steps, warmup):
+            eng.set_symmetric(1 if sym else 0)      # (a one-rank "direct" block is the whole array: keep it on the direct kernel)
+            wk = make_wake(sym)
+            for _ in range(warmup):
+                wk.step()
+            fence()
+            el, kms, nl, cms, nc = timed_region(wk.step, steps, wk)
+            k_all, c_all = per_rank(kms), per_rank(cms)
+            rec = {"kernel_variant": "symmetric" if sym else "direct", "collective": collective_words(sym),
+                   "value": wk.pairs_per_step * steps / el, "unit": "pairs/s", "steps": steps, "warmup": warmup,
+                   "ms_per_step": el / steps * 1e3,
+                   "pair_kernel_ms_per_rank": k_all, "pair_kernel_ms_max_over_mean": max(k_all) / (sum(k_all) / len(k_all)) if sum(k_all) > 0 else None,
+                   "collective_ms_per_rank": c_all, "collective_ms_max_over_mean": max(c_all) / (sum(c_all) / len(c_all)) if sum(c_all) > 0 else None,
+                   "collective_ms_min_over_ranks": min(c_all), "collectives_timed_per_rank": nc,
+                   "collective_bytes_per_rank": (16 * wk.n_pad + 8) if sym else 8 * wk.n_loc}
+            return wk, rec, el, kms, nl
+
+        def left():
+            """Seconds of the budget still unspent (the slowest rank's clock: every rank must decide alike)."""
+            return args.budget_s - over_ranks(time.perf_counter() - t_process)
+
+        wake, main_rec, elapsed, kernel_ms, launches = run_variant(symmetric, args.steps, args.warmup)
         pairs_per_step = wake.pairs_per_step
         pairs_per_launch = float(wake.n_pad) * float(wake.n_pad) / world if symmetric else float(wake.n_loc) * float(wake.n_pad)
-        collective = ("one all_reduce(sum) of int64[2 N + 1] fixed-point sums per step" if symmetric
-                      else "one all_gather of fp32[2, N / G] positions per step") + \
-            (" (ncclAllReduce / ncclAllGather issued inside libludvm_hip.so on its own communicator)" if coll == "library"
-             else " (torch.distributed)")
+        per_rank_ms, per_rank_coll_ms = main_rec["pair_kernel_ms_per_rank"], main_rec["collective_ms_per_rank"]
+        collective = main_rec["collective"]
+        ns_l, nt_l = wake.n_pad, (wake.n_pad if symmetric else wake.n_loc)
         desc = (f"config 4: synthetic wake N={n}, sharded over {world} GPU(s); per step: "
                 + ("symmetric kernel on the rank's I-tile block of the unordered pairs + ONE all-reduce of the 64-bit "
                    "fixed-point sums + replicated Euler update" if symmetric else
                    "all-pairs kernel on own N/G targets + Euler update + ONE all-gather of positions"))
-    scaling = "strong"
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        # the other variant, then the repeats, within the budget; the checks (two steps + the oracle's ~2e9 pairs) keep a reserve
+        step_s = elapsed / args.steps
+        other_sym = not symmetric
+        other_step_s = step_s * (0.7 if other_sym else 1.6)          # direct / symmetric ~ 1.5 [MI355X, one GPU]
+        reserve = (step_s + other_step_s + 40.0) if args.check else 5.0
+        wake_o = other_rec = None
+        if args.other_variant and n >= 16384:
+            fit = int((left() - reserve) * 0.8 / other_step_s) - 1            # (one warm-up step)
+            o_steps = min(args.steps, fit)
+            if o_steps >= 1:
+                wake_o, other_rec, _, _, _ = run_variant(other_sym, o_steps, 1)
+            else:
+                other_rec = {"kernel_variant": "symmetric" if other_sym else "direct", "skipped":
+                             f"budget: {left():.0f} s left of --budget-s {args.budget_s:.0f}, a step takes ~{other_step_s:.1f} s"}
+        n_rep = max(0, min(args.repeats, int((left() - reserve) / max(elapsed, 1e-9))))
 
-    if world > 1:
-        # RCCL builds its communicators on the first collective of each kind: do that outside the measurement
-        # even when --warmup is 0
-        probe = torch.zeros(world * 4, dtype=torch.float32, device=device)
-        piece = torch.ones(4, dtype=torch.float32, device=device)
-        dist.all_gather_into_tensor(probe, piece)
-        dist.all_reduce(torch.ones(4, dtype=torch.int64, device=device))     # the symmetric variant's collective
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    fence()
+        eng.set_symmetric(1 if symmetric else 0)
+        repeats = [timed_region(wake.step, args.steps, wake)[0] for _ in range(n_rep)]
 
-    def timed_region():
-        eng.kernel_timing(True)
-        eng.kernel_time_ms(reset=True)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        el = time.perf_counter() - t0
-        kms, nl = eng.kernel_time_ms(reset=True)
-        eng.kernel_timing(False)
-        t = torch.tensor([el], dtype=torch.float64, device=device)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), kms, nl
-
-    elapsed, kernel_ms, launches = timed_region()
-    u_first = w_first = None
-    if cpu_rec is not None and workload == "cfg3":
-        u_first = du[: len(cpu_u)].cpu().numpy().astype(np.float64)
-        w_first = dw[: len(cpu_u)].cpu().numpy().astype(np.float64)
-    repeats = [timed_region()[0] for _ in range(max(0, args.repeats))]
-
-    # N = 1: config 4's workload (N = 8e6, what --gpus 2, 4, 8 run sharded) on this one GPU, so that "8 vs 1" compares the
-    # same work; not part of `value`
-    cfg4_rec = None
-    if world == 1 and workload == "cfg3" and args.cfg4_steps > 0 and not args.vortices:
-        n4 = 8_000_000
-        x4, z4, g4 = synthetic_wake(n4)
-        wake4 = ShardedWake(x4, z4, g4, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric)
-        torch.cuda.synchronize()
-        eng.kernel_timing(True)
-        eng.kernel_time_ms(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(args.cfg4_steps):
-            wake4.step()
-        torch.cuda.synchronize()
-        el4 = time.perf_counter() - t0
-        k4, _ = eng.kernel_time_ms(reset=True)
-        eng.kernel_timing(False)
-        cfg4_rec = {"workload": f"config 4 on ONE GPU: synthetic wake N={n4}, one self-advection step per step ({variant} kernel, "
-                                "no collective)", "value": wake4.pairs_per_step * args.cfg4_steps / el4, "unit": "pairs/s",
-                    "steps": args.cfg4_steps, "warmup": 0, "ms_per_step": el4 / args.cfg4_steps * 1e3, "pair_kernel_ms": k4}
-        del wake4
-
-    # per-rank kernel time (the pair kernel alone, HIP events on the launch stream)
-    kt = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
-    per_rank_ms = [kernel_ms]
-    if world > 1:
-        allk = torch.zeros([world], dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(allk, kt)
-        per_rank_ms = [float(v) for v in allk.cpu()]
+        checks = {}
+        if args.check:
+            checks[main_rec["kernel_variant"]] = check_wake(wake, g, rank, torch)
+            if wake_o is not None:
+                eng.set_symmetric(1 if other_sym else 0)
+                checks[other_rec["kernel_variant"]] = check_wake(wake_o, g, rank, torch)
+        cfg4_extra = {main_rec["kernel_variant"] + "_variant": dict(main_rec, reported_as_value=True)}
+        if other_rec is not None:
+            cfg4_extra[other_rec["kernel_variant"] + "_variant"] = dict(other_rec, reported_as_value=False)
+        if args.check:
+            cfg4_extra["result_check"] = checks
 
     if rank == 0:
+        from ludvm_amd.comm import MIN_TARGETS, MIN_WAKE
         value = pairs_per_step * args.steps / elapsed
         kern_s = kernel_ms * 1e-3
         exe = EXECUTED_FLOP_PER_PAIR[variant]
         alg_tflops = FLOP_PER_PAIR * pairs_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
         exe_tflops = exe * pairs_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
         # algorithmic HBM bytes per launch: 12 B per source read, 8 B per target read, 8 B written
-        ns_l = n if workload == "cfg3" else wake.n_pad
-        nt_l = n if workload == "cfg3" else (wake.n_pad if symmetric else wake.n_loc)
         alg_bytes = 12.0 * ns_l + 16.0 * nt_l
-        quad = symmetric and ns_l > 639 * 512 and os.environ.get("LUDVM_SYM_QUAD", "1") != "0"     # (the library's rule)
+        quad = symmetric and ns_l > 639 * 512     # (the library's rule)
         kernel_name = (("ludvm::pair_sym_quad_f32<8> (+ pair_sym_f32<8> on the diagonal tiles), fixed-point accumulation" if quad
                         else "ludvm::pair_sym_f32<8> fixed-point accumulation") if symmetric
                        else "ludvm::pair_f32<2,1024> direct, partial slabs")
         traffic = PMC_TRAFFIC_CFG3.get(kernel_name) if (workload == "cfg3" and n == 1_000_000 and not args.tpl and not args.splits) else None
+        mean = lambda v: sum(v) / len(v)      # noqa: E731
         out = {
             "metric": "biot_savart_pair_interactions_per_s", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -341,7 +478,14 @@ def main():
                        "collective_note": coll_note,
                        "n_vortices": n, "v_core": V_CORE, "device": info["name"],
                        "cu_count": info["cu_count"], "kernel_variant": variant, "targets_per_lane": args.tpl or "auto",
-                       "source_splits": args.splits or "auto", "pair_kernel_ms_per_rank": per_rank_ms},
+                       "source_splits": args.splits or "auto", "pair_kernel_ms_per_rank": per_rank_ms,
+                       "pair_kernel_ms_max_over_mean": max(per_rank_ms) / mean(per_rank_ms) if mean(per_rank_ms) > 0 else None,
+                       "collective_ms_per_rank": per_rank_coll_ms,
+                       "collective_ms_max_over_mean": (max(per_rank_coll_ms) / mean(per_rank_coll_ms)
+                                                       if per_rank_coll_ms and mean(per_rank_coll_ms) > 0 else None),
+                       # thresholds of the CLASS-level sharding (LUDVM(distributed=...): time_loop / induced_velocity), not
+                       # used by this workload; estimates, not yet measured on xGMI
+                       "class_sharding_thresholds": {"min_wake": MIN_WAKE, "min_targets": MIN_TARGETS}},
             "roofline": {
                 # per the metric's definition: algorithmic FLOPs -- 13 per ordered pair -- over the
                 # dominant kernel's own time.  The symmetric kernel EXECUTES 9 per ordered pair (it shares dx, dz, r^2,
@@ -362,6 +506,7 @@ def main():
                                    "in this run)") if traffic else "no PMC pass on record for this kernel / size",
             },
         }
+        out.update(cfg4_extra)
         if cfg4_rec is not None:
             out["config4_one_gpu"] = cfg4_rec
         if cpu_rec is not None:
@@ -371,6 +516,7 @@ def main():
             else:
                 cpu_rec["gpu_vs_oracle_max_rel_err"] = None
             out["cpu_baseline"] = cpu_rec
+        out["wall_s"] = time.perf_counter() - t_process
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if coll == "library":

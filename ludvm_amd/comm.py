@@ -15,6 +15,13 @@ import time
 
 import numpy as np
 
+# From these sizes on the class-level sharding engages (LUDVM(distributed=...)): below them one collective per call / per
+# time step costs more than the split saves.  Estimates from one-GPU kernel times against an assumed ~20-50 us collective
+# floor -- NOT yet measured on xGMI (no multi-GPU box has been available to this build); both are constructor arguments of
+# ShardGroup / LibraryGroup.
+MIN_TARGETS = 65536
+MIN_WAKE = 131072
+
 
 def _env_int(*names, default=None):
     for n in names:
@@ -74,7 +81,7 @@ class LibraryGroup:
     _created = 0          # groups this process has created through a default rendezvous: every rank creates them in the same
                           # order, so the count names the file (a rank must not pick up the identifier of the previous group)
 
-    def __init__(self, engine, rank=None, world=None, rendezvous=None, unique_id=None, min_targets=65536, min_wake=131072,
+    def __init__(self, engine, rank=None, world=None, rendezvous=None, unique_id=None, min_targets=MIN_TARGETS, min_wake=MIN_WAKE,
                  timeout=600.0):
         r, w, _ = launcher_rank()
         self.engine = engine

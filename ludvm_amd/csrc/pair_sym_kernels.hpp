@@ -965,7 +965,9 @@ pair_sym_quad_f32(SymArgs a) {
   const int lane32x4 = ((lane + 32) & 63) * 4;
   float chk = 0.0f;
 
-  // ---- this wave's quarter of a partner tile: slices t = 2 wv, 2 wv + 1 of every lane, fetched one round ahead ---------------
+  // ---- this wave's quarter of a partner tile, fetched one round ahead: the four slices of slab plane wv / 2 for the home
+  //      lanes of half wv & 1 -- lane l holds slices 4 (wv / 2) + 2 (l & 1), + 1 of home lane 32 (wv & 1) + l / 2 ------------
+  const int qhome = 32 * (wv & 1) + (lane >> 1);
   float pjx[2], pjz[2], pjg[2];
   Org poj[NS];
   auto partner_of = [&](int dd) -> unsigned {
@@ -978,18 +980,21 @@ pair_sym_quad_f32(SymArgs a) {
     const unsigned Jc = J < ntiles ? J : 0u;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const unsigned j = Jc * W + lane + 64u * (2 * wv + s);
+      const unsigned j = Jc * W + (unsigned)qhome + 64u * (unsigned)(4 * (wv >> 1) + 2 * (lane & 1) + s);
       pjx[s] = load_or(a.x, j, n, kPadPosF); pjz[s] = load_or(a.z, j, n, kPadPosF); pjg[s] = load_or(a.g, j, n, 0.0f);
     }
 #pragma unroll
     for (int q = 0; q < NS; ++q) poj[q] = origin_records(((Jc * W) >> kOriginShift) + q);
   };
-  // slices 2 wv, 2 wv + 1 are components (2 wv) % 4, +1 of plane (2 wv) / 4: one 8-byte store per lane and array
+  // A lane's pair is components 2 (lane & 1), + 1 of slot `qhome` in plane wv / 2: byte 8 * lane of the wave's 512-byte run
+  // -- consecutive 8-byte stores, no bank conflict.  (Round 3 gave wave w slices 2 w, 2 w + 1 of EVERY home lane: 8-byte
+  // stores 16 bytes apart, two to four lanes per bank -- SQ_LDS_BANK_CONFLICT 3.4e7 cycles per N = 1e6 launch.)  The slab's
+  // contents, and with them every result bit, are the same.
   auto store_quarter = [&]() {
-    const int q = (2 * wv) / 4, c = (2 * wv) % 4;
+    const int at = (wv >> 1) * kPlane + 128 * (wv & 1) + 2 * lane;
     auto put = [&](float* l, const float (&v)[2]) {
-      *reinterpret_cast<f32x2*>(&l[q * kPlane + lane * 4 + c]) = (f32x2){v[0], v[1]};
-      if (lane < 32) *reinterpret_cast<f32x2*>(&l[q * kPlane + 256 + lane * 4 + c]) = (f32x2){v[0], v[1]};
+      *reinterpret_cast<f32x2*>(&l[at]) = (f32x2){v[0], v[1]};
+      if ((wv & 1) == 0) *reinterpret_cast<f32x2*>(&l[at + 256]) = (f32x2){v[0], v[1]};      // slots 64 .. 95 repeat 0 .. 31
     };
     put(lx, pjx); put(lz, pjz); put(lg, pjg);
   };

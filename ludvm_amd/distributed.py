@@ -21,11 +21,13 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .comm import MIN_TARGETS, MIN_WAKE
+
 
 class ShardGroup:
     """The ranks that share one simulation (a torch.distributed process group; None = the default group)."""
 
-    def __init__(self, group=None, device=None, min_targets=65536, min_wake=131072):
+    def __init__(self, group=None, device=None, min_targets=MIN_TARGETS, min_wake=MIN_WAKE):
         if not dist.is_initialized():
             raise RuntimeError("LUDVM(distributed=...) needs torch.distributed to be initialised (one process per GPU, "
                                "e.g. torchrun; backend 'nccl' = RCCL)")

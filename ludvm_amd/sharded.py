@@ -28,6 +28,8 @@ The pair arithmetic is injected (`kernel`): the product passes HipShardKernel (H
 pointers); the CPU tests pass a checker built on the oracle to cover the sharding / collective logic
 under gloo.
 """
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -191,6 +193,77 @@ class ShardedWake:
             self._acc = torch.zeros([2 * n_pad + 1], dtype=torch.int64, device=device)
             self._scale = torch.zeros([32], dtype=torch.uint8, device=device)
             self.kernel.sym_scale(self.gs, self.v_core, self._scale)     # circulations do not change: once
+        self._timing = False
+        self._coll_events, self._coll_ms, self._coll_count = [], 0.0, 0
+
+    # ---- the collective's own time ----------------------------------------------------------------------------------------
+    def collective_timing(self, enable):
+        """Time every step's collective from here on: events on the stream it is issued on (torch's current stream, which
+        the engine launches on too), so the figure is what the step waits between the pair kernel and the Euler update --
+        the transfer AND the wait for the slowest rank's kernel."""
+        self._timing = bool(enable)
+
+    def _coll_begin(self):
+        if not self._timing:
+            return None
+        if self.device.type != "cuda":
+            return time.perf_counter()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    def _coll_end(self, tok):
+        if tok is None:
+            return
+        if self.device.type != "cuda":
+            self._coll_ms += (time.perf_counter() - tok) * 1e3
+            self._coll_count += 1
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self._coll_events.append((tok, e1))
+
+    def collective_time_ms(self, reset=True):
+        """(average ms per collective, collectives timed) since the last reset; waits for the recorded events."""
+        for e0, e1 in self._coll_events:
+            e1.synchronize()
+            self._coll_ms += e0.elapsed_time(e1)
+            self._coll_count += 1
+        self._coll_events = []
+        avg, cnt = (self._coll_ms / self._coll_count if self._coll_count else 0.0), self._coll_count
+        if reset:
+            self._coll_ms, self._coll_count = 0.0, 0
+        return avg, cnt
+
+    # ---- do the replicas hold the same wake? ------------------------------------------------------------------------------
+    def checksum(self):
+        """Four 64-bit integers over the bit patterns of the current positions of the N real vortices: plain and
+        index-weighted sums of x and of z (the weights catch a permutation; no term can overflow: |bits| < 2^31, weight
+        <= 251, N < 2^23 per 2^62).  Every rank of a sharded run must report the same four numbers."""
+        idx = torch.arange(self.n, device=self.xs.device, dtype=torch.int64) % 251 + 1
+        out = []
+        for a in (self.xs, self.zs):
+            bits = a[: self.n].contiguous().view(torch.int32).to(torch.int64)
+            out += [int(bits.sum().item()), int((bits * idx).sum().item())]
+        return out
+
+    def gather_checksums(self):
+        """[world][4] checksums of all ranks (on every rank), through the same channel the step's collective uses."""
+        mine = self.checksum()
+        if self.world == 1:
+            return [mine]
+        if self.library:
+            allc = self.kernel.engine.comm_allgather(np.asarray(mine, dtype=np.int64))
+            return [[int(v) for v in row] for row in np.asarray(allc).reshape(self.world, 4)]
+        dev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        send = torch.tensor(mine, dtype=torch.int64, device=dev)
+        recv = torch.empty([self.world * 4], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        return [[int(v) for v in row] for row in recv.view(self.world, 4).cpu()]
+
+    def ranks_agree(self):
+        sums = self.gather_checksums()
+        return all(s == sums[0] for s in sums)
 
     @property
     def pairs_per_step(self):
@@ -206,10 +279,12 @@ class ShardedWake:
             self.kernel.sym_accumulate(self.xs, self.zs, self.gs, self.rank * tiles, tiles, self.v_core, self._scale,
                                        self._acc)
             if self.world > 1 or self.force:
+                tok = self._coll_begin()
                 if self.library:
                     self.kernel.engine.comm_allreduce_i64_dev(self._acc.data_ptr(), self._acc.numel())
                 else:
                     dist.all_reduce(self._acc, op=dist.ReduceOp.SUM, group=self.group)
+                self._coll_end(tok)
             nxt = self._xz if self.xs.data_ptr() != self._xz.data_ptr() else self._xz2()
             self.kernel.advect_from_sums(self._acc, self._scale, self.xs, self.zs, 0, self.n_pad, self.dt, nxt[0], nxt[1])
             self.xs, self.zs = nxt[0], nxt[1]
@@ -217,10 +292,12 @@ class ShardedWake:
         send = self._send
         self.kernel.advect(self.xs, self.zs, self.gs, self.lo, self.n_loc, self.v_core, self.dt, send[0], send[1])
         if self.world > 1 or self.force:
+            tok = self._coll_begin()
             if self.library:
                 self.kernel.engine.comm_allgather_dev(send.data_ptr(), self._recv.data_ptr(), send.numel() * 4)
             else:
                 dist.all_gather_into_tensor(self._recv.view(-1), send.view(-1), group=self.group)
+            self._coll_end(tok)
             # [G, 2, n_loc] -> [2, G*n_loc].  In-place reuse of _xz is safe: in stream order the pair
             # kernel that read it has finished before this copy starts.
             self._xz.view(2, self.world, self.n_loc).copy_(self._recv.permute(1, 0, 2))

@@ -49,10 +49,56 @@ def test_bench_json_contract(symmetric):
     assert c["gpu_vs_oracle_max_rel_err"] < 1e-5
 
 
+def _assert_self_checking_config4(d, ranks, main="symmetric", collectives_issued=True):
+    """What every config-4 line must carry: the collective's own time per rank beside the pair
+    kernel's, BOTH step variants, and a result check that passed."""
+    c = d["config"]
+    assert len(c["pair_kernel_ms_per_rank"]) == ranks and len(c["collective_ms_per_rank"]) == ranks
+    assert c["pair_kernel_ms_max_over_mean"] >= 1.0
+    assert c["class_sharding_thresholds"] == {"min_wake": 131072, "min_targets": 65536}
+    other = "direct" if main == "symmetric" else "symmetric"
+    for name, reported in ((main, True), (other, False)):
+        v = d[name + "_variant"]
+        assert v["kernel_variant"] == name and v["reported_as_value"] is reported and "skipped" not in v, v
+        assert v["value"] > 1e10 and v["steps"] >= 1 and v["ms_per_step"] > 0
+        assert len(v["pair_kernel_ms_per_rank"]) == ranks and all(t > 0 for t in v["pair_kernel_ms_per_rank"])
+        assert len(v["collective_ms_per_rank"]) == ranks
+        if collectives_issued:
+            assert all(t > 0 for t in v["collective_ms_per_rank"]) and v["collectives_timed_per_rank"] == v["steps"]
+            assert v["collective_ms_max_over_mean"] >= 1.0
+        # the kernel and the collective are both inside the step
+        assert max(v["pair_kernel_ms_per_rank"]) + min(v["collective_ms_per_rank"]) <= v["ms_per_step"] * 1.05
+        assert ("all_reduce" if name == "symmetric" else "all_gather") in v["collective"]
+    assert d[main + "_variant"]["value"] == pytest.approx(d["value"]) and d[main + "_variant"]["steps"] == d["steps"]
+    assert c["collective_ms_per_rank"] == d[main + "_variant"]["collective_ms_per_rank"]
+    for name in (main, other):
+        k = d["result_check"][name]
+        assert "error" not in k, k
+        assert k["ranks_agree"] is True and k["finite"] is True and k["samples"] == 256
+        assert k["gpu_vs_oracle_max_rel_err"] < 1e-5, k
+
+
 def test_bench_config4_shape_on_one_gpu():
     d = _run("--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1", "--cpu-rows", "0")
     assert d["scaling"] == "strong" and "config 4" in d["config"]["workload"] and "cpu_baseline" not in d
     assert d["value"] > 1e11
+    # one rank, no process group: no collective is issued (times 0), everything else is there
+    _assert_self_checking_config4(d, 1, collectives_issued=False)
+    assert d["config"]["collective_ms_per_rank"] == [0.0]
+
+
+def test_bench_config4_direct_variant_reported():
+    d = _run("--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1", "--cpu-rows", "0", "--symmetric", "0")
+    assert d["config"]["kernel_variant"] == "direct"
+    _assert_self_checking_config4(d, 1, main="direct", collectives_issued=False)
+    assert d["symmetric_variant"]["value"] > d["direct_variant"]["value"] * 0.8
+
+
+def test_bench_budget_drops_the_other_variant_and_the_repeats_first():
+    """--budget-s too small for anything but the reported region: the line still comes, says what was skipped."""
+    d = _run("--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1", "--cpu-rows", "0", "--budget-s", "1")
+    assert d["value"] > 1e11 and d["repeat_values"] == [] and "budget" in d["direct_variant"]["skipped"]
+    assert d["result_check"]["symmetric"]["ranks_agree"] is True and "direct" not in d["result_check"]
 
 
 def test_bench_config4_through_the_library_communicator_on_one_rank():
@@ -62,6 +108,7 @@ def test_bench_config4_through_the_library_communicator_on_one_rank():
              "--collectives", "library")
     assert d["config"]["collective_note"] is None, d["config"]["collective_note"]
     assert "inside libludvm_hip.so" in d["config"]["collective"] and d["value"] > 1e11
+    _assert_self_checking_config4(d, 1)          # ncclAllReduce AND ncclAllGather issued (one-rank identities), timed, checked
     ref = _run("--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1", "--cpu-rows", "0",
                "--collectives", "torch")
     assert "torch.distributed" in ref["config"]["collective"] and ref["config"]["collective_note"] is None
@@ -116,6 +163,16 @@ def test_bench_two_ranks_through_the_launcher():
     assert "all_reduce" in d["config"]["collective"]
     assert abs(d["value"] - 120000.0**2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+    _assert_self_checking_config4(d, 2)
+
+
+def test_bench_config4_one_rank_on_the_real_rccl_backend_with_torch_collectives():
+    """One rank, process group on the real "nccl" backend (LUDVM_BENCH_FORCE_DIST=1), torch.distributed's collectives
+    forced: the all-reduce and the all-gather of both variants are issued on RCCL, timed and checked."""
+    d = _launch(1, {"LUDVM_BENCH_FORCE_DIST": "1"}, "--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1",
+                "--collectives", "torch")
+    assert "torch.distributed" in d["config"]["collective"] and d["config"]["ranks"] == 1
+    _assert_self_checking_config4(d, 1)
 
 
 def test_bench_stdout_is_one_line_with_the_rccl_backend_initialised():
@@ -188,3 +245,4 @@ def test_bench_two_ranks_on_rccl_with_two_gpus():
             assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 2
             assert len(d["config"]["pair_kernel_ms_per_rank"]) == 2 and d["value"] > 1e11
             assert ("libludvm_hip" in d["config"]["collective"]) == (coll == "auto")
+            _assert_self_checking_config4(d, 2, main="symmetric" if sym == "1" else "direct")

@@ -110,9 +110,21 @@ def _worker(rank, world, port, n, steps, out, symmetric):
         per = (n + world - 1) // world
         assert wake.n_loc == ((per + 2047) // 2048 * 2048 if symmetric else per) and wake.lo == rank * wake.n_loc   # whole quads of 4 tiles
         assert wake.pairs_per_step == float(n) * n
+        wake.collective_timing(True)
         for _ in range(steps):
             wake.step()
+        ms, cnt = wake.collective_time_ms()
+        assert cnt == steps and ms > 0 and wake.collective_time_ms() == (0.0, 0)      # one collective per step, timed
         xs, zs = wake.positions()
+        # the replicas hold the same wake: equal checksums on every rank, through the step's own channel
+        sums = wake.gather_checksums()
+        assert len(sums) == world and all(len(c) == 4 for c in sums) and wake.ranks_agree()
+        bits = xs.view(np.int32).astype(np.int64)
+        assert sums[rank][0] == int(bits.sum()) and sums[rank][1] == int((bits * (np.arange(n) % 251 + 1)).sum())
+        # ... and a replica that has drifted by one bit in one coordinate is seen by everyone
+        if rank == world - 1:
+            wake.xs[n // 2] = torch.nextafter(wake.xs[n // 2], torch.tensor(1e9))
+        assert not wake.ranks_agree()
         if rank == 0:
             np.save(out, np.stack([xs, zs]))
     finally:
@@ -145,6 +157,12 @@ def test_single_process_world_of_one(symmetric):
     wake = ShardedWake(x, z, g, 0.065, 5e-2, OracleShardKernel(), torch.device("cpu"), symmetric=symmetric)
     wake.step()
     wake.step()
+    assert wake.ranks_agree() and len(wake.gather_checksums()) == 1
+    a = wake.checksum()
+    wake.xs[[3, 7]] = wake.xs[[7, 3]]            # a permutation keeps the plain sums, not the weighted ones
+    b = wake.checksum()
+    assert a[0] == b[0] and a[1] != b[1] and a[2:] == b[2:]
+    wake.xs[[3, 7]] = wake.xs[[7, 3]]
     xr, zr = _serial(300, 2, 0.065, 5e-2)
     xs, zs = wake.positions()
     np.testing.assert_allclose(xs, xr, rtol=0, atol=2e-6)
