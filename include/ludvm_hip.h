@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LUDVM_ABI_VERSION 3
+#define LUDVM_ABI_VERSION 4
 
 enum {
   LUDVM_OK = 0,
@@ -62,8 +62,10 @@ typedef struct ludvm_ctx ludvm_ctx;
 /* ---- lifecycle -------------------------------------------------------------------------- */
 
 int ludvm_abi_version(void);
-/* Create a context bound to HIP device `device_ordinal` (must be a gfx950 part unless the
- * environment variable LUDVM_ALLOW_ANY_ARCH=1 is set).  Owns one stream and its workspaces. */
+/* Create a context bound to HIP device `device_ordinal` (must be a gfx950 part).  Owns one stream and its workspaces.
+ * The library's results never depend on the environment: a production build reads LUDVM_RCCL_LIB (which librccl to open)
+ * and LUDVM_COMM_FORCE (tests) and nothing else; the A/B switches of the measurement build (libludvm_hip_exp.so,
+ * -DLUDVM_EXPERIMENTS) are listed in INTEGRATION.md. */
 int ludvm_create(int device_ordinal, ludvm_ctx** out);
 int ludvm_destroy(ludvm_ctx* ctx);
 const char* ludvm_last_error(const ludvm_ctx* ctx);
@@ -90,14 +92,10 @@ int ludvm_set_tuning(ludvm_ctx* ctx, int targets_per_lane, int source_splits);
  * mode 0 = never (direct kernel), 1 = automatic (default; fp32, N >= 16384),
  * mode >= 2 = automatic with that value as the smallest N that takes the symmetric kernel. */
 int ludvm_set_symmetric(ludvm_ctx* ctx, int mode);
-/* Tuning of the symmetric kernel (tools and tests; 0 = the library's heuristics): vortices per lane (4: 256-vortex
- * tiles, 8: 512-vortex tiles; plain fp32 positions only) and the number of wavefronts (1, 2, 4) that share the 64
- * rotation steps of one tile pair -- 0 (default): chosen from the launch's size, with the work items dispatched last
- * by four wavefronts each where the size gives fewer for the bulk (mixed granularity: the end of a launch is then made of
- * short items); -1: the mixed form at every size; -2: one number per launch, as until round 3 (environment
- * LUDVM_SYM_MIXED=1 / 0 selects -1 / -2); -4 (with 8 vortices per lane, from 16 tiles on): the quad variant -- four I
- * tiles per workgroup share each partner tile, one atomic per J vortex and workgroup -- which the default takes from 640
- * tiles on.  Results change only through the partition into fp32 partial sums. */
+/* Tuning of the symmetric kernel (tests; 0 = the library's rule by launch size): vortices per lane (4: 256-vortex tiles,
+ * 8: 512-vortex tiles; plain fp32 positions only) and the number of wavefronts (1, 2, 4) that share the 64 rotation steps
+ * of one tile pair.  Results change only through the partition into fp32 partial sums.  (The measurement build also takes
+ * three negative codes that force a variant at every size; a production build answers them with LUDVM_E_ARG.) */
 int ludvm_set_sym_tuning(ludvm_ctx* ctx, int vortices_per_lane, int rotation_split);
 
 /* Sharding ONE simulation's roll-up over several GPUs (LUDVM.time_loop, LUDVM.py:1095-1127, with a wake too large
@@ -301,12 +299,7 @@ int ludvm_wake_step(ludvm_ctx* ctx, const double* new_x, const double* new_z, co
  *   [3] a LEV was shed in the previous step          [4] LESPcrit with its current sign (:802-805)
  *   [5] sum Gamma_TEV   [6] sum Gamma_LEV            [7..10] tev_x, lev_x, tev_z, lev_z of the coming step
  *   [11] out: vortices shed by the last step (1 or 2)
- *   [12..14] in: the wake sizes after the three anchor steps max(64 (floor(first_step / 64) - 2 + q) - 1, 0), q = 0, 1, 2
- *            (the caller knows the wake size after every step it has run; step 0 = the initial wake).  Each step's launch
- *            geometry is derived from the wake size two 64-step periods back -- read from the device inside a call, given
- *            here across calls -- so a run's bits do not depend on where its calls begin.  0 = not given: the bounds
- *            restart at this call (results then depend on the chunking, to fp32 rounding, near the tile thresholds)
- *   [12..15] out: x[size-2], x[size-1], z[size-2], z[size-1] after the last roll-up
+ *   [12..15] out: x[size-2], x[size-1], z[size-2], z[size-1] after the last roll-up (ignored on input)
  *   [16..16+ncoef) Fourier coefficients of the previous step.
  * rows (out): count rows of 12 + 2 ncoef + 2 npan doubles:
  *   g_tev, g_lev, shed(0/1), bound, LESP_prev, LESP, Fn, Fs, M, wake slot of the new TEV,
@@ -315,16 +308,22 @@ int ludvm_wake_step(ludvm_ctx* ctx, const double* new_x, const double* new_z, co
  * hist (out, may be NULL): the reference's dense trajectory history (:1108-1127) -- after each step's roll-up the
  *   positions of all wake vortices, count rows of x[hist_nmax] | z[hist_nmax] in wake (shedding) order;
  *   hist_nmax >= wake size + 2 count.
+ * anchors (in, may be NULL): the wake sizes after the four anchor steps max(64 (floor(first_step / 64) - 3 + q) - 1, 0),
+ *   q = 0 .. 3 (the caller knows the wake size after every step it has run; step 0 = the initial wake); -1 = not given.
+ *   Each step's launch geometry is derived from the wake size two 64-step periods back -- read from the device inside a
+ *   call, given here across calls -- so a run's bits do not depend on where its calls begin.  Every given size is checked
+ *   against state[0] (one or two vortices per step since the anchor), LUDVM_E_ARG otherwise.  NULL / all -1: the bounds
+ *   restart at this call (results then depend on the chunking, to fp32 rounding, near the tile thresholds).
  * Synchronous: returns when the last step has finished.  `precision` selects the roll-up arithmetic as in
  * ludvm_wake_advect; the solve is float64.  From the symmetric-kernel threshold on, a step's chord sums and solve run on
- * a second stream beside the symmetric kernel (environment LUDVM_MARCH_OVERLAP=0 keeps every step serial).  The launch
+ * a second stream beside the symmetric kernel.  The launch
  * geometry of every step is a function of the step number and of the simulation itself (never of host timing, nor -- with
- * state[12..14] given -- of where the calls begin), and every sum is order-independent or done in a fixed order: two runs
+ * `anchors` given -- of where the calls begin), and every sum is order-independent or done in a fixed order: two runs
  * return the same bits, however they are cut into calls. */
 int ludvm_march_setup(ludvm_ctx* ctx, int npan, int ncoef, const double* scalars, const double* tables, const double* kin,
                       size_t kin_rows);
 int ludvm_march_run(ludvm_ctx* ctx, long long first_step, long long count, int precision, double* state, double* rows,
-                    double* hist, size_t hist_nmax);
+                    double* hist, size_t hist_nmax, const long long* anchors);
 
 /* ---- flow field: backs LUDVM.flowfield (LUDVM.py:1186-1298) -------------------------------- */
 

@@ -11,12 +11,14 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_si
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libludvm_hip.so")
+# the measurement build (-DLUDVM_EXPERIMENTS: environment switches, forced kernel variants); Engine(lib_path=EXP_LIB_PATH)
+EXP_LIB_PATH = os.path.join(_HERE, "csrc", "libludvm_hip_exp.so")
 
 OK, E_ARG, E_HIP, E_NOMEM, E_NODEVICE, E_STATE, E_COMM = range(7)
 PREC_F32, PREC_F32X2, PREC_F64 = 0, 1, 2
 SYM_TILE = 512
 SYM_OWNER_ALIGN = 4      # tiles: an owner's block of the tile ring is a whole number of these quads (include/ludvm_hip.h)
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 SYM_SCALE_BYTES = 32
 
@@ -69,7 +71,7 @@ SIGNATURES = {
     "ludvm_wake_step": [c_void_p, _pd, _pd, _pd, c_size_t, c_double, _pd, _pd, _pd, c_size_t, c_double, c_int, _pd, _pd,
                         c_int, c_size_t, _pd, _pd, c_size_t, _pd, _pd, _pd, _pd, _pd, _pd, _pd, _pd],
     "ludvm_march_setup": [c_void_p, c_int, c_int, _pd, _pd, _pd, c_size_t],
-    "ludvm_march_run": [c_void_p, c_longlong, c_longlong, c_int, _pd, _pd, _pd, c_size_t],
+    "ludvm_march_run": [c_void_p, c_longlong, c_longlong, c_int, _pd, _pd, _pd, c_size_t, POINTER(c_longlong)],
     "ludvm_flowfield_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, _pd, _pd, _pd, c_size_t,
                             c_double, _pf, _pf],
     "ludvm_flowfield_vorticity_f32": [c_void_p, c_double, c_double, c_double, c_size_t, c_size_t, _pd, _pd, _pd, c_size_t,

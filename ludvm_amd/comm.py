@@ -39,33 +39,65 @@ def launcher_rank():
     return rank, world, local
 
 
+def _private_dir():
+    """A directory only this user can write to (0700, owned by us), for the rendezvous files: under a shared /tmp another
+    local user could otherwise pre-create the file, or plant a symlink where rank 0 is about to write."""
+    d = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ludvm_rdv_{os.getuid()}")
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise PermissionError(f"{d} exists but is not a directory of ours closed to other users; set LUDVM_RENDEZVOUS")
+    return d
+
+
 def default_rendezvous():
     """A file name all processes of one launch agree on and later launches do not reuse: the launcher's job identifier
-    where there is one, else the parent process (the launcher itself) and the rendezvous port."""
+    where there is one, else the parent process (the launcher itself) and the rendezvous port -- inside a per-user 0700
+    directory."""
     if os.environ.get("LUDVM_RENDEZVOUS"):
         return os.environ["LUDVM_RENDEZVOUS"]
     job = (os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("SLURM_JOB_ID") or os.environ.get("OMPI_MCA_ess_base_jobid")
            or "")
-    tag = f"{os.getuid()}_{job}_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ludvm_rdv_{tag}")
+    tag = f"{job}_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
+    return os.path.join(_private_dir(), f"rdv_{tag}")
 
 
 def exchange_id(rank, make_id, path, timeout=600.0):
-    """Rank 0 creates the identifier (make_id() -> bytes) and publishes it atomically at `path`; the others wait for it."""
+    """Rank 0 creates the identifier (make_id() -> bytes) and publishes it atomically at `path`; the others wait for it.
+    Rank 0 never writes through a link and first removes whatever a crashed launch left under the name; the readers take
+    only a regular file that belongs to this user."""
+    nofollow = getattr(os, "O_NOFOLLOW", 0)
     if rank == 0:
         uid = make_id()
+        try:
+            os.unlink(path)                    # a stale identifier would send the other ranks into a dead communicator
+        except FileNotFoundError:
+            pass
         tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
+        try:
+            os.unlink(tmp)
+        except FileNotFoundError:
+            pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | nofollow, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(uid)
         os.replace(tmp, path)
         return uid
+    import stat
     t0 = time.monotonic()
     while True:
         try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) >= 128:
-                return uid[:128]
+            fd = os.open(path, os.O_RDONLY | nofollow)
+            with os.fdopen(fd, "rb") as f:
+                st = os.fstat(f.fileno())
+                if stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid():
+                    uid = f.read()
+                    if len(uid) >= 128:
+                        return uid[:128]
         except OSError:
             pass
         if time.monotonic() - t0 > timeout:
@@ -124,6 +156,10 @@ class LibraryGroup:
     def barrier(self):
         self.engine.comm_allgather(np.zeros(1, np.int8))
 
+    def all_ok(self, ok):
+        """True when every rank reports success; a barrier that carries one bit."""
+        return bool(np.all(self.engine.comm_allgather(np.array([1 if ok else 0], np.int8)) != 0))
+
     # ---- sharded roll-up: the communicator already shards the engine ------------------------------------------------------
     def attach(self, engine, capacity):
         if engine is not self.engine:
@@ -131,4 +167,6 @@ class LibraryGroup:
         return self.world > 1
 
     def detach(self, engine):
-        pass
+        """Nothing to undo: the communicator shards the engine for as long as it exists (from min_wake vortices on), i.e.
+        until close() -- also for roll-ups issued between two time loops.  (ShardGroup.detach unshards its engine.)"""
+

@@ -21,6 +21,18 @@
 
 using namespace ludvm;
 
+// Measurement switches.  A PRODUCTION build reads two environment variables, neither of which can change a result bit:
+// LUDVM_RCCL_LIB (which librccl to open) and LUDVM_COMM_FORCE (a one-rank communicator issues its collectives: tests).
+// Everything else -- the A/B switches of rounds 1-3 (kernel variants, thresholds, chunking; six of them change the
+// partition into fp32 partial sums and hence result bits) and the negative codes of ludvm_set_sym_tuning -- exists only in
+// the measurement build, `make libludvm_hip_exp.so` (-DLUDVM_EXPERIMENTS), which tools/ and the tests of forced variants
+// load.  In a production build the names below do not even reach the object file (tests/test_cabi.py checks).
+#ifdef LUDVM_EXPERIMENTS
+#define LUDVM_EXP_ENV(name) std::getenv(name)
+#else
+#define LUDVM_EXP_ENV(name) static_cast<const char*>(nullptr)
+#endif
+
 namespace {
 
 struct Buf {
@@ -770,7 +782,7 @@ extern "C" {
 int ludvm_abi_version(void) { return LUDVM_ABI_VERSION; }
 
 int ludvm_create(int device_ordinal, ludvm_ctx** out) {
-  const char* small_env = std::getenv("LUDVM_SMALL_TILE_MAX");
+  const char* small_env = LUDVM_EXP_ENV("LUDVM_SMALL_TILE_MAX");
   if (!out) return LUDVM_E_ARG;
   *out = nullptr;
   int ndev = 0;
@@ -783,8 +795,7 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
     delete c;
     return LUDVM_E_HIP;
   }
-  const char* any = std::getenv("LUDVM_ALLOW_ANY_ARCH");
-  if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0 && !(any && any[0] == '1')) {
+  if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
     delete c;
     return LUDVM_E_NODEVICE;
   }
@@ -793,21 +804,21 @@ int ludvm_create(int device_ordinal, ludvm_ctx** out) {
     return LUDVM_E_HIP;
   }
   c->stream = c->own_stream;
-  if (const char* gk = std::getenv("LUDVM_GRID_KERNEL")) {      // row | patch | patch2 | patch4
+  if (const char* gk = LUDVM_EXP_ENV("LUDVM_GRID_KERNEL")) {      // row | patch | patch2 | patch4
     const std::string k(gk);
     c->grid_kernel = k == "row" || k == "1" ? 1 : (k == "patch2" ? 3 : (k == "patch4" ? 4 : 2));
   }
-  if (const char* fp = std::getenv("LUDVM_FEW_PACKED")) c->few_packed = !(fp[0] == '0');
-  if (const char* sq = std::getenv("LUDVM_SYM_QUAD")) c->sym_quad = !(sq[0] == '0');
-  if (const char* sq = std::getenv("LUDVM_SYM_QUAD_MIN_TILES")) c->sym_quad_min_tiles = std::max<long long>(16, std::atoll(sq));
-  if (const char* xr = std::getenv("LUDVM_XCD_RUN")) c->xcd_run = std::max(0, std::atoi(xr));
-  if (const char* ti = std::getenv("LUDVM_SYM_TAIL_ITEMS")) c->sym_tail_items = std::max<long long>(0, std::atoll(ti));
-  if (const char* mx = std::getenv("LUDVM_SYM_MIXED")) {        // 1: mixed granularity at every size; 0: at none (A/B measurements)
+  if (const char* fp = LUDVM_EXP_ENV("LUDVM_FEW_PACKED")) c->few_packed = !(fp[0] == '0');
+  if (const char* sq = LUDVM_EXP_ENV("LUDVM_SYM_QUAD")) c->sym_quad = !(sq[0] == '0');
+  if (const char* sq = LUDVM_EXP_ENV("LUDVM_SYM_QUAD_MIN_TILES")) c->sym_quad_min_tiles = std::max<long long>(16, std::atoll(sq));
+  if (const char* xr = LUDVM_EXP_ENV("LUDVM_XCD_RUN")) c->xcd_run = std::max(0, std::atoi(xr));
+  if (const char* ti = LUDVM_EXP_ENV("LUDVM_SYM_TAIL_ITEMS")) c->sym_tail_items = std::max<long long>(0, std::atoll(ti));
+  if (const char* mx = LUDVM_EXP_ENV("LUDVM_SYM_MIXED")) {        // 1: mixed granularity at every size; 0: at none (A/B measurements)
     if (mx[0] == '1') c->tune_sym_rsplit = -1;
     if (mx[0] == '0') c->tune_sym_rsplit = -2;
   }
   if (small_env) { c->small_tile_max = std::atoll(small_env); c->small_tile_max_f64 = std::min<long long>(c->small_tile_max, 12000); }
-  const char* small64_env = std::getenv("LUDVM_SMALL_TILE_MAX_F64");
+  const char* small64_env = LUDVM_EXP_ENV("LUDVM_SMALL_TILE_MAX_F64");
   if (small64_env) c->small_tile_max_f64 = std::atoll(small64_env);
   *out = c;
   return LUDVM_OK;
@@ -883,9 +894,14 @@ int ludvm_set_sym_tuning(ludvm_ctx* c, int vortices_per_lane, int rotation_split
   if (!c) return LUDVM_E_ARG;
   if (vortices_per_lane != 0 && vortices_per_lane != 4 && vortices_per_lane != 8)
     return fail(c, LUDVM_E_ARG, "vortices_per_lane must be 0 (heuristic), 4 or 8");
-  if (rotation_split != 0 && rotation_split != -1 && rotation_split != -2 && rotation_split != -4 && rotation_split != 1 && rotation_split != 2 &&
-      rotation_split != 4)
-    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (by size), -1 (mixed granularity), -2 (one granularity), -4 (quad variant), 1, 2 or 4");
+#ifdef LUDVM_EXPERIMENTS
+  // measurement build: -1 mixed granularity at every size, -2 at none, -4 the quad variant at every size
+  const bool code_ok = rotation_split == -1 || rotation_split == -2 || rotation_split == -4;
+#else
+  const bool code_ok = false;
+#endif
+  if (rotation_split != 0 && rotation_split != 1 && rotation_split != 2 && rotation_split != 4 && !code_ok)
+    return fail(c, LUDVM_E_ARG, "rotation_split must be 0 (by size), 1, 2 or 4");
   c->tune_sym_t = vortices_per_lane;
   c->tune_sym_rsplit = rotation_split;
   return LUDVM_OK;
@@ -1726,7 +1742,7 @@ void march_workspace(const ludvm_ctx* c, long long n_ub, int precision, size_t n
 }  // namespace
 
 int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int precision, double* state, double* rows,
-                    double* hist, size_t hist_nmax) {
+                    double* hist, size_t hist_nmax, const long long* anchors) {
   if (!c) return LUDVM_E_ARG;
   if (!c->march_ready) return fail(c, LUDVM_E_STATE, "ludvm_march_setup has not been called");
   if (!valid_precision(precision)) return fail(c, LUDVM_E_ARG, "unknown precision");
@@ -1786,36 +1802,46 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   //
   // Round 3: the bounds no longer restart at the call.  Step s is sized from the ANCHOR step A(s) = 64 (floor(s / 64) - 2) - 1
   // (the last step of the sync period two periods back; step 0 for the first 128 steps of a run): an anchor inside this
-  // call is read from the ring as above, an anchor before it is given by the caller in state[12..14] (the class knows
-  // the wake size after every step it has run).  Tile size, waves per item, serial or overlapped step and the direct
-  // kernels' source splits are then functions of the step number and of the simulation alone: the same bits whatever
-  // the chunking (march_chunk, checkpoint_every, dense or sparse history) -- and a resumed run continues bit for bit.
-  // A caller that leaves state[12..14] at 0 gets the old behaviour (bounds restart at the call's exact wake size).
+  // call is read from the ring as above, an anchor before it is given by the caller in `anchors` (the class knows the wake
+  // size after every step it has run).  Tile size, waves per item, serial or overlapped step and the direct kernels'
+  // source splits are then functions of the step number and of the simulation alone: the same bits whatever the chunking
+  // (march_chunk, checkpoint_every, dense or sparse history) -- and a resumed run continues bit for bit.
+  // Round 4 (ABI 4): FOUR anchors, periods floor(first_step / 64) - 3 + q, in an argument of their own.  The bound after
+  // step first_step - 1 -- the first step's `n_before` -- belongs to the period before first_step's when first_step is a
+  // multiple of 64, one period further back than the three that state[12..14] used to carry: every call that began at
+  // 192, 256, 320, ... failed with "anchor step not among the caller's" (default chunks never start there,
+  // snapshot_steps, checkpoint_every and resume do).  -1 = not given (0 is a wake size: a run without free vortices has
+  // an empty wake after step 0); anchors = NULL or all four -1: the bounds restart at this call's exact wake size.
   constexpr long long kSyncEvery = 64;
   auto anchor_of = [](long long s) { return std::max<long long>(kSyncEvery * (s / kSyncEvery - 2) - 1, 0); };
   long long ev_anchor[2] = {-1, -1};      // the last step enqueued before the slot's event was recorded
-  const long long k0 = first_step / kSyncEvery - 2;
-  long long given_step[3], given_n[3];
-  bool anchors_given = true;
-  for (int q = 0; q < 3; ++q) {
+  const long long k0 = first_step / kSyncEvery - 3;
+  long long given_step[4], given_n[4];
+  bool anchors_given = false;
+  for (int q = 0; q < 4; ++q) {
     given_step[q] = std::max<long long>(kSyncEvery * (k0 + q) - 1, 0);
-    given_n[q] = (long long)state[12 + q];
-    if (given_n[q] <= 0) anchors_given = false;
+    given_n[q] = anchors ? anchors[q] : -1;
+    if (given_n[q] < 0) continue;
+    anchors_given = true;
+    // a given size must be one the wake can have had: one or two vortices per step between the anchor and now
+    const long long gap = first_step - 1 - given_step[q];
+    if (gap < 0 || given_n[q] + gap > n0 || given_n[q] + 2 * gap < n0)
+      return fail(c, LUDVM_E_ARG, "march: anchors[] (wake sizes after the anchor steps) contradict state[0]");
   }
   long long cur_a = -1, cur_n = 0;        // the anchor in force and the wake size after it
   // wake size after step s's solve is at most n_after(anchor) + 2 (s - anchor)
   auto set_anchor = [&](long long sstep) -> int {
-    if (!anchors_given) {
-      // (no history from the caller: anchors before the call are replaced by the call's own start)
-      const long long a = anchor_of(sstep);
-      if (a < first_step) { cur_a = first_step - 1; cur_n = n0; return LUDVM_OK; }
-    }
     const long long a = anchor_of(sstep);
+    if (!anchors_given && a < first_step) {
+      // (no history from the caller: anchors before the call are replaced by the call's own start)
+      cur_a = first_step - 1; cur_n = n0;
+      return LUDVM_OK;
+    }
     if (a == cur_a) return LUDVM_OK;
     if (a < first_step) {
-      for (int q = 0; q < 3; ++q)
-        if (given_step[q] == a) { cur_a = a; cur_n = given_n[q]; return LUDVM_OK; }
-      return fail(c, LUDVM_E_STATE, "march: anchor step not among the caller's");
+      for (int q = 0; q < 4; ++q)
+        if (given_step[q] == a && given_n[q] >= 0) { cur_a = a; cur_n = given_n[q]; return LUDVM_OK; }
+      return fail(c, LUDVM_E_ARG, "march: the wake size after anchor step " + std::to_string(a) + " is not among anchors[]");
     }
     const int slot = (int)(((a + 1) / kSyncEvery) & 1);
     if (ev_anchor[slot] != a) return fail(c, LUDVM_E_STATE, "march: no event for the anchor step");
@@ -1828,12 +1854,12 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   };
   CHK(set_anchor(first_step - 1 > 0 ? first_step - 1 : 0));
   long long prev_ub = cur_n + 2 * (std::max<long long>(first_step - 1, 0) - cur_a);   // bound after step first_step - 1
-  if (prev_ub < n0) return fail(c, LUDVM_E_ARG, "march: state[12..14] (wake sizes after the anchor steps) contradict state[0]");
+  if (prev_ub < n0) return fail(c, LUDVM_E_ARG, "march: anchors[] contradict state[0]");
   bool overlapped = false;          // the accumulators have been zeroed for the overlapped steps
   bool fork_signalled = false;      // the previous step's finisher already signals ev_fork
-  static const bool ext_fork = [] { const char* e = std::getenv("LUDVM_MARCH_EXT_EVENTS"); return !(e && e[0] == '0'); }();
+  static const bool ext_fork = [] { const char* e = LUDVM_EXP_ENV("LUDVM_MARCH_EXT_EVENTS"); return !(e && e[0] == '0'); }();
   // LUDVM_MARCH_OVERLAP=0 keeps every step serial (A/B measurements; results agree to fp32 rounding)
-  const char* ov_env = std::getenv("LUDVM_MARCH_OVERLAP");
+  const char* ov_env = LUDVM_EXP_ENV("LUDVM_MARCH_OVERLAP");
   const bool overlap_ok = !(ov_env && ov_env[0] == '0');
   hipStream_t const main_stream = c->stream;
   const double vc4 = m.vc4;

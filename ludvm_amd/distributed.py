@@ -64,6 +64,12 @@ class ShardGroup:
     def barrier(self):
         dist.barrier(group=self.group)
 
+    def all_ok(self, ok):
+        """True when every rank reports success; a barrier that carries one bit."""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
     # ---- sharded roll-up ---------------------------------------------------------------------------------------
     def attach(self, engine, capacity):
         """Shard the engine's symmetric roll-ups over the group: accumulators in a tensor this object owns, summed by

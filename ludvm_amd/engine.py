@@ -346,19 +346,29 @@ class Engine:
         self._check(self._lib.ludvm_march_setup(self._ctx, int(npan), int(ncoef), _pd(sc), _pd(tb), _pd(kin), kin.shape[0]))
         self._march_dims = (int(npan), int(ncoef))
 
-    def march_run(self, first_step, count, precision, state, hist_nmax=0):
+    def march_run(self, first_step, count, precision, state, hist_nmax=0, anchors=None):
         """Advance the resident wake through time steps [first_step, first_step + count) without a host round
         trip per step (ludvm_march_run).  `state` (16 + ncoef float64) is updated in place; returns the
         per-step rows [count, 12 + 2 ncoef + 2 npan] -- and, with hist_nmax > 0, the positions of every wake
-        vortex after each step, [count, 2, hist_nmax] (the reference's dense history)."""
+        vortex after each step, [count, 2, hist_nmax] (the reference's dense history).  `anchors`: the wake sizes after
+        the four anchor steps `march_anchor_steps(first_step)` (-1 = not given; None = none), which make the launch
+        geometry -- and with it the fp32 rounding -- independent of where the calls begin."""
         npan, ncoef = self._march_dims
         if state.dtype != np.float64 or not state.flags.c_contiguous or len(state) != self.MARCH_STATE_HEAD + ncoef:
             raise ValueError("march_run: state must be contiguous float64 of length 16 + ncoef")
         rows = np.empty([int(count), self.MARCH_ROW_HEAD + 2 * ncoef + 2 * npan])
         hist = np.empty([int(count), 2, int(hist_nmax)]) if hist_nmax else None
+        anc = None
+        if anchors is not None:
+            anc = (ctypes.c_longlong * 4)(*[int(v) for v in anchors])
         self._check(self._lib.ludvm_march_run(self._ctx, int(first_step), int(count), _prec(precision), _pd(state), _pd(rows),
-                                              _pd(hist), int(hist_nmax)))
+                                              _pd(hist), int(hist_nmax), anc))
         return (rows, hist) if hist_nmax else rows
+
+    @staticmethod
+    def march_anchor_steps(first_step):
+        """The four steps whose wake sizes ludvm_march_run wants in `anchors` for a call that begins at first_step."""
+        return [max(64 * (int(first_step) // 64 - 3 + q) - 1, 0) for q in range(4)]
 
     # -- flow field ------------------------------------------------------------------------------
     def flowfield(self, xmin, zmin, dr, nx, nz, circulation, xw, zw, v_core):

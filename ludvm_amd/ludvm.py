@@ -204,7 +204,16 @@ class LUDVM:
         if Npoints is None:
             Npoints = self.Npoints
         c = self.chord
-        if Naca is None and filename is not None:
+        from_file = Naca is None and filename is not None
+        if from_file or str(Naca)[:2] != '00':
+            # (symmetric NACA 00xx sections -- every BASELINE config -- have a zero mean line whatever its source)
+            import warnings
+            warnings.warn("LUDVM: the mean line of a cambered NACA section / a .dat file is restated from the published "
+                          "NACA 4-digit formula (or the averaged surfaces of the file); the reference takes it from the PyPI "
+                          "package `airfoils` (LUDVM.py:301-335: mean of the interpolated surfaces), which is not available "
+                          "to this build -- parity with the reference is UNPINNED for this section (symmetric 00xx sections "
+                          "are pinned).", RuntimeWarning, stacklevel=3)
+        if from_file:
             xa, etaa = self._mean_line_from_dat(filename, Npoints)
         else:
             xs = np.linspace(0.0, 1.0, Npoints)
@@ -683,17 +692,15 @@ class LUDVM:
         n_wake = nf + itev + ilev
         st = np.zeros(16 + nc)
         st[:11] = [n_wake, itev, ilev, float(LEV_shed[i - 1] != -1), lesp_crit, sum_tev, sum_lev] + list(place)
-        # wake sizes after the three anchor steps before this call (ludvm_march_run, state[12..14]): the launch geometry of
+        # wake sizes after the four anchor steps before this call (ludvm_march_run, `anchors`): the launch geometry of
         # every step then follows from the step number and the run itself, not from where the stretches begin
         shed_before = np.cumsum(LEV_shed[:i] != -1)            # LEVs shed in steps 0 .. q (step 0 sheds none)
-        for q in range(3):
-            a = max(64 * (i // 64 - 2 + q) - 1, 0)
-            st[12 + q] = nf + a + (shed_before[a] if a < i else 0)
+        anchors = [nf + a + int(shed_before[a]) for a in self.engine.march_anchor_steps(i)]      # (all of them < i)
         st[16:] = self.fourier[i - 1, 0, :]
         if record:
-            R, hist = self.engine.march_run(i, cnt, prec_code, st, hist_nmax=n_wake + 2 * cnt)
+            R, hist = self.engine.march_run(i, cnt, prec_code, st, hist_nmax=n_wake + 2 * cnt, anchors=anchors)
         else:
-            R = self.engine.march_run(i, cnt, prec_code, st)
+            R = self.engine.march_run(i, cnt, prec_code, st, anchors=anchors)
         steps = np.arange(i, j)
         tix = itev + np.arange(cnt)
         shed_v = R[:, 2] != 0
@@ -753,9 +760,28 @@ class LUDVM:
         # one simulation shared by several ranks: every rank holds the same state, rank 0 alone writes it (they would race on
         # the temporary file), and nobody goes on before the file is in place
         sh = self._shard if (self._shard is not None and self._shard.world > 1) else None
-        if sh is not None and sh.rank != 0:
-            sh.barrier()
-            return
+        if sh is None:
+            return self._write_checkpoint_file(next_step, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
+                                               tev_slot, lev_slot)
+        # The ranks meet in all_ok() -- the barrier -- and learn there whether the file is in place: if rank 0 could not
+        # write it (disk full, bad path) everybody raises, instead of rank 0 raising alone and the others waiting for it in
+        # a collective that has no timeout
+        err = None
+        if sh.rank == 0:
+            try:
+                self._write_checkpoint_file(next_step, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
+                                            tev_slot, lev_slot)
+            except Exception as e:          # noqa: BLE001  (re-raised below, on every rank)
+                err = e
+        if not sh.all_ok(err is None):
+            if err is not None:
+                raise err
+            raise RuntimeError(f"rank 0 could not write the checkpoint {self.checkpoint_path}")
+
+    def _write_checkpoint_file(self, next_step, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
+                               tev_slot, lev_slot):
+        import json
+        import os
         C, P = self.circulation, self.path
         n = self.engine.wake_size()
         wx, wz, wg = self.engine.wake_read(0, n, gamma=True)
@@ -782,8 +808,6 @@ class LUDVM:
         tmp = self.checkpoint_path + '.tmp.npz'
         np.savez(tmp, **d)
         os.replace(tmp, self.checkpoint_path)      # a reader never sees a half-written file
-        if sh is not None:
-            sh.barrier()
 
     @classmethod
     def resume(cls, path, engine=None, device=0, verbose=True, checkpoint_every=0, checkpoint_path=None, march=True,

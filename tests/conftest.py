@@ -39,3 +39,14 @@ def g2():
 
 
 CONFIG1 = dict(t0=0, tf=20, dt=5e-2, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2, Naca="0012")
+
+
+@pytest.fixture(scope="module")
+def exp_eng():
+    """An engine on the MEASUREMENT build of the library (libludvm_hip_exp.so, -DLUDVM_EXPERIMENTS): the same kernels, plus
+    the codes and environment switches that force a kernel variant at sizes where the product's rule would not pick it.
+    The product build refuses them (tests/test_cabi.py)."""
+    from ludvm_amd import Engine, _ffi
+    e = Engine(0, lib_path=_ffi.EXP_LIB_PATH)
+    yield e
+    e.close()

@@ -30,6 +30,32 @@ def test_header_library_and_binding_agree():
     assert lib.ludvm_abi_version() == _ffi.ABI_VERSION
 
 
+def test_production_library_reads_no_experiment_switch():
+    """a production build's bits must not depend on the environment.  The A/B switches of rounds 1-3
+    and the negative codes of ludvm_set_sym_tuning live behind -DLUDVM_EXPERIMENTS (libludvm_hip_exp.so); the product's
+    object file does not even contain their names, and the only variables it reads cannot change a result."""
+    import re
+    moved = ("LUDVM_SYM_MIXED", "LUDVM_SYM_TAIL_ITEMS", "LUDVM_SYM_QUAD", "LUDVM_SYM_QUAD_MIN_TILES", "LUDVM_SMALL_TILE_MAX",
+             "LUDVM_SMALL_TILE_MAX_F64", "LUDVM_MARCH_OVERLAP", "LUDVM_MARCH_EXT_EVENTS", "LUDVM_GRID_KERNEL", "LUDVM_FEW_PACKED",
+             "LUDVM_XCD_RUN", "LUDVM_ALLOW_ANY_ARCH")
+
+    def names(path):
+        return set(m.decode() for m in re.findall(rb"LUDVM_[A-Z0-9_]+", open(path, "rb").read()))
+    prod, exp = names(_ffi.LIB_PATH), names(_ffi.EXP_LIB_PATH)
+    assert not (prod & set(moved)), prod & set(moved)
+    assert {"LUDVM_RCCL_LIB", "LUDVM_COMM_FORCE"} <= prod
+    assert set(moved) - {"LUDVM_ALLOW_ANY_ARCH"} <= exp          # ... and the measurement build has them all
+    # both builds export the same ABI
+    exp_lib = _ffi.load(_ffi.EXP_LIB_PATH)
+    assert exp_lib.ludvm_abi_version() == _ffi.ABI_VERSION
+    # the source reads the environment through the one macro (plus the two production variables)
+    src = open(os.path.join(ROOT, "ludvm_amd", "csrc", "ludvm_hip.hip")).read()
+    direct = re.findall(r'std::getenv\("(\w+)"\)', src)
+    assert sorted(direct) == ["LUDVM_COMM_FORCE", "LUDVM_RCCL_LIB"], direct
+    for hdr in ("pair_kernels.hpp", "pair_sym_kernels.hpp", "march_kernels.hpp"):
+        assert "getenv" not in open(os.path.join(ROOT, "ludvm_amd", "csrc", hdr)).read(), hdr
+
+
 def test_every_entry_point_cites_the_reference():
     text = open(os.path.join(ROOT, "include", "ludvm_hip.h")).read()
     assert text.count("LUDVM.py:") >= 15

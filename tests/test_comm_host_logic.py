@@ -32,6 +32,9 @@ def test_default_rendezvous_is_per_launch(monkeypatch):
     a = comm.default_rendezvous()
     monkeypatch.setenv("MASTER_PORT", "29501")
     assert comm.default_rendezvous() != a and str(os.getppid()) in a
+    d = os.path.dirname(a)                      # a directory of ours that nobody else can write to
+    st = os.stat(d)
+    assert st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0
     monkeypatch.setenv("LUDVM_RENDEZVOUS", "/somewhere/else")
     assert comm.default_rendezvous() == "/somewhere/else"
 
@@ -52,6 +55,25 @@ def test_identifier_travels_through_the_file(tmp_path):
     assert got == {1: uid, 2: uid}
     with pytest.raises(TimeoutError):
         comm.exchange_id(1, None, str(tmp_path / "nobody_writes_here"), timeout=0.2)
+    assert (os.stat(path).st_mode & 0o077) == 0
+
+
+def test_rendezvous_does_not_follow_links_nor_trust_stale_files(tmp_path):
+    """rank 0 removes what a crashed launch left under the name and never writes through a link; a reader does
+    not take an identifier from a link."""
+    path = str(tmp_path / "rdv")
+    victim = tmp_path / "victim"
+    victim.write_bytes(b"precious")
+    os.symlink(str(victim), path)                                   # a link where the identifier is about to go
+    with pytest.raises(TimeoutError):
+        comm.exchange_id(1, None, path, timeout=0.2)                # ... is not read through
+    uid = bytes(reversed(range(128)))
+    os.symlink(str(victim), f"{path}.{os.getpid()}.tmp")            # ... nor written through
+    assert comm.exchange_id(0, lambda: uid, path) == uid
+    assert victim.read_bytes() == b"precious" and not os.path.islink(path)
+    assert comm.exchange_id(2, None, path, timeout=5) == uid
+    # a stale identifier of an earlier launch is replaced, not handed out
+    assert comm.exchange_id(0, lambda: bytes(128), path) == bytes(128) and comm.exchange_id(1, None, path, timeout=5) == bytes(128)
 
 
 class _OneRankEngine:

@@ -97,3 +97,25 @@ def _ckpt_worker(rank, world, port, ck):
 
 def test_shared_run_writes_its_checkpoint_once_and_resumes_shared(tmp_path):
     mp.spawn(_ckpt_worker, args=(2, _free_port(), str(tmp_path / "ck.npz")), nprocs=2, join=True)
+
+
+def _ckpt_fail_worker(rank, world, port, ck):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_engine import FakeEngine
+        from ludvm_amd import LUDVM
+        from ludvm_amd.distributed import ShardGroup
+        # the checkpoint path lies in a directory that does not exist: rank 0's write fails -- and EVERY rank raises, at the
+        # same step, instead of rank 0 raising alone while the others wait for it in the barrier
+        with pytest.raises((OSError, RuntimeError)) as ei:
+            LUDVM(**dict(CONFIG1, tf=3), verbose=False, engine=FakeEngine(), precision="f64", distributed=ShardGroup(),
+                  checkpoint_every=20, checkpoint_path=ck)
+        assert isinstance(ei.value, OSError) == (rank == 0)
+        dist.barrier()          # both ranks got here: nobody hangs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failed_checkpoint_write_raises_on_every_rank(tmp_path):
+    mp.spawn(_ckpt_fail_worker, args=(2, _free_port(), str(tmp_path / "no_such_dir" / "ck.npz")), nprocs=2, join=True)

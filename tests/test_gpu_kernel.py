@@ -243,12 +243,12 @@ def test_grid_patch_kernels_equal_the_row_kernel_bit_for_bit():
     lane).  Same operations on the same operands in the same order -> the same bits, for row counts that are and are not
     multiples of the patch, one and several source splits, small- and large-tile source sets, local-origin sources."""
     import os
-    from ludvm_amd import Engine
+    from ludvm_amd import Engine, _ffi
     res = {}
     for kind in ("row", "patch2", "patch4", "patch"):
-        os.environ["LUDVM_GRID_KERNEL"] = kind
+        os.environ["LUDVM_GRID_KERNEL"] = kind          # a switch of the measurement build (-DLUDVM_EXPERIMENTS)
         try:
-            e = Engine(0)
+            e = Engine(0, lib_path=_ffi.EXP_LIB_PATH)
         finally:
             del os.environ["LUDVM_GRID_KERNEL"]
         try:
@@ -794,8 +794,18 @@ def test_full_size_config4_self_advection_step(eng):
         eng.set_stream(None)
 
 
+def test_product_build_refuses_the_measurement_codes(eng):
+    """The negative codes of ludvm_set_sym_tuning (force a kernel variant at every size) belong to the measurement build."""
+    from ludvm_amd import LudvmHipError
+    for code in (-1, -2, -4):
+        with pytest.raises(LudvmHipError):
+            eng.set_sym_tuning(8, code)
+    eng.set_sym_tuning(8, 2)
+    eng.set_sym_tuning(0, 0)
+
+
 @pytest.mark.parametrize("n", [16384 + 77, 50000, 150001])
-def test_symmetric_kernel_rotation_split_variants(eng, n):
+def test_symmetric_kernel_rotation_split_variants(exp_eng, n):
     """Every tiling of the symmetric kernel (256 / 512-vortex tiles) with a tile pair's 64 rotation steps done by
     1, 2 or 4 wavefronts, by the size rule (0, the default: the rule's number for the bulk and four for the work items
     dispatched last -- mixed granularity -- where the rule gives fewer than four), with the mixed form at every size (-1) or
@@ -803,6 +813,7 @@ def test_symmetric_kernel_rotation_split_variants(eng, n):
     variant repeats bit for bit."""
     import torch
     from ludvm_amd import LudvmHipError
+    eng = exp_eng          # the measurement build: the negative codes force a variant at every size
     rng = np.random.default_rng(n)
     x = rng.uniform(-10, 0, n).astype(np.float32)
     z = rng.uniform(-2, 2, n).astype(np.float32)

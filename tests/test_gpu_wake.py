@@ -627,18 +627,55 @@ def test_march_bits_do_not_depend_on_where_the_calls_begin(threshold, prec, tmp_
         e.close()
 
 
+@pytest.mark.parametrize("threshold,prec", [(0, "f64"), (40, "f32")])
+def test_march_calls_that_begin_on_a_multiple_of_64(threshold, prec):
+    """a ludvm_march_run call whose first step is a multiple of 64 from 192 on needs the bound after the
+    step before it, whose anchor lies one 64-step period further back than the three sizes the caller used to hand over:
+    every such call failed ("anchor step not among the caller's").  Default chunks never begin there; stretches that follow
+    a recorded step (snapshot_steps every 5: 255 is recorded, the next stretch begins at 256), odd chunk lengths (191: the
+    second call begins at 192) and resumed runs do.  With four anchors (ABI 4) they run, and give the bits of the run that
+    is cut nowhere."""
+    from ludvm_amd import Engine, LUDVM
+    e = Engine(0)
+    try:
+        if threshold:
+            e.set_symmetric(threshold)
+        kw = dict(CONFIG1, tf=17)              # 340 steps
+        whole = LUDVM(**kw, verbose=False, engine=e, precision=prec, history="sparse", snapshot_steps=[])
+        runs = []
+        for chunk in (191, 64 * 3, 256):       # second calls begin at 192, 193, 257; 191 again at 383 > nt
+            LUDVM._march_chunk = chunk
+            try:
+                runs.append(LUDVM(**kw, verbose=False, engine=e, precision=prec, history="sparse", snapshot_steps=[]))
+            finally:
+                del LUDVM._march_chunk
+        for b in runs:
+            for name in ("Cl", "Cd", "Cm", "LEV_shed"):
+                assert np.array_equal(getattr(whole, name), getattr(b, name)), name
+            assert np.array_equal(whole.path["TEV"][whole.nt - 1], b.path["TEV"][b.nt - 1])
+        # recorded steps are per-step calls (solve on the host, roll-up sized from the exact wake): such a run is its own
+        # family -- what is asserted is that every stretch runs (those after steps 255 and 319 begin at 256 and 320), that
+        # it sheds like the uncut run and stays within rounding of it while the flow has not amplified the difference
+        snap = LUDVM(**kw, verbose=False, engine=e, precision=prec, history="sparse", snapshot_steps=range(0, 341, 5))
+        assert np.array_equal(snap.LEV_shed[:100], whole.LEV_shed[:100])
+        assert np.abs(snap.Cl[:60] - whole.Cl[:60]).max() <= (1e-9 if prec == "f64" else 2e-4)
+        assert 255 in snap.path["TEV"] and 320 in snap.path["TEV"]
+    finally:
+        e.close()
+
+
 def test_march_with_the_quad_variant_of_the_symmetric_kernel():
     """The quad variant (four I tiles per workgroup share each partner tile; default from 1024 tiles) inside the march, where
     the kernel reads the wake size -- and with it its whole geometry, quads and owner blocks included -- on the device:
     forced from 16 tiles (ludvm_set_sym_tuning(8, -4)) on a wake that starts with 9000 free vortices.  Marched (serial and
     overlapped steps) and per-step runs agree with a float64 run to fp32 rounding, shed alike, and repeat bit for bit."""
-    from ludvm_amd import Engine, LUDVM
+    from ludvm_amd import Engine, LUDVM, _ffi
     rng = np.random.default_rng(12)
     nfree = 9000
     xy = np.stack([rng.uniform(-3.0, -0.5, nfree), rng.uniform(-1.0, 1.0, nfree)], axis=1)
     gam = rng.standard_normal(nfree) * 2e-5
     kw = dict(CONFIG1, tf=1.5, circulation_freevort=gam, xy_freevort=xy.T)
-    e = Engine(0)
+    e = Engine(0, lib_path=_ffi.EXP_LIB_PATH)      # (forcing the variant at this size is a code of the measurement build)
     try:
         ref = LUDVM(**kw, verbose=False, engine=e, precision="f64", history="sparse", march=False)
         e.set_symmetric(4096)
@@ -664,8 +701,8 @@ def test_march_and_overlap_logic_isolated_from_rounding():
     rounding level -- 2e-6 on the loads while the flow has not amplified it, identical shedding.  Before the kernels
     were deterministic this comparison was blurred by atomics reordering."""
     import os
-    from ludvm_amd import Engine, LUDVM
-    e = Engine(0)
+    from ludvm_amd import Engine, LUDVM, _ffi
+    e = Engine(0, lib_path=_ffi.EXP_LIB_PATH)      # (the switch exists in the measurement build only)
     try:
         e.set_symmetric(8)
         kw = dict(CONFIG1, tf=6)
@@ -750,6 +787,11 @@ def test_march_rejects_bad_calls(eng):
     st[0] = 3                                # not the current wake size
     with pytest.raises(LudvmHipError):
         eng.march_run(1, 2, "f32", st)
+    st[0] = 0
+    assert eng.march_anchor_steps(1) == [0, 0, 0, 0] and eng.march_anchor_steps(192) == [0, 63, 127, 191]
+    assert eng.march_anchor_steps(200) == [0, 63, 127, 191] and eng.march_anchor_steps(256) == [63, 127, 191, 255]
+    with pytest.raises(LudvmHipError, match="anchors"):       # a wake size after step 0 that the wake cannot have had
+        eng.march_run(1, 2, "f32", st, anchors=[5, 5, 5, 5])
 
 
 @pytest.mark.parametrize("precision,win", [

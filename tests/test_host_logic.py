@@ -167,12 +167,18 @@ def test_dat_section_and_sin_motion(tmp_path):
     pts = np.r_[np.c_[xs[::-1], yt[::-1]], np.c_[xs[1:], -yt[1:]]]
     dat = tmp_path / "sym.dat"
     dat.write_text("SYMMETRIC TEST SECTION\n" + "\n".join(f"{a:.6f} {b:.6f}" for a, b in pts) + "\n")
-    s = LUDVM(**dict(CONFIG1, tf=0.5, Naca=None, foil_filename=str(dat)), engine=FakeEngine(), verbose=False)
+    with pytest.warns(RuntimeWarning, match="UNPINNED"):          # a .dat section: said at run time, once per construction
+        s = LUDVM(**dict(CONFIG1, tf=0.5, Naca=None, foil_filename=str(dat)), engine=FakeEngine(), verbose=False)
     assert np.abs(s.airfoil["eta"]).max() < 1e-6 and s.airfoil["x"].shape == (81,)
-    ref = LUDVM(**dict(CONFIG1, tf=0.5), engine=FakeEngine(), verbose=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                             # the pinned symmetric sections do not warn
+        ref = LUDVM(**dict(CONFIG1, tf=0.5), engine=FakeEngine(), verbose=False)
     np.testing.assert_allclose(s.Cl, ref.Cl, rtol=0, atol=1e-4)
-    # cambered NACA digits run (parity unpinned) and give a lifting mean line
-    c = LUDVM(**dict(CONFIG1, tf=0.5, Naca="2412"), engine=FakeEngine(), verbose=False)
+    # cambered NACA digits run (parity unpinned) and give a lifting mean line -- with the warning
+    with pytest.warns(RuntimeWarning, match="LUDVM.py:301-335") as rec:
+        c = LUDVM(**dict(CONFIG1, tf=0.5, Naca="2412"), engine=FakeEngine(), verbose=False)
+    assert len([w for w in rec if "UNPINNED" in str(w.message)]) == 1
     assert abs(c.airfoil["eta"].max() - 0.02) < 2e-4 and np.all(np.isfinite(c.Cl))
     # motion='sin' (LUDVM.py:417-421)
     m = LUDVM(**dict(CONFIG1, tf=0.5), engine=FakeEngine(), verbose=False, run=False)

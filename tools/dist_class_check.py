@@ -95,13 +95,14 @@ nfree = 9000
 xy = np.stack([rng.uniform(-3.0, -0.5, nfree), rng.uniform(-1.0, 1.0, nfree)], axis=0)
 gam = rng.standard_normal(nfree) * 2e-5
 kwq = dict(kw, tf=1.5, circulation_freevort=gam, xy_freevort=xy)
-eng = Engine(local)
+from ludvm_amd import _ffi  # noqa: E402
+eng = Engine(local, lib_path=_ffi.EXP_LIB_PATH)      # (forcing the variant at this size is a code of the measurement build)
 eng.set_symmetric(4096)
 eng.set_sym_tuning(8, -4)
 sg = ShardGroup(min_targets=1000, min_wake=4096)
 eng_one = eng
 if library:
-    eng_one = Engine(local)
+    eng_one = Engine(local, lib_path=_ffi.EXP_LIB_PATH)
     eng_one.set_symmetric(4096)
     eng_one.set_sym_tuning(8, -4)
 for march in (True, False):

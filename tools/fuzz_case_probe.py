@@ -13,6 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("LUDVM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ludvm_amd", "csrc", "libludvm_hip_exp.so"))  # measurement build: forced variants / A-B switches
 KW = dict(t0=0, tf=2.58, dt=0.02, chord=1, rho=1.225, Uinf=1, Npoints=121, Ncoeffs=16, LESPcrit=0.2611018525180467, Naca="0012",
           alpha_m=2.775340829201788, alpha_max=22.050089628899826, k=2.3053742771281676, phi=154.87085685291925,
           h_max=1.3773564435731436, method="Faure")

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Per-config roofline table of DESIGN.md section 4, recomputed from the rocprofv3 summaries under profiles/ (no GPU needed).
+
+    python tools/roofline_table.py [round_prefix]            # default r04
+
+Per kernel: pairs per launch (stated in DESIGN.md section 4), average duration from `*_kernel_stats.csv`, credited fraction =
+13 FLOP x pairs / ns / 157.3e12, issued fraction (the FLOP per ordered pair the kernel really executes), VALU
+wave-instructions per launch from `*_pmc_sq.csv` against the instruction model, held clock = GRBM_GUI_ACTIVE / 8 XCDs /
+duration, time against the issue model at that clock, LDS bank-conflict cycles, and HBM-side traffic (2 x FETCH_SIZE +
+WRITE_SIZE, KB as rocprofv3 reports them; MI355X_MICROARCH.md's gfx950 correction) over the algorithmic bytes."""
+import csv
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PEAK = 157.3e12
+SIMDS = 256 * 4
+
+# (row label, file prefix, kernel-name substring, ordered pairs per launch, executed FLOP per ordered pair,
+#  VALU wave-instructions per 64-lane "pair-lane" group: instructions per ordered pair and lane,
+#  issue cycles per ordered pair and lane (packed op 4, v_rsq_f32 8; measured in tools/ubench), algorithmic HBM bytes)
+N3, G5 = 1_000_000, 4096 * 4096
+ROWS = [
+    ("config 3 / 4: symmetric, quad variant", "bench_cfg3_sym", "pair_sym_quad_f32<8>", float(N3) ** 2, 9,
+     13 / 4, (11 * 4 + 2 * 8) / 4, 28.0 * N3),
+    ("config 3 direct (`--symmetric 0`; every non-self call)", "bench_cfg3_direct", "pair_f32<2, 1024, false, 0, false>", float(N3) ** 2, 13,
+     10 / 2, (8 * 4 + 2 * 8) / 2, 28.0 * N3),
+    ("config 5: 4096^2 grid x 1e6 sources, 4 x 4 patch", "config5", "pair_f32<16, 1024, false, 2, false>", float(G5) * N3, 10.5 * 2 / 2 + 0,
+     7.25 / 2, (5.25 * 4 + 2 * 8) / 2, 12.0 * N3 + 8.0 * G5),
+    ("config 2 at ~60 000 vortices: symmetric, mixed granularity", "config2_sizes", "pair_sym_f32<8, false, 0, true>", 60075.0 ** 2, 9,
+     13 / 4, (11 * 4 + 2 * 8) / 4, 28.0 * 60075),
+    ("config 2 at ~36 000 vortices: symmetric, 4 waves per item", "config2_sizes", "pair_sym_f32<8, false, 4, true>", 36075.0 ** 2, 9,
+     13 / 4, (11 * 4 + 2 * 8) / 4, 28.0 * 36075),
+]
+
+
+def stats(prefix):
+    out = {}
+    with open(prefix + "_kernel_stats.csv") as f:
+        for r in csv.DictReader(f):
+            out[r["Name"]] = (int(r["Calls"]), float(r["AverageNs"]))
+    return out
+
+
+def pmc(prefix, which):
+    out = {}
+    with open(f"{prefix}_pmc_{which}.csv") as f:
+        for r in csv.DictReader(f):
+            out[(r["kernel"], r["counter"])] = float(r["mean_per_dispatch"])
+    return out
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    print("| kernel (workload) | pairs / launch | avg ms | credited frac (13 FLOP) | issued frac | VALU insts / launch (vs model) | "
+          "held clock GHz | time vs issue model | LDS conflict cycles | HBM traffic / algorithmic bytes |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
+    for label, pre, kern, pairs, exe, ipp, cpp, alg in ROWS:
+        p = os.path.join(ROOT, "profiles", f"{rnd}_{pre}")
+        ks = [(k, v) for k, v in stats(p).items() if kern in k]
+        assert len(ks) == 1, (kern, ks)
+        calls, ns = ks[0][1]
+        sq, fe, wr = pmc(p, "sq"), pmc(p, "fetch"), pmc(p, "write")
+        key = [k for k in sq if kern in k[0]][0][0]
+        valu, gui, lds = sq[(key, "SQ_INSTS_VALU")], sq[(key, "GRBM_GUI_ACTIVE")], sq[(key, "SQ_LDS_BANK_CONFLICT")]
+        fetch_kb, write_kb = fe[(key, "FETCH_SIZE")], wr[(key, "WRITE_SIZE")]
+        frac = 13 * pairs / (ns * 1e-9) / PEAK
+        model_insts = pairs / 64 * ipp
+        clock = gui / 8 / (ns * 1e-9)
+        model_s = pairs / 64 * cpp / SIMDS / clock
+        traffic = (2 * fetch_kb + write_kb) * 1024
+        print(f"| `{kern}` ({label}) | {pairs:.4g} | {ns * 1e-6:.3f} ({calls} launches) | **{frac:.3f}** | {frac * exe / 13:.3f} | "
+              f"{valu:.4g} ({valu / model_insts:.3f} x) | {clock * 1e-9:.2f} | {model_s / (ns * 1e-9):.3f} | {lds:.3g} | "
+              f"{traffic / 1e6:.0f} MB / {alg / 1e6:.1f} MB = {traffic / alg:.1f} x |")
+
+
+if __name__ == "__main__":
+    main()

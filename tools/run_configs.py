@@ -99,4 +99,6 @@ if __name__ == "__main__":
     ap.add_argument("--sym-threshold", type=int, default=0, help="cfg2: smallest wake that takes the symmetric kernel (0 = library default)")
     ap.add_argument("--no-timing", action="store_true", help="cfg2: no per-launch timing events (kernel_ms_total reads 0)")
     a = ap.parse_args()
+    if os.environ.get("LUDVM_PROFILE_PMC") == "1":      # counter passes (tools/profile_cmd.sh): one repetition is enough
+        a.reps = 1
     {"cfg5": cfg5, "cfg2": cfg2}[a.which](a)

@@ -4,6 +4,7 @@ at mid-size N, interleaved rounds, best of six (run on the GPU box).
 import os, sys, time, json
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LUDVM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ludvm_amd", "csrc", "libludvm_hip_exp.so"))  # measurement build: forced variants / A-B switches
 from ludvm_amd import Engine
 eng = Engine(0); dev = torch.device("cuda", 0)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
