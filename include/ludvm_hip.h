@@ -158,10 +158,26 @@ int ludvm_comm_allgather_host(ludvm_ctx* ctx, const void* send, void* recv, size
 /* u[p] =  sum_w g[w]*(zt[p]-zs[w]) / (2 pi sqrt(r^4 + vcore^4))
  * w[p] = -sum_w g[w]*(xt[p]-xs[w]) / (2 pi sqrt(r^4 + vcore^4)),  r^2 = dx^2+dz^2.
  * Host float64 in/out (what the reference passes and returns); `precision` selects the device
- * arithmetic.  ns == 0 or nt == 0 is valid (u, w zero-filled / untouched). */
+ * arithmetic.  ns == 0 or nt == 0 is valid (u, w zero-filled / untouched).
+ * The reference's float64 sum (LUDVM.py:565-569) does not depend on the order of its arrays; LUDVM_PREC_F32 here keeps
+ * 1e-5 of max|u| for ANY order: sources and targets that are not stored compactly (a user's array, a turbulence cloud of
+ * :98-130 -- unlike a shed wake) are evaluated in Morton order on the device and the results returned in the caller's
+ * order (the given order is kept, and with it every result bit, whenever it is already compact); a call with fewer
+ * than 2048 sources or targets -- too few to make 128-point origin classes compact -- runs in float64, and a set too
+ * sparse for its core (mean class extent > 300 v_core in the best order: fp32 offsets cannot resolve a core that small)
+ * takes hi+lo positions as LUDVM_PREC_F32X2 does. */
 int ludvm_induce_f64(ludvm_ctx* ctx, const double* xs, const double* zs, const double* gs, size_t ns,
                      const double* xt, const double* zt, size_t nt, double vcore, int precision,
                      double* u, double* w);
+/* The order the library itself would evaluate the n points (x, z) in: order[k] = index of the point that takes position
+ * k.  Morton order when the given order is not compact (see ludvm_induce_f64), else the identity (*reordered = 0; also
+ * for n < 2048).  For callers of the RESIDENT wake, whose slots are the caller's indices: LUDVM uploads a cloud of free
+ * vortices (LUDVM.py:98-130, :274-277) in this order and returns history rows in its own, so that fp32 roll-ups of an
+ * unordered cloud keep the accuracy tier of a shed wake.  *mean_class_extent (may be NULL) = mean over the 128-point origin
+ * classes, in that order, of (xmax - xmin) + (zmax - zmin); fp32 on local origins keeps 1e-5 of max|u| up to about
+ * 300 v_core (beyond: LUDVM_PREC_F32X2).  Deterministic. */
+int ludvm_spatial_order(ludvm_ctx* ctx, const double* x, const double* z, size_t n, unsigned* order, int* reordered,
+                        double* mean_class_extent);
 /* Same with host float32 buffers (always LUDVM_PREC_F32 arithmetic). */
 int ludvm_induce_f32(ludvm_ctx* ctx, const float* xs, const float* zs, const float* gs, size_t ns,
                      const float* xt, const float* zt, size_t nt, float vcore, float* u, float* w);

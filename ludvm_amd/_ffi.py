@@ -46,6 +46,7 @@ SIGNATURES = {
     "ludvm_comm_allgather_dev": [c_void_p, c_void_p, c_void_p, c_size_t],
     "ludvm_comm_allgather_host": [c_void_p, c_void_p, c_void_p, c_size_t],
     "ludvm_induce_f64": [c_void_p, _pd, _pd, _pd, c_size_t, _pd, _pd, c_size_t, c_double, c_int, _pd, _pd],
+    "ludvm_spatial_order": [c_void_p, _pd, _pd, c_size_t, POINTER(ctypes.c_uint), POINTER(c_int), _pd],
     "ludvm_induce_f32": [c_void_p, _pf, _pf, _pf, c_size_t, _pf, _pf, c_size_t, c_float, _pf, _pf],
     "ludvm_induce_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,
                              c_float, c_void_p, c_void_p],

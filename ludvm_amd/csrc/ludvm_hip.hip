@@ -5,6 +5,8 @@
 #include "pair_kernels.hpp"
 #include "pair_sym_kernels.hpp"
 #include "march_kernels.hpp"
+#include "order_kernels.hpp"
+#include "spatial_order.hpp"
 
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>      // types and prototypes only: librccl is opened at run time by ludvm_comm_init (no link dependency)
@@ -72,6 +74,7 @@ struct ludvm_ctx {
   Buf acc;    // raw (u, w) sums of the symmetric kernel: [2][nt_pad] 64-bit fixed-point integers
   Buf symsc;  // SymScale of the current symmetric launch, followed by its NaN counter (long long)
   Buf arena;  // staging for the host-pointer entry points
+  Buf orderws;  // spatial order of unordered inputs: two permutations, class extents, the sort's temporaries
   char* pin = nullptr;  // pinned host ring for small uploads from entry points that do not synchronize
   size_t pin_off = 0;
   char* pin_out = nullptr;  // pinned host buffer for small synchronous read-backs
@@ -719,6 +722,96 @@ int launch_sym(ludvm_ctx* c, SymOperands o, long long n, double vc4, long long* 
   return LUDVM_OK;
 }
 
+// ---- spatial order of unordered inputs ----------------------------------------------------------------
+// The fp32 kernels keep 1e-5 of max|u| because positions are offsets from the origin of a COMPACT origin class (256-element
+// block x index parity).  A shed wake is compact in its stored order; a caller's array or a turbulence cloud
+// (LUDVM.py:98-130) is not: 1.3e-4 / 5e-5 of max|u| for 1e5 / 1e6 vortices uniformly random in a 10 x 4 box at x = -55 with
+// v_core = 1.3e-3 [MI355X, profiles/r04_unordered_accuracy.txt].  The reference's float64 sum (:565-569) does not depend on
+// the order, so the host-pointer entry points may choose their own: Morton order, when -- and only when -- the given order
+// is not already compact, so that a shed wake's bits are what they were.
+constexpr size_t kOrderMin = 2048;     // below this many points a stateless fp32 call runs in float64 instead (see ludvm_induce_f64)
+
+struct OrderWs {
+  unsigned* order[2];
+  double* ext;
+  double* sum;
+  void* tmp;
+  size_t tmp_bytes;
+};
+
+inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// workspace for orders of up to nmax points in both slots (sized once per call: a later grow would free an order in use)
+int order_workspace(ludvm_ctx* c, size_t nmax, OrderWs* w) {
+  const size_t nblk = (nmax + kOriginBlock - 1) / kOriginBlock;
+  const size_t tb = spatial_order_temp_bytes(nmax);
+  CHK(ensure(c, c->orderws, 2 * up256(nmax * 4) + up256(nblk * 8) + 256 + tb));
+  char* p = static_cast<char*>(c->orderws.p);
+  w->order[0] = reinterpret_cast<unsigned*>(p); p += up256(nmax * 4);
+  w->order[1] = reinterpret_cast<unsigned*>(p); p += up256(nmax * 4);
+  w->ext = reinterpret_cast<double*>(p); p += up256(nblk * 8);
+  w->sum = reinterpret_cast<double*>(p); p += 256;
+  w->tmp = p;
+  w->tmp_bytes = tb;
+  return LUDVM_OK;
+}
+
+// Sum of the class extents of (dx, dz)[0, n) taken in `order` (nullptr: as stored) -> host.  Synchronizes the stream.
+int class_extent_sum(ludvm_ctx* c, const OrderWs& w, const double* dx, const double* dz, const unsigned* order, size_t n, double* out) {
+  const long long nblk = (long long)((n + kOriginBlock - 1) / kOriginBlock);
+  hipLaunchKernelGGL(class_extents, dim3((unsigned)nblk), dim3(kOriginBlock), 0, c->stream, dx, dz, order, (long long)n, w.ext);
+  hipLaunchKernelGGL(sum_fixed_order, dim3(1), dim3(256), 0, c->stream, w.ext, nblk, w.sum);
+  HIPCHK(c, hipGetLastError());
+  void* hv = nullptr;
+  CHK(d2h_small_sync(c, w.sum, sizeof(double), &hv));
+  *out = *static_cast<const double*>(hv);
+  return LUDVM_OK;
+}
+
+// Decide whether the n points (host copies hx, hz for the bounding box; device copies dx, dz) should be taken in Morton
+// order, and build that order in slot `slot` of the workspace.  *order_out = the permutation (position k holds the caller's
+// element order[k]) or nullptr when the given order stays: fewer than kOrderMin points, classes already as compact as an
+// area-filling arrangement would make them (3 x), or not at least 1.5 x less compact than the Morton order makes them.
+// *mean_extent = mean over the origin classes of (xmax - xmin) + (zmax - zmin) in the order that was chosen (0 when the
+// set was not examined).
+int spatial_order_if_needed(ludvm_ctx* c, const OrderWs& w, int slot, const double* hx, const double* hz, const double* dx,
+                            const double* dz, size_t n, const unsigned** order_out, double* mean_extent) {
+  *order_out = nullptr;
+  if (mean_extent) *mean_extent = 0.0;
+  if (n < kOrderMin) return LUDVM_OK;
+  double x0 = 1e300, x1 = -1e300, z0 = 1e300, z1 = -1e300;
+  for (size_t i = 0; i < n; ++i) {
+    const double vx = hx[i], vz = hz[i];
+    if (std::fabs(vx) < 1e300 && std::fabs(vz) < 1e300) {
+      x0 = std::min(x0, vx); x1 = std::max(x1, vx); z0 = std::min(z0, vz); z1 = std::max(z1, vz);
+    }
+  }
+  const double ex = x1 - x0, ez = z1 - z0;
+  if (!(ex >= 0.0) || !(ez >= 0.0) || (ex == 0.0 && ez == 0.0)) return LUDVM_OK;      // nothing finite, or one point
+  double e_given = 0.0;
+  CHK(class_extent_sum(c, w, dx, dz, nullptr, n, &e_given));
+  const double nclass = 2.0 * std::ceil((double)n / kOriginBlock);
+  if (mean_extent) *mean_extent = e_given / nclass;
+  const double side = std::sqrt(128.0 * ex * ez / (double)n);        // an area-filling class of 128 points
+  if (e_given <= 3.0 * nclass * 2.0 * side) return LUDVM_OK;
+  const double span = std::max(ex, ez);
+  OrderBox box{x0, z0, 65535.0 / span, 65535.0 / span};
+  HIPCHK(c, spatial_order_sort(dx, dz, n, box, w.tmp, w.tmp_bytes, w.order[slot], c->stream));
+  double e_sorted = 0.0;
+  CHK(class_extent_sum(c, w, dx, dz, w.order[slot], n, &e_sorted));
+  if (e_given <= 1.5 * e_sorted) return LUDVM_OK;
+  *order_out = w.order[slot];
+  if (mean_extent) *mean_extent = e_sorted / nclass;
+  return LUDVM_OK;
+}
+
+// fp32 on local origins resolves a pair difference to ~6e-8 of its class's extent; next to a core of radius v_core that is
+// (2 ... 6.5)e-8 extent / v_core of max|u| [MI355X: 1e6 / 1e5 vortices and 4096 targets in a 10 x 4 box at v_core = 1.3e-3:
+// extents 0.14 / 0.45 / 2.2, errors 2e-6 / 7e-6 / 1e-4].  Beyond this ratio -- a set too SPARSE for its core, which no order
+// can mend: a class is 128 points wherever they lie -- a stateless fp32 call takes hi+lo positions (exact differences, +30 %
+// time), so LUDVM_PREC_F32 keeps 1e-5 of max|u| for any input.  (A shed wake at config 2's spacing sits at 230.)
+constexpr double kMaxExtentOverCore = 300.0;
+
 bool valid_precision(int p) { return p == LUDVM_PREC_F32 || p == LUDVM_PREC_F32X2 || p == LUDVM_PREC_F64; }
 
 int wake_grow(ludvm_ctx* c, size_t capacity) {
@@ -832,7 +925,7 @@ int ludvm_destroy(ludvm_ctx* c) {
   if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);   // before its stream and buffers go
   for (auto& t : c->pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   for (auto& t : c->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
-  void* bufs[] = {c->part.p, c->acc.p, c->symsc.p, c->arena.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32,
+  void* bufs[] = {c->part.p, c->acc.p, c->symsc.p, c->arena.p, c->orderws.p, c->x64, c->z64, c->g64, c->xh, c->xl, c->zh, c->zl, c->g32,
                   c->xr, c->zr, c->cx, c->cz, c->march_tab.p, c->march_kin.p, c->march_rows.p, c->march_state.p, c->march_hist.p};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
@@ -1047,7 +1140,13 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
     std::memset(w, 0, nt * sizeof(double));
     return LUDVM_OK;
   }
-  const bool f64 = precision == LUDVM_PREC_F64, hilo = precision == LUDVM_PREC_F32X2;
+  // fp32 on local origins needs compact origin classes on BOTH sides.  A side of fewer than kOrderMin points cannot be
+  // made compact by ordering it (a class is 128 points whatever their number) and such a launch is latency- or
+  // f64-rate-bound at well under 2 ms anyway: it runs in float64, whose accuracy does not depend on the order
+  // (the G1 clouds of 257 x 1023 random points: 5e-4 ... 2e-3 of max|u| in fp32 before, rounding now).
+  if (precision == LUDVM_PREC_F32 && std::min(ns, nt) < kOrderMin) precision = LUDVM_PREC_F64;
+  const bool f64 = precision == LUDVM_PREC_F64;
+  bool hilo = precision == LUDVM_PREC_F32X2;
   // the caller passed the same arrays as sources and targets: self-interaction (the targets are not uploaded twice,
   // and from kSymMinN vortices the symmetric kernel takes it)
   const bool self = xt == xs && zt == zs && nt == ns;
@@ -1056,13 +1155,17 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
   // One packed block in = xs | zs | gs | xt | zt.  Small calls (every call of a README-size run) go through the pinned
   // ring: one upload, one conversion launch, the pair launch, one back-conversion, one pinned download.
   const bool small = in_doubles * 8 <= kPinBytes / 4 && out_doubles * 8 <= kPinOutBytes;
+  const bool may_order = !f64 && !hilo;                   // (both sides >= kOrderMin then)
   const size_t nsb = (size_t)origin_slots((long long)ns), ntb = (size_t)origin_slots((long long)nt);
   size_t bytes = Arena::need(in_doubles, 8) + Arena::need(out_doubles, 8);
   if (!f64) bytes += 5 * Arena::need(ns, 4) + 6 * Arena::need(nt, 4) + 2 * Arena::need(nsb, 4) + 2 * Arena::need(ntb, 4);
+  if (may_order) bytes += Arena::need(in_doubles, 8) + Arena::need(out_doubles, 8);      // the re-ordered copies
   CHK(ensure(c, c->arena, bytes));
   Arena ar(c->arena.p);
   double* din = ar.take<double>(in_doubles);
   double* dout = ar.take<double>(out_doubles);
+  double* din_ord = may_order ? ar.take<double>(in_doubles) : nullptr;
+  double* dout_ord = may_order ? ar.take<double>(out_doubles) : nullptr;
   if (small) {
     std::vector<double>& pk = c->pack;
     pk.resize(in_doubles);
@@ -1081,6 +1184,30 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
     if (ntu) {
       HIPCHK(c, hipMemcpyAsync(din + 3 * ns, xt, nt * 8, hipMemcpyHostToDevice, c->stream));
       HIPCHK(c, hipMemcpyAsync(din + 3 * ns + nt, zt, nt * 8, hipMemcpyHostToDevice, c->stream));
+    }
+  }
+  // unordered inputs (a caller's array, a turbulence cloud): sources, and targets that are not the sources, in Morton
+  // order where that makes the origin classes compact; the results go back to the caller's order at the end
+  const unsigned* ord_t = nullptr;
+  if (may_order) {
+    OrderWs ow{};
+    CHK(order_workspace(c, std::max(ns, nt), &ow));
+    const unsigned* ord_s = nullptr;
+    double ext_s = 0.0, ext_t = 0.0;
+    CHK(spatial_order_if_needed(c, ow, 0, xs, zs, din, din + ns, ns, &ord_s, &ext_s));
+    if (self) ord_t = ord_s;
+    else CHK(spatial_order_if_needed(c, ow, 1, xt, zt, din + 3 * ns, din + 3 * ns + nt, nt, &ord_t, &ext_t));
+    if (vcore > 0.0 && std::max(ext_s, ext_t) > kMaxExtentOverCore * vcore) {
+      hilo = true;                 // too sparse for its core: exact differences instead of an order (see kMaxExtentOverCore)
+      ord_t = nullptr;
+    } else if (ord_s || (ord_t && !self)) {
+      hipLaunchKernelGGL(gather_f64, dim3(blocks_for((long long)ns)), dim3(kBlock), 0, c->stream, din, din + ns, din + 2 * ns, ord_s,
+                         (long long)ns, din_ord, din_ord + ns, din_ord + 2 * ns);
+      if (!self)
+        hipLaunchKernelGGL(gather_f64, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, din + 3 * ns, din + 3 * ns + nt,
+                           (const double*)nullptr, ord_t, (long long)nt, din_ord + 3 * ns, din_ord + 3 * ns + nt, (double*)nullptr);
+      HIPCHK(c, hipGetLastError());
+      din = din_ord;
     }
   }
   PairArgs a{};
@@ -1136,11 +1263,17 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
         a.tcx = self ? sox : tox; a.tcz = self ? soz : toz;
         a.t_index0 = 0;
       }
-      CHK(induce_device(c, a, (long long)nt, (long long)ns, precision, fu, fw));
+      CHK(induce_device(c, a, (long long)nt, (long long)ns, hilo ? LUDVM_PREC_F32X2 : LUDVM_PREC_F32, fu, fw));
     }
     hipLaunchKernelGGL(cvt_packed_outputs, dim3(blocks_for((long long)out_doubles)), dim3(kBlock), 0, c->stream, fu, fw, dout,
                        (long long)nt);
     HIPCHK(c, hipGetLastError());
+    if (ord_t) {
+      hipLaunchKernelGGL(scatter_f64, dim3(blocks_for((long long)nt)), dim3(kBlock), 0, c->stream, dout, dout + nt, ord_t, (long long)nt,
+                         dout_ord, dout_ord + nt);
+      HIPCHK(c, hipGetLastError());
+      dout = dout_ord;
+    }
   }
   if (small) {
     void* hv = nullptr;
@@ -1152,6 +1285,33 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
   HIPCHK(c, hipMemcpyAsync(u, dout, nt * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(w, dout + nt, nt * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LUDVM_OK;
+}
+
+int ludvm_spatial_order(ludvm_ctx* c, const double* x, const double* z, size_t n, unsigned* order, int* reordered,
+                        double* mean_class_extent) {
+  if (!c) return LUDVM_E_ARG;
+  if (n && (!x || !z || !order)) return fail(c, LUDVM_E_ARG, "null array");
+  if (n >= ((size_t)1 << 32)) return fail(c, LUDVM_E_ARG, "too many points");
+  if (reordered) *reordered = 0;
+  if (mean_class_extent) *mean_class_extent = 0.0;
+  for (size_t i = 0; i < n; ++i) order[i] = (unsigned)i;
+  if (n < kOrderMin) return LUDVM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  CHK(ensure(c, c->arena, 2 * Arena::need(n, 8)));
+  Arena ar(c->arena.p);
+  double* dx = ar.take<double>(n);
+  double* dz = ar.take<double>(n);
+  HIPCHK(c, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dz, z, n * 8, hipMemcpyHostToDevice, c->stream));
+  OrderWs ow{};
+  CHK(order_workspace(c, n, &ow));
+  const unsigned* ord = nullptr;
+  CHK(spatial_order_if_needed(c, ow, 0, x, z, dx, dz, n, &ord, mean_class_extent));
+  if (!ord) return LUDVM_OK;
+  HIPCHK(c, hipMemcpyAsync(order, ord, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (reordered) *reordered = 1;
   return LUDVM_OK;
 }
 
@@ -2020,6 +2180,23 @@ static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, con
   HIPCHK(c, hipMemcpyAsync(dzs, zs, ns * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dgs, gs, ns * 8, hipMemcpyHostToDevice, c->stream));
   const dim3 bs(kBlock), gs_(blocks_for((long long)ns));
+  if (ns >= kOrderMin) {
+    // sources that are not in a compact order (a turbulence cloud rather than a shed wake) are taken in Morton order: the
+    // sum over the sources does not care, the origin classes become compact (every rank of a sharded flow field holds the
+    // same sources and derives the same order: the row blocks stay bit for bit the one-GPU rows)
+    double* oxs = ar.take<double>(ns);
+    double* ozs = ar.take<double>(ns);
+    double* ogs = ar.take<double>(ns);
+    OrderWs ow{};
+    CHK(order_workspace(c, ns, &ow));
+    const unsigned* ord = nullptr;
+    CHK(spatial_order_if_needed(c, ow, 0, xs, zs, dxs, dzs, ns, &ord, nullptr));
+    if (ord) {
+      hipLaunchKernelGGL(gather_f64, gs_, bs, 0, c->stream, dxs, dzs, dgs, ord, (long long)ns, oxs, ozs, ogs);
+      HIPCHK(c, hipGetLastError());
+      dxs = oxs; dzs = ozs; dgs = ogs;
+    }
+  }
   hipLaunchKernelGGL(cvt_f64_to_local, gs_, bs, 0, c->stream, dxs, fxs, sox, (long long)ns);
   hipLaunchKernelGGL(cvt_f64_to_local, gs_, bs, 0, c->stream, dzs, fzs, soz, (long long)ns);
   hipLaunchKernelGGL(cvt_f64_to_f32, gs_, bs, 0, c->stream, dgs, fgs, (float*)nullptr, (long long)ns);
@@ -2029,7 +2206,7 @@ static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, con
   return LUDVM_OK;
 }
 static size_t flowfield_upload_bytes(size_t ns) {
-  return 3 * Arena::need(ns, 8) + 3 * Arena::need(ns, 4) + 2 * Arena::need((size_t)origin_slots((long long)ns), 4);
+  return 6 * Arena::need(ns, 8) + 3 * Arena::need(ns, 4) + 2 * Arena::need((size_t)origin_slots((long long)ns), 4);
 }
 
 int ludvm_flowfield_f32(ludvm_ctx* c, double xmin, double zmin, double dr, size_t nx, size_t nz, const double* xs,

@@ -190,6 +190,21 @@ class Engine:
                                                float(v_core), _prec(precision), _pd(u), _pd(w)))
         return u, w
 
+    def spatial_order(self, x, z, with_extent=False):
+        """(order, reordered[, mean_class_extent]): the order the library evaluates unordered points in -- Morton order, or
+        the identity when the given order is already compact or there are fewer than 2048 points (ludvm_spatial_order).
+        Position k of an array stored in that order holds the caller's element order[k].  mean_class_extent: how compact
+        the 128-point origin classes are in that order (0.0 below 2048 points); fp32 on local origins keeps its tier up
+        to about 300 v_core."""
+        xs, zs = _f64(x), _f64(z)
+        if len(xs) != len(zs):
+            raise ValueError("x and z must have the same length")
+        order = np.empty(len(xs), np.uint32)
+        flag, ext = c_int(0), c_double(0.0)
+        self._check(self._lib.ludvm_spatial_order(self._ctx, _pd(xs), _pd(zs), len(xs),
+                                                  order.ctypes.data_as(POINTER(ctypes.c_uint)), byref(flag), byref(ext)))
+        return (order, bool(flag.value), float(ext.value)) if with_extent else (order, bool(flag.value))
+
     def induce_f32(self, circulation, xw, zw, xp, zp, v_core):
         g, xs, zs, xt, zt = _f32(circulation), _f32(xw), _f32(zw), _f32(xp), _f32(zp)
         u, w = np.empty(len(xt), np.float32), np.empty(len(xt), np.float32)

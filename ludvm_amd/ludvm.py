@@ -416,7 +416,28 @@ class LUDVM:
         # device wake, in shedding order: FREE first, then each step's TEV (and LEV when shed)
         eng.wake_clear()
         eng.wake_reserve(nf + 2 * nv + npan + 2)
-        eng.wake_append(free0[0], free0[1], g_free)
+        # A cloud of free vortices (generate_flowfield_turbulence, LUDVM.py:98-130) arrives in no spatial order; the fp32
+        # roll-up keeps its accuracy tier on compact 256-vortex blocks (a shed wake's stored order).  The engine names the
+        # order it wants (Morton; the identity for a compact or small set): the cloud is STORED in it, `fslot[j]` is the
+        # wake slot of the caller's free vortex j, and every path['FREE'] row is returned in the caller's order.
+        fslot = None
+        if self.precision == 'f32' and nf >= 2048 and hasattr(eng, 'spatial_order'):
+            order, reordered, extent = eng.spatial_order(free0[0], free0[1], with_extent=True)
+            if extent > 300.0 * self.v_core > 0.0:
+                # too sparse for its core: no order makes 128-vortex classes compact enough for fp32 offsets to resolve
+                # v_core (ludvm_hip.h, ludvm_spatial_order) -- the roll-up takes hi+lo positions instead
+                import warnings
+                warnings.warn(f"LUDVM: the free-vortex cloud is too sparse for v_core = {self.v_core:g} to keep 1e-5 of max|u| "
+                              f"in fp32 on local origins (mean 128-vortex class extent {extent:.3g} > 300 v_core); "
+                              "the wake-on-wake sums of this run use hi+lo positions (precision='f32x2')",
+                              RuntimeWarning, stacklevel=3)
+                self.precision, reordered = 'f32x2', False
+            if reordered:
+                fslot = np.empty(nf, dtype=np.int64)
+                fslot[order] = np.arange(nf)
+                eng.wake_append(free0[0][order], free0[1][order], g_free[order])
+        if fslot is None:
+            eng.wake_append(free0[0], free0[1], g_free)
         tev_slot = np.zeros(nv, dtype=np.int64)
         lev_slot = np.zeros(nv, dtype=np.int64)
         sum_tev = sum_lev = 0.0                   # running Kelvin sums (:758-760)
@@ -443,8 +464,11 @@ class LUDVM:
                     for srow in R['rows_steps']:
                         P[key].store(int(srow), R[f'row_{key}_{int(srow)}'])
             eng.wake_clear()
-            eng.wake_append(R['wake_x'], R['wake_z'], R['wake_g'])
+            eng.wake_append(R['wake_x'], R['wake_z'], R['wake_g'])        # (in the stored order, free vortices included)
+            fslot = R['free_slot'].astype(np.int64) if ('free_slot' in R.files and R['free_slot'].size == nf) else None
             self.ilev, self.itev, self.LEV_shed = int(R['self_ilev']), int(R['self_itev']), LEV_shed
+        self._free_slot = fslot
+        fsl = slice(0, nf) if fslot is None else fslot
 
         # preallocated host buffers for the two device calls of a step (engines that offer them)
         sb = eng.step_buffers(npan) if hasattr(eng, 'step_buffers') else None
@@ -629,7 +653,7 @@ class LUDVM:
                     row_t = np.stack([xs[tev_slot[:itev + 1]], zs[tev_slot[:itev + 1]]])
                     lslots = lev_slot[:ilev + 1] if shed else np.append(lev_slot[:ilev], n_after - 1)
                     row_l = np.stack([xs[lslots], zs[lslots]])
-                    row_f = np.stack([xs[:nf], zs[:nf]])
+                    row_f = np.stack([xs[fsl], zs[fsl]])
                     if full:
                         P['TEV'][i, :, :itev + 1] = row_t
                         P['LEV'][i, :, :ilev + 1] = row_l
@@ -740,7 +764,8 @@ class LUDVM:
                 P['LEV'][q, 0, :len(ls)], P['LEV'][q, 1, :len(ls)] = xs[ls], zs[ls]
                 if not shed_v[r]:
                     P['LEV'][q, :, il] = self.dt * R[r, 10:12]
-                P['FREE'][q, 0, :], P['FREE'][q, 1, :] = xs[:nf], zs[:nf]
+                fsl = slice(0, nf) if self._free_slot is None else self._free_slot
+                P['FREE'][q, 0, :], P['FREE'][q, 1, :] = xs[fsl], zs[fsl]
         last_shed = bool(shed_v[-1])
         # as the per-step path leaves them: the counters before the last step's increment
         self.itev, self.ilev, self.LEV_shed = itev + cnt - 1, ilev + n_shed - int(last_shed), LEV_shed
@@ -791,6 +816,7 @@ class LUDVM:
                  last_lev=nan2 if last_lev is None else last_lev, LEV_shed=LEV_shed, tev_slot=tev_slot,
                  lev_slot=lev_slot, self_itev=self.itev, self_ilev=self.ilev, wake_x=wx, wake_z=wz, wake_g=wg,
                  circulation_freevort=np.asarray(self.circulation_freevort),
+                 free_slot=np.zeros(0, np.int64) if self._free_slot is None else self._free_slot,
                  xy_freevort=np.asarray(self.xy_freevort, dtype=float))
         for key in ('TEV', 'LEV', 'bound', 'airfoil', 'gamma_airfoil', 'Gamma_airfoil'):
             d['circ_' + key] = C[key]

@@ -31,10 +31,12 @@ def _kernel_mass(g, xw, zw, xp, zp, vc):
     return (k * np.abs(dz)).sum(1), (k * np.abs(dx)).sum(1)
 
 
-# tier T1 tolerances, relative to max|u| of the call.  "off50": coordinates offset by -50
-# with separations ~1e-3 -- plain fp32 positions lose the difference there, which is what
-# the hi+lo mode is for; it must meet the O(1)-coordinate tolerance.
-TOL = {"f32": {"vc065": 1e-5, "vc0013": 5e-4, "off50": 2e-3},
+# Tolerances relative to max|u| of the call (tier T1).  Every G1 case has fewer than 2048 points on a side, and
+# such a call runs in float64 whatever fp32 precision was asked for (ludvm_induce_f64: too few points to make 128-point
+# origin classes compact, and nothing to gain from fp32 at that size) -- round 3 allowed 5e-4 / 2e-3 here for the random
+# 1023-vortex clouds in fp32 on local origins.  hi+lo ('f32x2') and the plain-fp32 entry (below) do run fp32 kernels.
+# "off50": coordinates offset by -50 with separations ~1e-3 -- plain fp32 positions lose the difference there.
+TOL = {"f32": {"vc065": 1e-11, "vc0013": 1e-11, "off50": 1e-11},
        "f32x2": {"vc065": 1e-5, "vc0013": 1e-5, "off50": 1e-5},
        "f64": {"vc065": 1e-12, "vc0013": 1e-12, "off50": 1e-12}}
 
@@ -48,19 +50,37 @@ def test_g1_golden_kats(eng, g1_cases, precision):
         u, w = eng.induce(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], float(c["v_core"]), precision=precision)
         assert u.dtype == np.float64 and u.shape == c["u"].shape
         err = _rel(u, w, c["u"], c["w"])
-        assert err <= TOL[precision][tag], (name, precision, err)
-        if precision != "f64" and not (tag == "off50" and precision == "f32"):
+        fp32_kernels = precision == "f32x2" or (precision == "f32" and min(len(c["xw"]), len(c["xp"])) >= 2048)
+        assert err <= (1e-5 if fp32_kernels else TOL[precision][tag]), (name, precision, err)
+        if precision != "f64":
             mu, mw = _kernel_mass(c["g"].astype(float), c["xw"], c["zw"], c["xp"], c["zp"], float(c["v_core"]))
-            lim = 1e-4 if precision == "f32" else 2e-6
+            lim = 1e-10 if not fp32_kernels else (1e-4 if precision == "f32" else 2e-6)
             assert np.all(np.abs(u - c["u"]) <= lim * mu + 1e-30), name
             assert np.all(np.abs(w - c["w"]) <= lim * mw + 1e-30), name
 
 
+def test_g1_golden_kats_through_the_plain_fp32_entry(eng, g1_cases):
+    """ludvm_induce_f32 (host float32 buffers: the caller's fp32 coordinates are used as they are, direct kernel) on the
+    reference's KATs: 1e-5 of max|u| at v_core = 0.065, 5e-4 at v_core = 1.3e-3 with O(1) coordinates (SURVEY 8d T1 "without
+    recentring"), and the loss SURVEY H2 predicts once the coordinates sit at -50."""
+    tol = {"vc065": 1e-5, "vc0013": 5e-4, "off50": 5e-2}
+    worst = {}
+    for name, c in g1_cases.items():
+        if "inviscid" in name:
+            continue
+        tag = "off50" if "off50" in name else ("vc0013" if name.endswith("vc0013") else "vc065")
+        u, w = eng.induce_f32(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], float(c["v_core"]))
+        err = _rel(u.astype(float), w.astype(float), c["u"], c["w"])
+        assert err <= tol[tag], (name, err)
+        worst[tag] = max(worst.get(tag, 0.0), err)
+    assert worst["off50"] > 1e-4           # (what local origins, hi+lo positions and the float64 route are for)
+
+
 def test_hilo_positions_remove_the_offset_cancellation(eng, g1_cases):
     c = g1_cases["p257x1023_off50_vc0013"]   # |x| ~ 55, separations ~ 1e-3, v_core = 1.3e-3
-    e32 = _rel(*eng.induce(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], 1.3e-3, precision="f32"), c["u"], c["w"])
+    e32 = _rel(*(a.astype(float) for a in eng.induce_f32(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], 1.3e-3)), c["u"], c["w"])
     e2 = _rel(*eng.induce(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], 1.3e-3, precision="f32x2"), c["u"], c["w"])
-    assert e2 < 1e-5 and e2 < e32
+    assert e2 < 1e-5 and 20 * e2 < e32
 
 
 @pytest.mark.parametrize("precision", ["f32", "f32x2", "f64"])
@@ -346,6 +366,105 @@ def test_flowfield_over_a_far_wake_keeps_1e5(eng):
                 assert plain > 20 * err, (plain, err)
             finally:
                 eng.set_stream(None)
+
+
+def _cloud(n, seed=77):
+    """n vortices uniformly random in a 10 x 4 box centred at x = -55: the order a caller's array or a turbulence cloud
+    (LUDVM.generate_flowfield_turbulence, LUDVM.py:98-130) has -- none -- at the distance config 2's wake ends at."""
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-60.0, -50.0, n), rng.uniform(-2.0, 2.0, n), rng.standard_normal(n) * 1e-2
+
+
+@pytest.mark.parametrize("n", [100_000, 1_000_000])
+def test_fp32_accuracy_does_not_depend_on_the_callers_order(eng, n):
+    """VERDICT r3 item 3.  The reference's float64 sum (LUDVM.py:565-569) is order-independent; the fp32 kernels' local
+    origins need compact 256-vortex blocks, which a shed wake's stored order gives and a random cloud's does not: measured
+    before [MI355X, profiles/r04_unordered_accuracy.txt] 1.3e-4 (1e5 vortices) / 5e-5 (1e6) of max|u| at v_core = 1.3e-3,
+    4.7e-4 / 1.7e-4 on 512 separate targets.  Now: sources and targets of a host-pointer call are taken in Morton order on
+    the device when their own order is not compact (results back in the caller's order), sides of fewer than 2048 points run
+    in float64, sets too sparse for their core (mean class extent > 300 v_core even in Morton order: 4096 targets in this
+    box) take hi+lo positions, and the resident wake is told the order and the extent (ludvm_spatial_order).  1e-5 of max|u|
+    on sampled targets against the C oracle: symmetric and direct kernel, self-interaction and separate targets, stateless
+    call and wake roll-up."""
+    vc = 1.3e-3
+    x, z, g = _cloud(n)
+    rng = np.random.default_rng(3)
+    sel = rng.choice(n, 512, replace=False)
+    ur, wr = c_oracle.induced_velocity(g, x, z, x[sel], z[sel], vc)
+    try:
+        scale = None
+        for sym in (1, 0):
+            eng.set_symmetric(sym)
+            u, w = eng.induce(g, x, z, x, z, vc, precision="f32")
+            if scale is None:
+                scale = max(np.abs(u).max(), np.abs(w).max())         # max|u| over ALL vortices (good to 1e-5 by this very test)
+                assert scale > 0.5 * max(np.abs(ur).max(), np.abs(wr).max())
+            err = max(np.abs(u[sel] - ur).max(), np.abs(w[sel] - wr).max()) / scale
+            assert err < 1e-5, (n, sym, err)
+        eng.set_symmetric(1)
+        # separate targets: 4096 of them (ordered on the device like the sources) and 512 (fewer than 2048: float64)
+        big = rng.choice(n, 4096, replace=False)
+        ub, wb = c_oracle.induced_velocity(g, x, z, x[big], z[big], vc)
+        u, w = eng.induce(g, x, z, x[big].copy(), z[big].copy(), vc, precision="f32")
+        assert max(np.abs(u - ub).max(), np.abs(w - wb).max()) / scale < 1e-5
+        u, w = eng.induce(g, x, z, x[sel].copy(), z[sel].copy(), vc, precision="f32")
+        assert max(np.abs(u - ur).max(), np.abs(w - wr).max()) / scale < 1e-11
+        # the resident wake keeps the caller's slots, so the caller stores the cloud in the order the engine names
+        # (and picks hi+lo positions when even that order leaves the classes too wide for the core, as LUDVM.time_loop does)
+        order, reordered, extent = eng.spatial_order(x, z, with_extent=True)
+        assert reordered and np.array_equal(np.sort(order), np.arange(n))
+        assert 0.3 * np.sqrt(128 * 40.0 / n) < extent < 3 * 2 * np.sqrt(128 * 40.0 / n)      # ~ 2 sides of a 128-point cell
+        prec = "f32x2" if extent > 300 * vc else "f32"
+        assert prec == "f32" or n < 500_000
+        slot = np.empty(n, np.int64)
+        slot[order] = np.arange(n)
+        for sym in (1, 0):
+            eng.set_symmetric(sym)
+            eng.wake_clear()
+            eng.wake_append(x[order], z[order], g[order])
+            u, w = eng.wake_advect(2.0 ** -10, [], [], [], vc, precision=prec, return_velocity=True)
+            err = max(np.abs(u[slot[sel]] - ur).max(), np.abs(w[slot[sel]] - wr).max()) / scale
+            assert err < 1e-5, (n, sym, err)
+        # the order is a pure function of the positions
+        order2, _ = eng.spatial_order(x, z)
+        assert np.array_equal(order, order2)
+    finally:
+        eng.set_symmetric(1)
+        eng.wake_clear()
+
+
+def test_a_shed_wake_keeps_its_order_and_its_bits(eng):
+    """The spatial order applies only where the given order is not compact: a shed wake -- single sheet, the alternating
+    TEV / LEV order, rolled up -- is evaluated as stored (ludvm_spatial_order: identity), so its results are the bits they
+    were before the order existed; a cloud that is ALREADY in Morton order is left alone as well."""
+    from test_gpu_wake import _late_time_wake
+    rng = np.random.default_rng(5)
+    for layout in ("sheet", "interleaved"):
+        x, z = _late_time_wake(layout, 40000, rng)
+        order, reordered = eng.spatial_order(x, z)
+        assert not reordered and np.array_equal(order, np.arange(40000)), layout
+    # a sheet wound into a spiral (a rolled-up starting vortex): compact along the sheet, though not monotone in space
+    s = np.linspace(0.0, 1.0, 30000)
+    x, z = -40.0 + (0.02 + s) * np.cos(40 * s), (0.02 + s) * np.sin(40 * s)
+    assert not eng.spatial_order(x, z)[1]
+    # fewer than 2048 points: never
+    assert not eng.spatial_order(*_cloud(2000)[:2])[1]
+    xc, zc, _ = _cloud(50000)
+    order, reordered = eng.spatial_order(xc, zc)
+    assert reordered
+    assert not eng.spatial_order(xc[order], zc[order])[1]
+
+
+def test_flowfield_over_an_unordered_cloud_keeps_1e5(eng):
+    """LUDVM.flowfield over a turbulence cloud (sources in no order): the host entry takes the sources in Morton order
+    (the sum over sources does not care), the float64 grid points are referred to compact source classes."""
+    vc = 1.3e-3
+    x, z, g = _cloud(200_000, seed=9)
+    xmin, zmin, dr, nx, nz = -55.3, -0.2, 0.004, 48, 64
+    u, w = eng.flowfield(xmin, zmin, dr, nx, nz, g, x, z, vc)
+    X, Z = np.meshgrid(xmin + np.arange(nx) * dr, zmin + np.arange(nz) * dr, indexing="ij")
+    ur, wr = c_oracle.induced_velocity(g, x, z, X.ravel(), Z.ravel(), vc)
+    assert _rel(u.ravel(), w.ravel(), ur, wr) < 1e-5
 
 
 def test_flowfield_float64_mode_and_row_blocks(eng):
@@ -762,9 +881,15 @@ def test_full_size_config5_flowfield(eng):
 
 
 def test_full_size_config4_self_advection_step(eng):
-    """BASELINE config 4's workload on one GPU: one symmetric self-advection step of N = 8e6 vortices
-    (6.4e13 ordered pairs).  Sampled displacements against the C oracle, and conservation of the linear
-    impulse sum_i G_i x_i (the pair forces cancel exactly in exact arithmetic)."""
+    """BASELINE config 4's workload on one GPU: one symmetric self-advection step of N = 8e6 vortices (6.4e13 ordered
+    pairs), and the direct variant's step of ONE owner of eight (rank 3: targets [3e6, 4e6) against all 8e6 sources,
+    ludvm_advect_dev_f32 -- what `--symmetric 0` runs per rank).  256 sampled velocities against the C oracle at
+    1e-5 max|u| with NO absolute floor (|u| ~ 2e-5 here, so with the run's dt = 0.05 a displacement is one
+    ulp of x and (x1 - x0) / dt bounded nothing):
+      * the symmetric kernel's fixed-point sums themselves, converted as finish_sym does (sum / scale / 2 pi);
+      * the displacements of a step with dt = 2^16 (dt u exact, |dt u| ~ 1: the rounding of x + dt u is 1e-7 of max|u|),
+        which also passes through the Euler finishers -- both variants;
+    and conservation of the linear impulse sum_i G_i u_i (the pair forces cancel exactly in exact arithmetic)."""
     import torch
     from ludvm_amd.sharded import HipShardKernel, ShardedWake
     n = 8_000_000
@@ -773,23 +898,51 @@ def test_full_size_config4_self_advection_step(eng):
     z = rng.uniform(-2, 2, n).astype(np.float32)
     g = (rng.standard_normal(n) / n).astype(np.float32)
     dev = torch.device("cuda", 0)
-    dt = 5e-2
+    dt = 65536.0
     try:
         wake = ShardedWake(x, z, g, 0.065, dt, HipShardKernel(eng), dev, symmetric=True)
         assert wake.n_loc % 512 == 0 and wake.pairs_per_step == float(n) * n
         wake.step()
         x1, z1 = wake.positions()
-        sel = rng.choice(n, 256, replace=False)
+        sel = np.sort(rng.choice(n, 256, replace=False))
         ur, wr = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float), x[sel].astype(float),
                                            z[sel].astype(float), 0.065)
         scale = max(np.abs(ur).max(), np.abs(wr).max())
-        # displacement / dt, limited by the fp32 rounding of the updated position (ulp(10) / dt ~ 2e-5)
-        assert np.abs((x1[sel].astype(float) - x[sel]) / dt - ur).max() < 2e-5 * scale + 4e-5
-        assert np.abs((z1[sel].astype(float) - z[sel]) / dt - wr).max() < 2e-5 * scale + 2e-5
+        assert 1e-5 < scale < 1e-3                      # (the regime the old absolute floor of 2-4e-5 swallowed)
+        # (a) the raw fixed-point sums (the step leaves them in the wake's accumulator: u | w | NaN counter)
+        rec = wake._scale.cpu().numpy()
+        inv = float(rec[8:16].view(np.float64)[0])      # SymScale {float scale, pad; double inv}
+        assert float(rec[:4].view(np.float32)[0]) * inv == 1.0
+        acc = wake._acc.cpu().numpy()
+        assert acc[2 * wake.n_pad] == 0                 # no non-finite partial sum
+        su, sw = acc[:n].astype(np.float64) * inv / (2 * np.pi), -acc[wake.n_pad:wake.n_pad + n].astype(np.float64) * inv / (2 * np.pi)
+        assert np.abs(su[sel] - ur).max() < 1e-5 * scale and np.abs(sw[sel] - wr).max() < 1e-5 * scale
         gd = g.astype(float)
-        for a0, a1 in ((x, x1), (z, z1)):
-            drift = abs(np.sum(gd * (a1.astype(float) - a0)))
-            assert drift < 1e-3 * np.sum(np.abs(gd) * np.abs(a1.astype(float) - a0)) + 1e-9
+        for v in (su, sw):
+            assert abs(np.sum(gd * v)) < 1e-3 * np.sum(np.abs(gd * v))
+        # (b) through the Euler finisher: displacement / 2^16
+        ud, wd = (x1.astype(float) - x) / dt, (z1.astype(float) - z) / dt
+        assert np.abs(ud[sel] - ur).max() < 1e-5 * scale and np.abs(wd[sel] - wr).max() < 1e-5 * scale
+        assert np.abs(ud - su).max() < 2e-6 * scale and np.abs(wd - sw).max() < 2e-6 * scale     # all 8e6: finisher == sums
+        del wake
+        # (c) the direct variant, owner 3 of 8
+        lo, cnt = 3_000_000, 1_000_000
+        dx, dz, dg = (torch.from_numpy(a).to(dev) for a in (x, z, g))
+        ox, oz = torch.empty(cnt, dtype=torch.float32, device=dev), torch.empty(cnt, dtype=torch.float32, device=dev)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.advect_dev(dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, lo, cnt, 0.065, dt, ox.data_ptr(), oz.data_ptr())
+        torch.cuda.synchronize()
+        own = sel[(sel >= lo) & (sel < lo + cnt)]
+        extra = np.sort(rng.choice(cnt, 256 - len(own), replace=False)) + lo
+        tsel = np.unique(np.r_[own, extra])
+        ur2, wr2 = c_oracle.induced_velocity(g.astype(float), x.astype(float), z.astype(float), x[tsel].astype(float),
+                                             z[tsel].astype(float), 0.065)
+        scale2 = max(np.abs(ur2).max(), np.abs(wr2).max())
+        u2 = (ox.cpu().numpy().astype(float) - x[lo:lo + cnt]) / dt
+        w2 = (oz.cpu().numpy().astype(float) - z[lo:lo + cnt]) / dt
+        assert np.abs(u2[tsel - lo] - ur2).max() < 1e-5 * scale2 and np.abs(w2[tsel - lo] - wr2).max() < 1e-5 * scale2
+        # ... and the two variants agree on the whole block
+        assert np.abs(u2 - su[lo:lo + cnt]).max() < 1e-5 * scale and np.abs(w2 - sw[lo:lo + cnt]).max() < 1e-5 * scale
     finally:
         eng.set_stream(None)
 

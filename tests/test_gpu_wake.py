@@ -664,6 +664,38 @@ def test_march_calls_that_begin_on_a_multiple_of_64(threshold, prec):
         e.close()
 
 
+def test_time_loop_over_an_unordered_cloud_of_free_vortices(eng, tmp_path):
+    """A cloud of free vortices in no spatial order (LUDVM.generate_flowfield_turbulence, LUDVM.py:98-130) in an fp32 run:
+    the class stores it in the order the engine names (ludvm_spatial_order) and hands every path['FREE'] row back in the
+    caller's order -- per-step path, marched dense history, and across a checkpoint / resume (bit for bit)."""
+    from ludvm_amd import LUDVM
+    rng = np.random.default_rng(21)
+    nf = 6000
+    xy = np.stack([rng.uniform(-3.0, -0.5, nf), rng.uniform(-1.0, 1.0, nf)])
+    gam = rng.standard_normal(nf) * 2e-5
+    kw = dict(CONFIG1, tf=1.5, circulation_freevort=gam, xy_freevort=xy)
+    ref = LUDVM(**kw, verbose=False, engine=eng, precision="f64", history="full")
+    assert ref._free_slot is None                              # float64 needs no order
+    runs = {}
+    for name, opts in (("march", dict(march=True)), ("per step", dict(march=False))):
+        r = runs[name] = LUDVM(**kw, verbose=False, engine=eng, precision="f32", history="full", **opts)
+        assert r._free_slot is not None and np.array_equal(np.sort(r._free_slot), np.arange(nf)), name
+        assert np.array_equal(r.path["FREE"][0], xy), name                     # the caller's order, from the first row on
+        assert np.array_equal(r.LEV_shed, ref.LEV_shed), name
+        assert np.abs(r.path["FREE"] - ref.path["FREE"]).max() < 1e-5, name    # vortex by vortex, every step
+        for q in ("Cl", "Cd", "Cm"):
+            assert np.abs(getattr(r, q) - getattr(ref, q)).max() <= 2e-5 * max(1.0, np.abs(getattr(ref, q)).max()), (name, q)
+    ck = str(tmp_path / "cloud.npz")
+    a = LUDVM(**kw, verbose=False, engine=eng, precision="f32", history="sparse", snapshot_steps=[10, 29])
+    LUDVM(**kw, verbose=False, engine=eng, precision="f32", history="sparse", snapshot_steps=[10, 29], checkpoint_every=12,
+          checkpoint_path=ck)
+    c = LUDVM.resume(ck, engine=eng, verbose=False)            # continues from step 25 with the stored order
+    assert np.array_equal(c._free_slot, a._free_slot)
+    assert np.array_equal(a.Cl, c.Cl) and np.array_equal(a.path["FREE"][29], c.path["FREE"][29])
+    assert np.array_equal(a.path["FREE"][a.nt - 1], c.path["FREE"][c.nt - 1])
+    assert np.abs(a.path["FREE"][a.nt - 1] - ref.path["FREE"][-1]).max() < 1e-5
+
+
 def test_march_with_the_quad_variant_of_the_symmetric_kernel():
     """The quad variant (four I tiles per workgroup share each partner tile; default from 1024 tiles) inside the march, where
     the kernel reads the wake size -- and with it its whole geometry, quads and owner blocks included -- on the device:

@@ -51,7 +51,20 @@ def main():
             eng.wake_clear()
             eng.wake_append(x, z, g)
             u, w = eng.wake_advect(2.0 ** -10, [], [], [], vc, precision="f32", return_velocity=True)
-            rec[f"wake_advect_{kname}_f32"] = float(max(np.abs(u[sel] - ur).max(), np.abs(w[sel] - wr).max()) / scale)
+            rec[f"wake_advect_{kname}_f32_callers_order"] = float(max(np.abs(u[sel] - ur).max(), np.abs(w[sel] - wr).max()) / scale)
+            if hasattr(eng, "spatial_order"):
+                # what LUDVM.time_loop does with a cloud of free vortices: store it in the order the engine names, and take
+                # hi+lo positions when even that order leaves the classes too wide for the core
+                order, reordered, extent = eng.spatial_order(x, z, with_extent=True)
+                slot = np.empty(n, np.int64)
+                slot[order] = np.arange(n)
+                prec = "f32x2" if extent > 300 * vc else "f32"
+                eng.wake_clear()
+                eng.wake_append(x[order], z[order], g[order])
+                u, w = eng.wake_advect(2.0 ** -10, [], [], [], vc, precision=prec, return_velocity=True)
+                rec[f"wake_advect_{kname}_engine_order_{prec}"] = float(max(np.abs(u[slot[sel]] - ur).max(),
+                                                                        np.abs(w[slot[sel]] - wr).max()) / scale)
+                rec["mean_class_extent_over_vcore"] = extent / vc
         eng.set_symmetric(1)
         rec["normalised_by_max_over_all_targets"] = {k: v * scale / scale_all for k, v in rec.items()
                                                      if k.startswith(("induce", "wake")) and not k.endswith("_s")}
