@@ -806,10 +806,11 @@ int spatial_order_if_needed(ludvm_ctx* c, const OrderWs& w, int slot, const doub
 }
 
 // fp32 on local origins resolves a pair difference to ~6e-8 of its class's extent; next to a core of radius v_core that is
-// (2 ... 6.5)e-8 extent / v_core of max|u| [MI355X: 1e6 / 1e5 vortices and 4096 targets in a 10 x 4 box at v_core = 1.3e-3:
-// extents 0.14 / 0.45 / 2.2, errors 2e-6 / 7e-6 / 1e-4].  Beyond this ratio -- a set too SPARSE for its core, which no order
-// can mend: a class is 128 points wherever they lie -- a stateless fp32 call takes hi+lo positions (exact differences, +30 %
-// time), so LUDVM_PREC_F32 keeps 1e-5 of max|u| for any input.  (A shed wake at config 2's spacing sits at 230.)
+// ~1.3e-8 extent / v_core of max|u| [MI355X, profiles/r04_unordered_accuracy.txt: 1e6 / 1e5 vortices in a 10 x 4 box at
+// v_core = 1.3e-3, Morton order: mean class extents 0.35 / 1.09 = 267 / 837 v_core, errors 3.4e-6 / 6.9e-6 of the sampled
+// max|u|; 4096 targets in the same box: 1e-4].  Beyond this ratio -- a set too SPARSE for its core, which no order can mend: a
+// class is 128 points wherever they lie -- a stateless fp32 call takes hi+lo positions (exact differences, +30 % time), so
+// LUDVM_PREC_F32 keeps 1e-5 of max|u| for any input.  (A shed wake at config 2's spacing sits at 230.)
 constexpr double kMaxExtentOverCore = 300.0;
 
 bool valid_precision(int p) { return p == LUDVM_PREC_F32 || p == LUDVM_PREC_F32X2 || p == LUDVM_PREC_F64; }

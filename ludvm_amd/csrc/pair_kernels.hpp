@@ -462,9 +462,17 @@ constexpr int kFewGroupsMax = 4;
 template <int TILE>
 __global__ void __launch_bounds__(kBlock)
 pair_f64_few(PairArgs a) {
-  __shared__ __attribute__((aligned(16))) double lx[kFewGroupsMax][TILE];
-  __shared__ __attribute__((aligned(16))) double lz[kFewGroupsMax][TILE];
-  __shared__ __attribute__((aligned(16))) double lg[kFewGroupsMax][TILE];
+  // A wavefront that straddles two groups (83 targets: lanes 64 .. 82 of wave 1 belong to group 0, the rest to group 1)
+  // reads the same j of two groups' tiles in one instruction; TILE doubles apart they share a bank (1024 B = 4 x 64 banks):
+  // SQ_LDS_BANK_CONFLICT was 10 % of this kernel's busy cycles in config 2 [MI355X, profiles/r04_config2_sizes_pmc_sq.csv].
+  // Two doubles of padding per group move the groups 4 banks apart.  (Addresses only: the same bits.)
+#ifndef LUDVM_FEW_PAD
+#define LUDVM_FEW_PAD 2
+#endif
+  constexpr int kPad = LUDVM_FEW_PAD;
+  __shared__ __attribute__((aligned(16))) double lx[kFewGroupsMax][TILE + kPad];
+  __shared__ __attribute__((aligned(16))) double lz[kFewGroupsMax][TILE + kPad];
+  __shared__ __attribute__((aligned(16))) double lg[kFewGroupsMax][TILE + kPad];
   const double* __restrict__ xs = static_cast<const double*>(a.xs);
   const double* __restrict__ zs = static_cast<const double*>(a.zs);
   const double* __restrict__ gs = static_cast<const double*>(a.gs);
