@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of two builds of the library on config 2 (full time_loop) -- alternating, three rounds:
-#   bash tools/ab_libs_cfg2.sh <libA.so> <libB.so>      (python-side switch LUDVM_HIP_LIB; run on the GPU box)
+#   bash tools/libs_ab_cfg2.sh <libA.so> <libB.so>      (python-side switch LUDVM_HIP_LIB; run on the GPU box)
 set -o pipefail
 A=$1; B=$2
 for r in 1 2 3; do
