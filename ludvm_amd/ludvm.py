@@ -500,13 +500,19 @@ class LUDVM:
                 self._shard.attach(eng, nf + 2 * nv + npan + 2)
             i = first_step
             while i < nt:
-                if can_march and (dense_march or not self._record_row(i)):
-                    j = i
-                    while j < nt and (dense_march or not self._record_row(j)) and j - i < march_chunk:
+                if can_march:
+                    # Every step is marched, whatever the history mode: a step whose row is recorded (sparse history) is a
+                    # call of its own that also returns the wake's positions after it -- so a run's bits do not depend on
+                    # which rows it keeps (rounds 1-3 took recorded steps through the per-step path, whose launches are
+                    # sized from the exact wake size instead of the march's anchor bound: fp32 rounding differed from the
+                    # first recorded step on)
+                    rec_i = (not dense_march) and self._record_row(i)
+                    j = i + 1 if rec_i else i
+                    while (not rec_i) and j < nt and (dense_march or not self._record_row(j)) and j - i < march_chunk:
                         j += 1
                         if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
                             break
-                    if j - i >= 2:
+                    if j > i:
                         if have_next:
                             place = [sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1]]
                         else:
@@ -516,7 +522,7 @@ class LUDVM:
                             place = [tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]]
                         (itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev) = self._march_stretch(
                             i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed, tev_slot,
-                            lev_slot, prec_code, record=dense_march)
+                            lev_slot, prec_code, record=dense_march or rec_i)
                         have_next = False
                         if self.verbose == True:  # noqa: E712
                             for q in range(i, j):
@@ -755,17 +761,26 @@ class LUDVM:
             # rows of the dense history from the per-step snapshots (wake order -> TEV / LEV / FREE slots); on a step
             # without LEV shedding the reference's zero-strength LEV slot lands at dt * (velocity at the origin)
             P = self.path
+            fsl = slice(0, nf) if self._free_slot is None else self._free_slot
             for r in range(cnt):
                 q, it, il = i + r, itev + r, int(levs_before[r])
                 xs, zs = hist[r, 0], hist[r, 1]
                 ts = tev_slot[:it + 1]
-                P['TEV'][q, 0, :it + 1], P['TEV'][q, 1, :it + 1] = xs[ts], zs[ts]
                 ls = lev_slot[:il + 1] if shed_v[r] else lev_slot[:il]
-                P['LEV'][q, 0, :len(ls)], P['LEV'][q, 1, :len(ls)] = xs[ls], zs[ls]
-                if not shed_v[r]:
-                    P['LEV'][q, :, il] = self.dt * R[r, 10:12]
-                fsl = slice(0, nf) if self._free_slot is None else self._free_slot
-                P['FREE'][q, 0, :], P['FREE'][q, 1, :] = xs[fsl], zs[fsl]
+                if self.history == 'full':
+                    P['TEV'][q, 0, :it + 1], P['TEV'][q, 1, :it + 1] = xs[ts], zs[ts]
+                    P['LEV'][q, 0, :len(ls)], P['LEV'][q, 1, :len(ls)] = xs[ls], zs[ls]
+                    if not shed_v[r]:
+                        P['LEV'][q, :, il] = self.dt * R[r, 10:12]
+                    P['FREE'][q, 0, :], P['FREE'][q, 1, :] = xs[fsl], zs[fsl]
+                elif self._record_row(q):
+                    # sparse history: the rows the per-step path would have stored (LEV row with the zero-strength slot)
+                    row_l = np.stack([xs[ls], zs[ls]])
+                    if not shed_v[r]:
+                        row_l = np.concatenate([row_l, (self.dt * R[r, 10:12])[:, None]], axis=1)
+                    P['TEV'].store(q, np.stack([xs[ts], zs[ts]]))
+                    P['LEV'].store(q, row_l)
+                    P['FREE'].store(q, np.stack([xs[fsl], zs[fsl]]))
         last_shed = bool(shed_v[-1])
         # as the per-step path leaves them: the counters before the last step's increment
         self.itev, self.ilev, self.LEV_shed = itev + cnt - 1, ilev + n_shed - int(last_shed), LEV_shed

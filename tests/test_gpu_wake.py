@@ -612,15 +612,11 @@ def test_march_bits_do_not_depend_on_where_the_calls_begin(threshold, prec, tmp_
         runs.append(LUDVM.resume(ck, engine=e, verbose=False))          # continues from step 211
         a = runs[0]
         for b in runs[1:]:
-            # (the LAST step is marched with the dense history -- solve on the device -- and a recorded per-step call with
-            # the sparse one -- solve on the host, roll-up sized from the exact wake size: across the two families
-            # everything before it is compared, within a family everything)
-            last = a.nt if b.history == a.history else a.nt - 1
+            # (round 4: recorded steps are marched too -- dense or sparse history, every step takes the same path)
             for name in ("Cl", "Cd", "Cm", "LEV_shed"):
-                assert np.array_equal(getattr(a, name)[:last], getattr(b, name)[:last]), (name, b.history)
-            assert np.array_equal(a.circulation["TEV"][:last - 1], b.circulation["TEV"][:last - 1])
-            if b.history == a.history:
-                assert np.array_equal(a.path["TEV"][a.nt - 1][:, :a.itev + 1], b.path["TEV"][b.nt - 1][:, :b.itev + 1])
+                assert np.array_equal(getattr(a, name), getattr(b, name)), (name, b.history)
+            assert np.array_equal(a.circulation["TEV"], b.circulation["TEV"])
+            assert np.array_equal(a.path["TEV"][a.nt - 1][:, :a.itev + 1], b.path["TEV"][b.nt - 1][:, :b.itev + 1])
         d0, d1 = [r for r in runs if r.history == "full"]
         assert np.array_equal(d0.path["TEV"], d1.path["TEV"]) and np.array_equal(d0.path["LEV"], d1.path["LEV"])
     finally:
@@ -653,13 +649,21 @@ def test_march_calls_that_begin_on_a_multiple_of_64(threshold, prec):
             for name in ("Cl", "Cd", "Cm", "LEV_shed"):
                 assert np.array_equal(getattr(whole, name), getattr(b, name)), name
             assert np.array_equal(whole.path["TEV"][whole.nt - 1], b.path["TEV"][b.nt - 1])
-        # recorded steps are per-step calls (solve on the host, roll-up sized from the exact wake): such a run is its own
-        # family -- what is asserted is that every stretch runs (those after steps 255 and 319 begin at 256 and 320), that
-        # it sheds like the uncut run and stays within rounding of it while the flow has not amplified the difference
+        # a recorded step is a march call of its own that also returns the wake (round 4; it used to take the per-step path,
+        # whose launches are sized differently): the stretches after steps 255 and 319 begin at 256 and 320, and the run
+        # that keeps 69 rows has the bits of the run that keeps one
         snap = LUDVM(**kw, verbose=False, engine=e, precision=prec, history="sparse", snapshot_steps=range(0, 341, 5))
-        assert np.array_equal(snap.LEV_shed[:100], whole.LEV_shed[:100])
-        assert np.abs(snap.Cl[:60] - whole.Cl[:60]).max() <= (1e-9 if prec == "f64" else 2e-4)
-        assert 255 in snap.path["TEV"] and 320 in snap.path["TEV"]
+        for name in ("Cl", "Cd", "Cm", "LEV_shed"):
+            assert np.array_equal(getattr(whole, name), getattr(snap, name)), name
+        assert 255 in snap.path["TEV"] and 320 in snap.path["TEV"] and 256 not in snap.path["TEV"]
+        assert np.array_equal(whole.path["TEV"][whole.nt - 1], snap.path["TEV"][snap.nt - 1])
+        # ... and its rows are the dense history's rows (the zero-strength LEV slot of non-shedding steps included)
+        dense = LUDVM(**kw, verbose=False, engine=e, precision=prec, history="full")
+        assert np.array_equal(dense.Cl, whole.Cl)
+        for q in (5, 100, 255, 320, 340):
+            for key in ("TEV", "LEV", "FREE"):
+                row = np.asarray(snap.path[key][q])
+                assert np.array_equal(row, dense.path[key][q][:, :row.shape[1]]), (key, q)
     finally:
         e.close()
 
