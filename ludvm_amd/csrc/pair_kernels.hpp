@@ -788,7 +788,9 @@ cvt_packed_inputs_local(const double* in, long long ns, long long nt, float* xs,
   auto local = [&](long long base, long long i, long long len, float* off, float* org) {
     const long long b = i >> kOriginShift;
     const int p = (int)(i & 1);
-    const float o = (float)in[base + origin_index(b, p, len)];
+    // (a class whose middle member is not a number -- a NaN target poisons only itself in the reference's sum -- takes 0)
+    const float o_raw = (float)in[base + origin_index(b, p, len)];
+    const float o = __builtin_fabsf(o_raw) < __builtin_inff() ? o_raw : 0.0f;
     if ((i & (kOriginBlock - 1)) < 2) org[2 * b + p] = o;
     // (a block that holds a single element: its odd class has no member to write the record, which the kernels still read)
     if ((i & (kOriginBlock - 1)) == 0 && i + 1 >= len) org[2 * b + 1] = o;

@@ -107,9 +107,40 @@ def test_empty_and_ragged_shapes(eng):
             xs, zs, g = rng.uniform(-3, 0, ns), rng.uniform(-1, 1, ns), rng.standard_normal(ns)
             xt, zt = rng.uniform(-3, 0, nt), rng.uniform(-1, 1, nt)
             ur, wr = O.induced_velocity(g, xs, zs, xt, zt, 0.065)
-            for prec, tol in (("f32", 2e-5), ("f64", 1e-12)):
-                u, w = eng.induce(g, xs, zs, xt, zt, 0.065, precision=prec)
-                assert _rel(u, w, ur, wr) <= tol, (ns, nt, prec)
+            u, w = eng.induce(g, xs, zs, xt, zt, 0.065, precision="f64")
+            assert _rel(u, w, ur, wr) <= 1e-12, (ns, nt)
+            u, w = eng.induce_f32(g, xs, zs, xt, zt, 0.065)          # the fp32 direct kernels on the caller's coordinates
+            assert _rel(u.astype(float), w.astype(float), ur, wr) <= 2e-5, (ns, nt)
+    # both sides from 2048 points on: fp32 on local origins (these random arrays are taken in Morton order on the device)
+    for ns, nt in ((2048, 2048), (2049, 4097), (4097, 2300), (30001, 2051)):
+        xs, zs, g = rng.uniform(-3, 0, ns), rng.uniform(-1, 1, ns), rng.standard_normal(ns)
+        xt, zt = rng.uniform(-3, 0, nt), rng.uniform(-1, 1, nt)
+        ur, wr = c_oracle.induced_velocity(g, xs, zs, xt, zt, 0.065)
+        u, w = eng.induce(g, xs, zs, xt, zt, 0.065, precision="f32")
+        assert _rel(u, w, ur, wr) <= 1e-5, (ns, nt)
+
+
+def test_a_non_finite_target_poisons_only_itself(eng):
+    """The reference's sum gives NaN exactly at a target whose position is NaN and nowhere else (LUDVM.py:556-569).  fp32 on
+    local origins refers a class of 128 targets to its middle member: when THAT one is not a number the class takes the
+    coordinate origin instead -- on a compact (kept as stored) and on an unordered (Morton-ordered) target set."""
+    rng = np.random.default_rng(8)
+    ns = 3000
+    xs, zs, g = rng.uniform(-3, 0, ns), rng.uniform(-1, 1, ns), rng.standard_normal(ns)
+    for layout in ("sheet", "cloud"):
+        nt = 5000
+        xt = np.linspace(-3.0, 0.0, nt) if layout == "sheet" else rng.uniform(-3, 0, nt)
+        zt = 0.1 * np.sin(3 * xt) if layout == "sheet" else rng.uniform(-1, 1, nt)
+        bad = [128, 129, 2500]                    # 128 / 129: the middle members of block 0's two classes (as stored)
+        xt[bad[0]], zt[bad[1]], xt[bad[2]] = np.nan, np.inf, -np.inf
+        ok = np.ones(nt, bool)
+        ok[bad] = False
+        ur, wr = c_oracle.induced_velocity(g, xs, zs, xt[ok], zt[ok], 0.065)
+        for prec in ("f32", "f32x2", "f64"):
+            u, w = eng.induce(g, xs, zs, xt, zt, 0.065, precision=prec)
+            assert not np.isfinite(u[bad[0]]) and not np.isfinite(w[bad[2]]), (layout, prec)
+            assert np.isfinite(u[ok]).all() and np.isfinite(w[ok]).all(), (layout, prec, int((~np.isfinite(u[ok])).sum()))
+            assert _rel(u[ok], w[ok], ur, wr) <= (1e-12 if prec == "f64" else 1e-5), (layout, prec)
 
 
 def test_strided_and_integer_inputs(eng, g1_cases):
