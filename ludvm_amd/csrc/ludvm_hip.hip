@@ -2167,7 +2167,7 @@ int ludvm_flowfield_dev_f32(ludvm_ctx* c, double xmin, double zmin, double dr, s
 // generated in float64 and referred to each source block's origin, so a flow field over a wake at |x| ~ 50 with
 // vortices 1e-3 apart keeps the precision it has near the origin (LUDVM.py:1206, :1216-1217 evaluate in float64).
 static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, const double* zs, const double* gs, size_t ns,
-                                  PairArgs& a) {
+                                  PairArgs& a, double* mean_extent) {
   const size_t nsb = (size_t)origin_slots((long long)ns);
   double* dxs = ar.take<double>(ns);
   double* dzs = ar.take<double>(ns);
@@ -2177,26 +2177,32 @@ static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, con
   float* fgs = ar.take<float>(ns);
   float* sox = ar.take<float>(nsb);
   float* soz = ar.take<float>(nsb);
+  double* oxs = ar.take<double>(ns);
+  double* ozs = ar.take<double>(ns);
+  double* ogs = ar.take<double>(ns);
   HIPCHK(c, hipMemcpyAsync(dxs, xs, ns * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dzs, zs, ns * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dgs, gs, ns * 8, hipMemcpyHostToDevice, c->stream));
   const dim3 bs(kBlock), gs_(blocks_for((long long)ns));
+  OrderWs ow{};
+  CHK(order_workspace(c, ns, &ow));
+  *mean_extent = 0.0;
   if (ns >= kOrderMin) {
     // sources that are not in a compact order (a turbulence cloud rather than a shed wake) are taken in Morton order: the
     // sum over the sources does not care, the origin classes become compact (every rank of a sharded flow field holds the
     // same sources and derives the same order: the row blocks stay bit for bit the one-GPU rows)
-    double* oxs = ar.take<double>(ns);
-    double* ozs = ar.take<double>(ns);
-    double* ogs = ar.take<double>(ns);
-    OrderWs ow{};
-    CHK(order_workspace(c, ns, &ow));
     const unsigned* ord = nullptr;
-    CHK(spatial_order_if_needed(c, ow, 0, xs, zs, dxs, dzs, ns, &ord, nullptr));
+    CHK(spatial_order_if_needed(c, ow, 0, xs, zs, dxs, dzs, ns, &ord, mean_extent));
     if (ord) {
       hipLaunchKernelGGL(gather_f64, gs_, bs, 0, c->stream, dxs, dzs, dgs, ord, (long long)ns, oxs, ozs, ogs);
       HIPCHK(c, hipGetLastError());
       dxs = oxs; dzs = ozs; dgs = ogs;
     }
+  } else {
+    // (too few to order; how wide their classes are still decides whether fp32 offsets resolve the core)
+    double e = 0.0;
+    CHK(class_extent_sum(c, ow, dxs, dzs, nullptr, ns, &e));
+    *mean_extent = e / (2.0 * std::ceil((double)ns / kOriginBlock));
   }
   hipLaunchKernelGGL(cvt_f64_to_local, gs_, bs, 0, c->stream, dxs, fxs, sox, (long long)ns);
   hipLaunchKernelGGL(cvt_f64_to_local, gs_, bs, 0, c->stream, dzs, fzs, soz, (long long)ns);
@@ -2259,7 +2265,20 @@ static int flowfield_rows(ludvm_ctx* c, double xmin, double zmin, double dr, siz
       HIPCHK(c, hipMemcpyAsync(dgs, gs, ns * 8, hipMemcpyHostToDevice, c->stream));
       a.xs = dxs; a.zs = dzs; a.gs = dgs; a.ns = (long long)ns;
     } else {
-      CHK(flowfield_upload_local(c, ar, xs, zs, gs, ns, a));
+      double mean_extent = 0.0;
+      CHK(flowfield_upload_local(c, ar, xs, zs, gs, ns, a, &mean_extent));
+      if (vcore > 0.0 && mean_extent > kMaxExtentOverCore * vcore) {
+        // Sources too sparse for their core (kMaxExtentOverCore): fp32 offsets cannot resolve it in any order and the grid
+        // kernels have no hi+lo variant -- the rows are evaluated in float64 (LUDVM.py:1206, :1216-1217 do) and returned as
+        // float32.  Rare: a shed wake sits at 230 v_core, config 5's cloud at 2.
+        const size_t cnt = row_count * nz;
+        std::vector<double> hu(cnt), hw(cnt), ho(ome ? cnt : 0);
+        CHK(flowfield_rows<double>(c, xmin, zmin, dr, nx, nz, row_first, row_count, xs, zs, gs, ns, vcore, hu.data(), hw.data(),
+                                   ome ? ho.data() : nullptr));
+        for (size_t k = 0; k < cnt; ++k) { u[k] = (T)hu[k]; w[k] = (T)hw[k]; }
+        if (ome) for (size_t k = 0; k < cnt; ++k) ome[k] = (T)ho[k];
+        return LUDVM_OK;
+      }
     }
     a.nt = (long long)nt;
     a.grid_nz = (long long)nz;

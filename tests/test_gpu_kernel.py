@@ -486,16 +486,25 @@ def test_a_shed_wake_keeps_its_order_and_its_bits(eng):
     assert not eng.spatial_order(xc[order], zc[order])[1]
 
 
-def test_flowfield_over_an_unordered_cloud_keeps_1e5(eng):
-    """LUDVM.flowfield over a turbulence cloud (sources in no order): the host entry takes the sources in Morton order
-    (the sum over sources does not care), the float64 grid points are referred to compact source classes."""
-    vc = 1.3e-3
+@pytest.mark.parametrize("vc,tol", [(0.01, 1e-5), (1.3e-3, 3e-7)])
+def test_flowfield_over_an_unordered_cloud_keeps_1e5(eng, vc, tol):
+    """LUDVM.flowfield over a turbulence cloud (sources in no order).  v_core = 0.01: the host entry takes the sources in
+    Morton order (the sum over sources does not care), the float64 grid points are referred to compact source classes.
+    v_core = 1.3e-3: 2e5 sources in a 10 x 4 box are too sparse for that core in ANY order (mean class extent ~600 v_core;
+    ludvm_hip.hip, kMaxExtentOverCore) and the grid kernels have no hi+lo variant: the rows are evaluated in float64 and
+    returned as float32."""
     x, z, g = _cloud(200_000, seed=9)
     xmin, zmin, dr, nx, nz = -55.3, -0.2, 0.004, 48, 64
     u, w = eng.flowfield(xmin, zmin, dr, nx, nz, g, x, z, vc)
+    assert u.dtype == np.float32
     X, Z = np.meshgrid(xmin + np.arange(nx) * dr, zmin + np.arange(nz) * dr, indexing="ij")
     ur, wr = c_oracle.induced_velocity(g, x, z, X.ravel(), Z.ravel(), vc)
-    assert _rel(u.ravel(), w.ravel(), ur, wr) < 1e-5
+    assert _rel(u.ravel(), w.ravel(), ur, wr) < tol
+    extent = eng.spatial_order(x, z, with_extent=True)[2]
+    assert (extent > 300 * vc) == (vc < 0.005)
+    # the fused call (velocity + vorticity) takes the same route and returns the same velocities
+    u2, w2, ome2 = eng.flowfield_vorticity(xmin, zmin, dr, nx, nz, g, x, z, vc)
+    assert np.array_equal(u, u2) and np.array_equal(w, w2) and np.isfinite(ome2).all()
 
 
 def test_flowfield_float64_mode_and_row_blocks(eng):
