@@ -484,6 +484,20 @@ def test_a_shed_wake_keeps_its_order_and_its_bits(eng):
     order, reordered = eng.spatial_order(xc, zc)
     assert reordered
     assert not eng.spatial_order(xc[order], zc[order])[1]
+    # odd sizes, degenerate sets: always a permutation; points on a line or all in one place need no order
+    for n in (2048, 2049, 65537, 300_001):
+        xo, zo, _ = _cloud(n, seed=n)
+        order, reordered = eng.spatial_order(xo, zo)
+        assert reordered and np.array_equal(np.sort(order), np.arange(n)), n
+        # neighbours in the order are neighbours in space: the mean step is a few point spacings, not the box size
+        step = np.hypot(np.diff(xo[order]), np.diff(zo[order])).mean()
+        assert step < 3.0 * np.sqrt(40.0 / n) and step < 0.1 * np.hypot(np.diff(xo), np.diff(zo)).mean(), (n, step)
+    line = np.linspace(-60.0, -50.0, 5000)
+    assert not eng.spatial_order(line, np.zeros(5000))[1]
+    assert not eng.spatial_order(np.full(5000, -55.0), np.full(5000, 0.25))[1]
+    shuffled = np.random.default_rng(2).permutation(line)
+    order, reordered = eng.spatial_order(shuffled, np.zeros(5000))          # a shuffled line IS put back in order
+    assert reordered and np.all(np.diff(shuffled[order]) >= -10.0 / 65535)
 
 
 @pytest.mark.parametrize("vc,tol", [(0.01, 1e-5), (1.3e-3, 3e-7)])
