@@ -16,9 +16,16 @@ import time
 import numpy as np
 
 # From these sizes on the class-level sharding engages (LUDVM(distributed=...)): below them one collective per call / per
-# time step costs more than the split saves.  Estimates from one-GPU kernel times against an assumed ~20-50 us collective
-# floor -- NOT yet measured on xGMI (no multi-GPU box has been available to this build); both are constructor arguments of
-# ShardGroup / LibraryGroup.
+# time step costs more than the split saves.  What a sharded roll-up step SAVES is measured (one GPU, the slowest owner's
+# tile block against the whole ring: tools/shard_break_even.py, profiles/r04_shard_break_even.txt [MI355X]):
+#     wake size      all-reduce     saved per step at G = 2 / 4 / 8
+#        32 768        0.5 MB          62 /   95 /   99 us
+#        65 536        1   MB         249 /  372 /  405 us
+#       131 072        2   MB         957 / 1460 / 1661 us      <- MIN_WAKE: a budget of 1-1.7 ms for a 2 MB all-reduce
+#       262 144        4   MB        3843 / 5897 / 6930 us
+# The collective's own time over xGMI is NOT yet measured (no multi-GPU box has been available to this build): 131 072 leaves
+# it a 10-30x margin over the tens of microseconds RCCL usually needs at that size; 65 536 would leave 3-8x.  Both are
+# constructor arguments of ShardGroup / LibraryGroup.
 MIN_TARGETS = 65536
 MIN_WAKE = 131072
 
