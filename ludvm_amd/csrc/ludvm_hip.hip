@@ -745,58 +745,55 @@ inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 int order_workspace(ludvm_ctx* c, size_t nmax, OrderWs* w) {
   const size_t nblk = (nmax + kOriginBlock - 1) / kOriginBlock;
   const size_t tb = spatial_order_temp_bytes(nmax);
-  CHK(ensure(c, c->orderws, 2 * up256(nmax * 4) + up256(nblk * 8) + 256 + tb));
+  CHK(ensure(c, c->orderws, 2 * up256(nmax * 4) + up256(nblk * 5 * 8) + 256 + tb));
   char* p = static_cast<char*>(c->orderws.p);
   w->order[0] = reinterpret_cast<unsigned*>(p); p += up256(nmax * 4);
   w->order[1] = reinterpret_cast<unsigned*>(p); p += up256(nmax * 4);
-  w->ext = reinterpret_cast<double*>(p); p += up256(nblk * 8);
+  w->ext = reinterpret_cast<double*>(p); p += up256(nblk * 5 * 8);
   w->sum = reinterpret_cast<double*>(p); p += 256;
   w->tmp = p;
   w->tmp_bytes = tb;
   return LUDVM_OK;
 }
 
-// Sum of the class extents of (dx, dz)[0, n) taken in `order` (nullptr: as stored) -> host.  Synchronizes the stream.
-int class_extent_sum(ludvm_ctx* c, const OrderWs& w, const double* dx, const double* dz, const unsigned* order, size_t n, double* out) {
+// Sum of the class extents of (dx, dz)[0, n) taken in `order` (nullptr: as stored), and the set's bounding box
+// box[4] = xmin, xmax, zmin, zmax (may be NULL) -> host.  Synchronizes the stream.
+int class_extent_sum(ludvm_ctx* c, const OrderWs& w, const double* dx, const double* dz, const unsigned* order, size_t n, double* out,
+                     double* box = nullptr) {
   const long long nblk = (long long)((n + kOriginBlock - 1) / kOriginBlock);
   hipLaunchKernelGGL(class_extents, dim3((unsigned)nblk), dim3(kOriginBlock), 0, c->stream, dx, dz, order, (long long)n, w.ext);
-  hipLaunchKernelGGL(sum_fixed_order, dim3(1), dim3(256), 0, c->stream, w.ext, nblk, w.sum);
+  hipLaunchKernelGGL(reduce_extents, dim3(1), dim3(256), 0, c->stream, w.ext, nblk, w.sum);
   HIPCHK(c, hipGetLastError());
   void* hv = nullptr;
-  CHK(d2h_small_sync(c, w.sum, sizeof(double), &hv));
-  *out = *static_cast<const double*>(hv);
+  CHK(d2h_small_sync(c, w.sum, 5 * sizeof(double), &hv));
+  const double* r = static_cast<const double*>(hv);
+  *out = r[0];
+  if (box) for (int k = 0; k < 4; ++k) box[k] = r[1 + k];
   return LUDVM_OK;
 }
 
-// Decide whether the n points (host copies hx, hz for the bounding box; device copies dx, dz) should be taken in Morton
+// Decide whether the n points (device float64 dx, dz) should be taken in Morton
 // order, and build that order in slot `slot` of the workspace.  *order_out = the permutation (position k holds the caller's
 // element order[k]) or nullptr when the given order stays: fewer than kOrderMin points, classes already as compact as an
 // area-filling arrangement would make them (3 x), or not at least 1.5 x less compact than the Morton order makes them.
 // *mean_extent = mean over the origin classes of (xmax - xmin) + (zmax - zmin) in the order that was chosen (0 when the
 // set was not examined).
-int spatial_order_if_needed(ludvm_ctx* c, const OrderWs& w, int slot, const double* hx, const double* hz, const double* dx,
-                            const double* dz, size_t n, const unsigned** order_out, double* mean_extent) {
+int spatial_order_if_needed(ludvm_ctx* c, const OrderWs& w, int slot, const double* dx, const double* dz, size_t n,
+                            const unsigned** order_out, double* mean_extent) {
   *order_out = nullptr;
   if (mean_extent) *mean_extent = 0.0;
   if (n < kOrderMin) return LUDVM_OK;
-  double x0 = 1e300, x1 = -1e300, z0 = 1e300, z1 = -1e300;
-  for (size_t i = 0; i < n; ++i) {
-    const double vx = hx[i], vz = hz[i];
-    if (std::fabs(vx) < 1e300 && std::fabs(vz) < 1e300) {
-      x0 = std::min(x0, vx); x1 = std::max(x1, vx); z0 = std::min(z0, vz); z1 = std::max(z1, vz);
-    }
-  }
-  const double ex = x1 - x0, ez = z1 - z0;
+  double e_given = 0.0, box[4];
+  CHK(class_extent_sum(c, w, dx, dz, nullptr, n, &e_given, box));
+  const double x0 = box[0], z0 = box[2], ex = box[1] - box[0], ez = box[3] - box[2];
   if (!(ex >= 0.0) || !(ez >= 0.0) || (ex == 0.0 && ez == 0.0)) return LUDVM_OK;      // nothing finite, or one point
-  double e_given = 0.0;
-  CHK(class_extent_sum(c, w, dx, dz, nullptr, n, &e_given));
   const double nclass = 2.0 * std::ceil((double)n / kOriginBlock);
   if (mean_extent) *mean_extent = e_given / nclass;
   const double side = std::sqrt(128.0 * ex * ez / (double)n);        // an area-filling class of 128 points
   if (e_given <= 3.0 * nclass * 2.0 * side) return LUDVM_OK;
   const double span = std::max(ex, ez);
-  OrderBox box{x0, z0, 65535.0 / span, 65535.0 / span};
-  HIPCHK(c, spatial_order_sort(dx, dz, n, box, w.tmp, w.tmp_bytes, w.order[slot], c->stream));
+  OrderBox box_k{x0, z0, 65535.0 / span, 65535.0 / span};
+  HIPCHK(c, spatial_order_sort(dx, dz, n, box_k, w.tmp, w.tmp_bytes, w.order[slot], c->stream));
   double e_sorted = 0.0;
   CHK(class_extent_sum(c, w, dx, dz, w.order[slot], n, &e_sorted));
   if (e_given <= 1.5 * e_sorted) return LUDVM_OK;
@@ -1195,9 +1192,9 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
     CHK(order_workspace(c, std::max(ns, nt), &ow));
     const unsigned* ord_s = nullptr;
     double ext_s = 0.0, ext_t = 0.0;
-    CHK(spatial_order_if_needed(c, ow, 0, xs, zs, din, din + ns, ns, &ord_s, &ext_s));
+    CHK(spatial_order_if_needed(c, ow, 0, din, din + ns, ns, &ord_s, &ext_s));
     if (self) ord_t = ord_s;
-    else CHK(spatial_order_if_needed(c, ow, 1, xt, zt, din + 3 * ns, din + 3 * ns + nt, nt, &ord_t, &ext_t));
+    else CHK(spatial_order_if_needed(c, ow, 1, din + 3 * ns, din + 3 * ns + nt, nt, &ord_t, &ext_t));
     if (vcore > 0.0 && std::max(ext_s, ext_t) > kMaxExtentOverCore * vcore) {
       hilo = true;                 // too sparse for its core: exact differences instead of an order (see kMaxExtentOverCore)
       ord_t = nullptr;
@@ -1308,7 +1305,7 @@ int ludvm_spatial_order(ludvm_ctx* c, const double* x, const double* z, size_t n
   OrderWs ow{};
   CHK(order_workspace(c, n, &ow));
   const unsigned* ord = nullptr;
-  CHK(spatial_order_if_needed(c, ow, 0, x, z, dx, dz, n, &ord, mean_class_extent));
+  CHK(spatial_order_if_needed(c, ow, 0, dx, dz, n, &ord, mean_class_extent));
   if (!ord) return LUDVM_OK;
   HIPCHK(c, hipMemcpyAsync(order, ord, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2192,7 +2189,7 @@ static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, con
     // sum over the sources does not care, the origin classes become compact (every rank of a sharded flow field holds the
     // same sources and derives the same order: the row blocks stay bit for bit the one-GPU rows)
     const unsigned* ord = nullptr;
-    CHK(spatial_order_if_needed(c, ow, 0, xs, zs, dxs, dzs, ns, &ord, mean_extent));
+    CHK(spatial_order_if_needed(c, ow, 0, dxs, dzs, ns, &ord, mean_extent));
     if (ord) {
       hipLaunchKernelGGL(gather_f64, gs_, bs, 0, c->stream, dxs, dzs, dgs, ord, (long long)ns, oxs, ozs, ogs);
       HIPCHK(c, hipGetLastError());
