@@ -222,6 +222,8 @@ class ShardedWake:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self._coll_events.append((tok, e1))
+        if len(self._coll_events) >= 1024:          # (a caller that never asks: fold the finished pairs in, keep the list short)
+            self.collective_time_ms(reset=False)
 
     def collective_time_ms(self, reset=True):
         """(average ms per collective, collectives timed) since the last reset; waits for the recorded events."""
@@ -238,8 +240,9 @@ class ShardedWake:
     # ---- do the replicas hold the same wake? ------------------------------------------------------------------------------
     def checksum(self):
         """Four 64-bit integers over the bit patterns of the current positions of the N real vortices: plain and
-        index-weighted sums of x and of z (the weights catch a permutation; no term can overflow: |bits| < 2^31, weight
-        <= 251, N < 2^23 per 2^62).  Every rank of a sharded run must report the same four numbers."""
+        index-weighted sums of x and of z (the weights, 1 .. 251 by index, catch a permutation; |bits| < 2^31, so the sums
+        stay below 2^63 up to 2^23 = 8.4e6 vortices and wrap -- identically on every rank -- beyond).  Every rank of a
+        sharded run must report the same four numbers."""
         idx = torch.arange(self.n, device=self.xs.device, dtype=torch.int64) % 251 + 1
         out = []
         for a in (self.xs, self.zs):
