@@ -507,7 +507,16 @@ class LUDVM:
                     # sized from the exact wake size instead of the march's anchor bound: fp32 rounding differed from the
                     # first recorded step on)
                     rec_i = (not dense_march) and self._record_row(i)
-                    j = i + 1 if rec_i else i
+                    j = i
+                    if rec_i:
+                        # a run of consecutive recorded steps is one call (its snapshots are [steps, 2, wake size] doubles:
+                        # at most 256 MB of them)
+                        n_now = nf + itev + ilev
+                        most = max(1, min(512, int(256e6 / (16.0 * (n_now + 1024)))))
+                        while j < nt and self._record_row(j) and j - i < most:
+                            j += 1
+                            if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
+                                break
                     while (not rec_i) and j < nt and (dense_march or not self._record_row(j)) and j - i < march_chunk:
                         j += 1
                         if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
