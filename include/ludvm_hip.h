@@ -164,8 +164,8 @@ int ludvm_comm_allgather_host(ludvm_ctx* ctx, const void* send, void* recv, size
  * :98-130 -- unlike a shed wake) are evaluated in Morton order on the device and the results returned in the caller's
  * order (the given order is kept, and with it every result bit, whenever it is already compact); a call with fewer
  * than 2048 sources or targets -- too few to make 128-point origin classes compact -- runs in float64, and a set too
- * sparse for its core (mean class extent > 300 v_core in the best order: fp32 offsets cannot resolve a core that small)
- * takes hi+lo positions as LUDVM_PREC_F32X2 does. */
+ * sparse for its core (mean class extent > 150 v_core in Morton order, > 300 v_core for a set that is compact as given:
+ * fp32 offsets cannot resolve a core that small) takes hi+lo positions as LUDVM_PREC_F32X2 does. */
 int ludvm_induce_f64(ludvm_ctx* ctx, const double* xs, const double* zs, const double* gs, size_t ns,
                      const double* xt, const double* zt, size_t nt, double vcore, int precision,
                      double* u, double* w);
@@ -175,7 +175,8 @@ int ludvm_induce_f64(ludvm_ctx* ctx, const double* xs, const double* zs, const d
  * vortices (LUDVM.py:98-130, :274-277) in this order and returns history rows in its own, so that fp32 roll-ups of an
  * unordered cloud keep the accuracy tier of a shed wake.  *mean_class_extent (may be NULL) = mean over the 128-point origin
  * classes, in that order, of (xmax - xmin) + (zmax - zmin); fp32 on local origins keeps 1e-5 of max|u| up to about
- * 300 v_core (beyond: LUDVM_PREC_F32X2).  Deterministic. */
+ * 150 v_core for a cloud that had to be reordered, 300 v_core for a set that is compact as given (beyond:
+ * LUDVM_PREC_F32X2).  Deterministic. */
 int ludvm_spatial_order(ludvm_ctx* ctx, const double* x, const double* z, size_t n, unsigned* order, int* reordered,
                         double* mean_class_extent);
 /* Same with host float32 buffers (always LUDVM_PREC_F32 arithmetic). */

@@ -803,12 +803,18 @@ int spatial_order_if_needed(ludvm_ctx* c, const OrderWs& w, int slot, const doub
 }
 
 // fp32 on local origins resolves a pair difference to ~6e-8 of its class's extent; next to a core of radius v_core that is
-// ~1.3e-8 extent / v_core of max|u| [MI355X, profiles/r04_unordered_accuracy.txt: 1e6 / 1e5 vortices in a 10 x 4 box at
-// v_core = 1.3e-3, Morton order: mean class extents 0.35 / 1.09 = 267 / 837 v_core, errors 3.4e-6 / 6.9e-6 of the sampled
-// max|u|; 4096 targets in the same box: 1e-4].  Beyond this ratio -- a set too SPARSE for its core, which no order can mend: a
-// class is 128 points wherever they lie -- a stateless fp32 call takes hi+lo positions (exact differences, +30 % time), so
-// LUDVM_PREC_F32 keeps 1e-5 of max|u| for any input.  (A shed wake at config 2's spacing sits at 230.)
-constexpr double kMaxExtentOverCore = 300.0;
+// up to ~5e-8 extent / v_core of max|u| for an area-filling cloud [MI355X, profiles/r04_extent_rule_calibration.txt: 2e5 ... 2e6
+// vortices in a 10 x 4 box, v_core 6.5e-4 ... 6.5e-2, Morton order: errors 0.5 ... 5e-8 per unit of extent / v_core, a tail
+// statistic of the rare pairs closer than v_core that straddle two classes; 9e-6 at a ratio of 189, 1.2e-5 at 376] and ~1.5e-8
+// for a shed wake, whose close pairs follow each other in the stored order (3.5e-6 at config 2's 230).  Beyond these ratios
+// -- a set too SPARSE for its core, which no order can mend: a class is 128 points wherever they lie -- a stateless fp32
+// call takes hi+lo positions (exact differences, +30 % time) and a flow field float64, so LUDVM_PREC_F32 keeps 1e-5 of
+// max|u| for any input.
+constexpr double kMaxExtentOverCore = 300.0;          // the given order was kept (compact as stored: sheet-like)
+constexpr double kMaxExtentOverCoreCloud = 150.0;     // the set had to be put in Morton order (area-filling)
+inline bool too_sparse(double mean_extent, bool reordered, double vcore) {
+  return vcore > 0.0 && mean_extent > (reordered ? kMaxExtentOverCoreCloud : kMaxExtentOverCore) * vcore;
+}
 
 bool valid_precision(int p) { return p == LUDVM_PREC_F32 || p == LUDVM_PREC_F32X2 || p == LUDVM_PREC_F64; }
 
@@ -1195,8 +1201,8 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
     CHK(spatial_order_if_needed(c, ow, 0, din, din + ns, ns, &ord_s, &ext_s));
     if (self) ord_t = ord_s;
     else CHK(spatial_order_if_needed(c, ow, 1, din + 3 * ns, din + 3 * ns + nt, nt, &ord_t, &ext_t));
-    if (vcore > 0.0 && std::max(ext_s, ext_t) > kMaxExtentOverCore * vcore) {
-      hilo = true;                 // too sparse for its core: exact differences instead of an order (see kMaxExtentOverCore)
+    if (too_sparse(ext_s, ord_s != nullptr, vcore) || too_sparse(ext_t, ord_t != nullptr && !self, vcore)) {
+      hilo = true;                 // too sparse for its core: exact differences instead of an order (see too_sparse)
       ord_t = nullptr;
     } else if (ord_s || (ord_t && !self)) {
       hipLaunchKernelGGL(gather_f64, dim3(blocks_for((long long)ns)), dim3(kBlock), 0, c->stream, din, din + ns, din + 2 * ns, ord_s,
@@ -2164,7 +2170,7 @@ int ludvm_flowfield_dev_f32(ludvm_ctx* c, double xmin, double zmin, double dr, s
 // generated in float64 and referred to each source block's origin, so a flow field over a wake at |x| ~ 50 with
 // vortices 1e-3 apart keeps the precision it has near the origin (LUDVM.py:1206, :1216-1217 evaluate in float64).
 static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, const double* zs, const double* gs, size_t ns,
-                                  PairArgs& a, double* mean_extent) {
+                                  PairArgs& a, double* mean_extent, bool* reordered) {
   const size_t nsb = (size_t)origin_slots((long long)ns);
   double* dxs = ar.take<double>(ns);
   double* dzs = ar.take<double>(ns);
@@ -2184,6 +2190,7 @@ static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, con
   OrderWs ow{};
   CHK(order_workspace(c, ns, &ow));
   *mean_extent = 0.0;
+  *reordered = false;
   if (ns >= kOrderMin) {
     // sources that are not in a compact order (a turbulence cloud rather than a shed wake) are taken in Morton order: the
     // sum over the sources does not care, the origin classes become compact (every rank of a sharded flow field holds the
@@ -2194,6 +2201,7 @@ static int flowfield_upload_local(ludvm_ctx* c, Arena& ar, const double* xs, con
       hipLaunchKernelGGL(gather_f64, gs_, bs, 0, c->stream, dxs, dzs, dgs, ord, (long long)ns, oxs, ozs, ogs);
       HIPCHK(c, hipGetLastError());
       dxs = oxs; dzs = ozs; dgs = ogs;
+      *reordered = true;
     }
   } else {
     // (too few to order; how wide their classes are still decides whether fp32 offsets resolve the core)
@@ -2263,9 +2271,10 @@ static int flowfield_rows(ludvm_ctx* c, double xmin, double zmin, double dr, siz
       a.xs = dxs; a.zs = dzs; a.gs = dgs; a.ns = (long long)ns;
     } else {
       double mean_extent = 0.0;
-      CHK(flowfield_upload_local(c, ar, xs, zs, gs, ns, a, &mean_extent));
-      if (vcore > 0.0 && mean_extent > kMaxExtentOverCore * vcore) {
-        // Sources too sparse for their core (kMaxExtentOverCore): fp32 offsets cannot resolve it in any order and the grid
+      bool reordered = false;
+      CHK(flowfield_upload_local(c, ar, xs, zs, gs, ns, a, &mean_extent, &reordered));
+      if (too_sparse(mean_extent, reordered, vcore)) {
+        // Sources too sparse for their core (too_sparse): fp32 offsets cannot resolve it in any order and the grid
         // kernels have no hi+lo variant -- the rows are evaluated in float64 (LUDVM.py:1206, :1216-1217 do) and returned as
         // float32.  Rare: a shed wake sits at 230 v_core, config 5's cloud at 2.
         const size_t cnt = row_count * nz;

@@ -195,7 +195,7 @@ class Engine:
         the identity when the given order is already compact or there are fewer than 2048 points (ludvm_spatial_order).
         Position k of an array stored in that order holds the caller's element order[k].  mean_class_extent: how compact
         the 128-point origin classes are in that order (0.0 below 2048 points); fp32 on local origins keeps its tier up
-        to about 300 v_core."""
+        to about 150 v_core for a reordered cloud, 300 v_core for a set that is compact as given."""
         xs, zs = _f64(x), _f64(z)
         if len(xs) != len(zs):
             raise ValueError("x and z must have the same length")

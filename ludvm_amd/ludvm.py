@@ -423,12 +423,12 @@ class LUDVM:
         fslot = None
         if self.precision == 'f32' and nf >= 2048 and hasattr(eng, 'spatial_order'):
             order, reordered, extent = eng.spatial_order(free0[0], free0[1], with_extent=True)
-            if extent > 300.0 * self.v_core > 0.0:
+            if extent > (150.0 if reordered else 300.0) * self.v_core > 0.0:
                 # too sparse for its core: no order makes 128-vortex classes compact enough for fp32 offsets to resolve
                 # v_core (ludvm_hip.h, ludvm_spatial_order) -- the roll-up takes hi+lo positions instead
                 import warnings
                 warnings.warn(f"LUDVM: the free-vortex cloud is too sparse for v_core = {self.v_core:g} to keep 1e-5 of max|u| "
-                              f"in fp32 on local origins (mean 128-vortex class extent {extent:.3g} > 300 v_core); "
+                              f"in fp32 on local origins (mean 128-vortex class extent {extent:.3g} > {150 if reordered else 300} v_core); "
                               "the wake-on-wake sums of this run use hi+lo positions (precision='f32x2')",
                               RuntimeWarning, stacklevel=3)
                 self.precision, reordered = 'f32x2', False

@@ -58,7 +58,7 @@ def main():
                 order, reordered, extent = eng.spatial_order(x, z, with_extent=True)
                 slot = np.empty(n, np.int64)
                 slot[order] = np.arange(n)
-                prec = "f32x2" if extent > 300 * vc else "f32"
+                prec = "f32x2" if extent > (150 if reordered else 300) * vc else "f32"
                 eng.wake_clear()
                 eng.wake_append(x[order], z[order], g[order])
                 u, w = eng.wake_advect(2.0 ** -10, [], [], [], vc, precision=prec, return_velocity=True)
