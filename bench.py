@@ -32,6 +32,10 @@ Config 4 (every N > 1 run) is a self-checking measurement, because nobody gets t
     that step (`gpu_vs_oracle_max_rel_err`, relative to max|u|).
   * a time budget (--budget-s, default 300 s of wall time for the whole process): the repeats and the other variant's
     step count shrink to fit (N = 2 steps take 3.5 s / 5.5 s each); what was run is stated (`steps`).
+  * two safety nets, because a hang in an optional late phase must not lose the measurement: the library's communicator is
+    joined in a helper thread (--comm-init-timeout: past it torch.distributed's collectives take over on a fresh engine);
+    and past --deadline-s (540 s) rank 0 prints the line as it stands -- `incomplete` names the phase that did not finish
+    -- and every rank exits.  The line is rebuilt at every milestone (reported region, other variant, each repeat, checks).
 
 The collective of the N > 1 step is issued INSIDE libludvm_hip.so on its own RCCL communicator (ludvm_comm_*;
 --collectives library, the default on the nccl backend; torch.distributed only ships the 128-byte identifier and does
@@ -154,10 +158,15 @@ def check_wake(wake, g, rank, torch):
     return rec
 
 
-def join_library_communicator(eng, rank, world, device, backend, dist, torch):
+def join_library_communicator(eng, rank, world, device, backend, dist, torch, timeout_s=90.0):
     """The engine's own communicator: rank 0's identifier goes round through torch (any channel would do); its sharding of
     resident-wake roll-ups is switched off (min_vortices), ShardedWake hands out the tile blocks itself.  If librccl cannot
-    be opened (every rank fails alike, before any collective), torch's collectives take over.  -> (collectives, note)"""
+    be opened (every rank fails alike, before any collective), torch's collectives take over.
+    The join (ncclCommInitRank: a collective with no timeout of its own) and the known-sum proof run in a helper thread:
+    a rank whose join does not return within `timeout_s` reports failure, the ranks agree on the outcome through torch, and
+    the run goes on with torch.distributed's collectives on a FRESH engine (the stuck call keeps the old context) -- the
+    first multi-GPU run must not be lost to a hang in an optional path.  -> (collectives, note, engine_abandoned)"""
+    import threading
     try:
         uid = [eng.comm_unique_id() if rank == 0 else None]
     except Exception as e:       # noqa: BLE001
@@ -166,31 +175,48 @@ def join_library_communicator(eng, rank, world, device, backend, dist, torch):
     if world > 1:
         dist.broadcast_object_list(uid, src=0, device=device if backend == "nccl" else None)
     if uid[0] is None:
-        return "torch", (note if rank == 0 else "library communicator unavailable on rank 0; torch.distributed collectives used")
+        return "torch", (note if rank == 0 else "library communicator unavailable on rank 0; torch.distributed collectives used"), False
     # join, then prove the communicator on a known sum before the steps depend on it; the ranks agree on the outcome through
     # torch (one rank falling back alone would leave the others inside a collective)
-    ok, why = 1, ""
-    try:
-        eng.comm_init(rank, world, uid[0], min_vortices=1 << 62)
-        chk = torch.arange(1, 9, dtype=torch.int64, device=device) * (rank + 1)
-        torch.cuda.synchronize()
-        eng.comm_allreduce_i64_dev(chk.data_ptr(), chk.numel())
-        torch.cuda.synchronize()
-        want = torch.arange(1, 9, dtype=torch.int64) * (world * (world + 1) // 2)
-        if not torch.equal(chk.cpu(), want):
-            ok, why = 0, "wrong sum from the library's all-reduce"
-    except Exception as e:       # noqa: BLE001
-        ok, why = 0, str(e)
-    flag = torch.tensor([ok], dtype=torch.int64, device=device)
-    if world > 1:
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 0:
+    res = {"ok": 0, "why": f"ludvm_comm_init did not return within {timeout_s:.0f} s"}
+
+    def join():
         try:
-            eng.comm_destroy()
-        except Exception:       # noqa: BLE001
-            pass
-        return "torch", f"library communicator not usable ({why or 'another rank failed'}); torch.distributed collectives used"
-    return "library", None
+            torch.cuda.set_device(device)              # (the current device is per thread)
+            while os.environ.get("LUDVM_BENCH_TEST_HANG_COMM") == "1":      # test hook: a join that never returns
+                time.sleep(1.0)
+            eng.comm_init(rank, world, uid[0], min_vortices=1 << 62)
+            chk = torch.arange(1, 9, dtype=torch.int64, device=device) * (rank + 1)
+            torch.cuda.synchronize()
+            eng.comm_allreduce_i64_dev(chk.data_ptr(), chk.numel())
+            torch.cuda.synchronize()
+            want = torch.arange(1, 9, dtype=torch.int64) * (world * (world + 1) // 2)
+            if torch.equal(chk.cpu(), want):
+                res.update(ok=1, why="")
+            else:
+                res.update(ok=0, why="wrong sum from the library's all-reduce")
+        except Exception as e:       # noqa: BLE001
+            res.update(ok=0, why=str(e))
+    th = threading.Thread(target=join, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    hung = th.is_alive()
+    ok, why = (0, res["why"]) if hung else (res["ok"], res["why"])
+    flag = torch.tensor([ok, 1 if hung else 0], dtype=torch.int64, device=device)
+    if world > 1:
+        both = torch.stack([flag[0], -flag[1]])          # MIN of ok, MAX of hung
+        dist.all_reduce(both, op=dist.ReduceOp.MIN)
+        flag = torch.stack([both[0], -both[1]])
+    all_ok, any_hung = int(flag[0].item()), int(flag[1].item())
+    if all_ok == 0:
+        if not any_hung:
+            try:
+                eng.comm_destroy()
+            except Exception:       # noqa: BLE001
+                pass
+        return ("torch", f"library communicator not usable ({why or 'another rank failed'}); torch.distributed collectives used",
+                bool(any_hung))
+    return "library", None, False
 
 
 def main():
@@ -211,6 +237,12 @@ def main():
                     help="N > 1: who issues the step's collective -- the library's own RCCL communicator (default on nccl) or torch.distributed")
     ap.add_argument("--budget-s", type=float, default=300.0,
                     help="config 4: wall-time budget of the whole process; repeats and the other variant's steps shrink to fit")
+    ap.add_argument("--deadline-s", type=float, default=540.0,
+                    help="hard limit on the process's wall time: past it rank 0 prints the line with what has been measured so far "
+                         "(\"incomplete\" names the phase that did not finish) and every rank exits -- a hang in a late, optional "
+                         "phase must not take the measurement with it (0 = no limit)")
+    ap.add_argument("--comm-init-timeout", type=float, default=90.0,
+                    help="config 4: seconds the library's communicator may take to come up before torch.distributed takes over")
     ap.add_argument("--other-variant", type=int, choices=[0, 1], default=1,
                     help="config 4: also time the other step variant (direct <-> symmetric) after the reported one")
     ap.add_argument("--check", type=int, choices=[0, 1], default=1,
@@ -226,6 +258,36 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    # What has been measured so far, as a finished JSON line, for the deadline below.  `line` is replaced (never edited in
+    # place) at every milestone; `emit` writes it once.
+    import threading
+    state = {"line": None, "phase": "start-up", "done": False, "hard_exit": False}
+    emit_lock = threading.Lock()
+
+    def emit(line):
+        with emit_lock:
+            if state["done"]:
+                return False
+            state["done"] = True
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+            return True
+
+    def deadline_watch():
+        # a daemon thread: past --deadline-s of wall time the run is cut short with whatever line exists
+        while not state["done"]:
+            if time.perf_counter() - t_process > args.deadline_s:
+                line = state["line"]
+                printed = False
+                if line is not None:
+                    line = dict(line, incomplete=f"--deadline-s {args.deadline_s:.0f} reached during: {state['phase']}",
+                                wall_s=time.perf_counter() - t_process)
+                    printed = emit(line)
+                print(f"bench.py: deadline of {args.deadline_s:.0f} s reached during: {state['phase']}", file=sys.stderr, flush=True)
+                os._exit(0 if (printed or int(os.environ.get("RANK", "0")) != 0) else 3)
+            time.sleep(0.5)
+    if args.deadline_s > 0:
+        threading.Thread(target=deadline_watch, daemon=True).start()
 
     import torch
     import torch.distributed as dist
@@ -323,6 +385,92 @@ def main():
             wake.collective_timing(False)
         return over_ranks(el), kms, nl, cms, nc
 
+    # ---- the JSON line, from what is known once the reported timed region is over (later phases add to it) ----------------
+    M = {}          # the reported region: elapsed, kernel_ms, launches, pairs_per_step, pairs_per_launch, desc, collective, ...
+
+    def make_out(repeats, cfg4_extra, cfg4_rec, final):
+        from ludvm_amd.comm import MIN_TARGETS, MIN_WAKE
+        elapsed, kernel_ms, launches = M["elapsed"], M["kernel_ms"], M["launches"]
+        pairs_per_step, pairs_per_launch = M["pairs_per_step"], M["pairs_per_launch"]
+        per_rank_ms, per_rank_coll_ms = M["per_rank_ms"], M["per_rank_coll_ms"]
+        ns_l, nt_l = M["ns_l"], M["nt_l"]
+        value = pairs_per_step * args.steps / elapsed
+        kern_s = kernel_ms * 1e-3
+        exe = EXECUTED_FLOP_PER_PAIR[variant]
+        alg_tflops = FLOP_PER_PAIR * pairs_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
+        exe_tflops = exe * pairs_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
+        # algorithmic HBM bytes per launch: 12 B per source read, 8 B per target read, 8 B written
+        alg_bytes = 12.0 * ns_l + 16.0 * nt_l
+        quad = symmetric and ns_l > 639 * 512     # (the library's rule)
+        kernel_name = (("ludvm::pair_sym_quad_f32<8> (+ pair_sym_f32<8> on the diagonal tiles), fixed-point accumulation" if quad
+                        else "ludvm::pair_sym_f32<8> fixed-point accumulation") if symmetric
+                       else "ludvm::pair_f32<2,1024> direct, partial slabs")
+        traffic = PMC_TRAFFIC_CFG3.get(kernel_name) if (workload == "cfg3" and n == 1_000_000 and not args.tpl and not args.splits) else None
+        mean = lambda v: sum(v) / len(v)      # noqa: E731
+        out = {
+            "metric": "biot_savart_pair_interactions_per_s", "value": value, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeat_values": [pairs_per_step * args.steps / r for r in repeats],
+            "config": {"workload": M["desc"], "collective_backend": backend if world > 1 else None,
+                       "ranks": dist.get_world_size() if (world > 1 or force_dist) else 1, "collective": M["collective"],
+                       "collective_note": M["coll_note"],
+                       "n_vortices": n, "v_core": V_CORE, "device": info["name"],
+                       "cu_count": info["cu_count"], "kernel_variant": variant, "targets_per_lane": args.tpl or "auto",
+                       "source_splits": args.splits or "auto", "pair_kernel_ms_per_rank": per_rank_ms,
+                       "pair_kernel_ms_max_over_mean": max(per_rank_ms) / mean(per_rank_ms) if mean(per_rank_ms) > 0 else None,
+                       "collective_ms_per_rank": per_rank_coll_ms,
+                       "collective_ms_max_over_mean": (max(per_rank_coll_ms) / mean(per_rank_coll_ms)
+                                                       if per_rank_coll_ms and mean(per_rank_coll_ms) > 0 else None),
+                       # thresholds of the CLASS-level sharding (LUDVM(distributed=...): time_loop / induced_velocity), not
+                       # used by this workload; estimates, not yet measured on xGMI
+                       "class_sharding_thresholds": {"min_wake": MIN_WAKE, "min_targets": MIN_TARGETS}},
+            "roofline": {
+                # per the metric's definition (SURVEY 8(d)): algorithmic FLOPs -- 13 per ordered pair -- over the
+                # dominant kernel's own time.  The symmetric kernel EXECUTES 9 per ordered pair (it shares dx, dz, r^2,
+                # q and the rsqrt between (i,j) and (j,i)): `executed` is the share of the vector ALU's peak that was
+                # actually issued, and the one to read as hardware utilisation
+                "bound": "valu",
+                "kernel": kernel_name + (" (each unordered pair once; packed fp32 vector ALU; no MFMA, not HBM-bound)"
+                                         if symmetric else " (packed fp32 vector ALU; no MFMA, not HBM-bound)"),
+                "achieved": alg_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": alg_tflops / FP32_VECTOR_PEAK_TFLOPS, "flop_per_pair": FLOP_PER_PAIR,
+                "executed": {"flop_per_pair": exe, "achieved": exe_tflops, "frac": exe_tflops / FP32_VECTOR_PEAK_TFLOPS},
+                "pairs_per_launch": pairs_per_launch,
+                "kernel_ms_avg": kernel_ms, "kernel_launches_timed": launches,
+                "hbm_algorithmic_bytes_per_launch": alg_bytes,
+                "hbm_achieved_gbps": alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0, "hbm_peak_gbps": HBM_PEAK_GBPS,
+                "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": (traffic["source"] + " (separate rocprofv3 --pmc passes of this command; not collected "
+                                   "in this run)") if traffic else "no PMC pass on record for this kernel / size",
+            },
+        }
+        out.update(cfg4_extra)
+        if cfg4_rec is not None:
+            out["config4_one_gpu"] = cfg4_rec
+        if cpu_rec is not None:
+            rec = dict(cpu_rec)
+            u_first, w_first = M.get("u_first"), M.get("w_first")
+            if u_first is not None:
+                scale = max(np.abs(cpu_u).max(), np.abs(cpu_w).max())
+                rec["gpu_vs_oracle_max_rel_err"] = float(max(np.abs(u_first - cpu_u).max(), np.abs(w_first - cpu_w).max()) / scale)
+            else:
+                rec["gpu_vs_oracle_max_rel_err"] = None
+            out["cpu_baseline"] = rec
+        out["wall_s"] = time.perf_counter() - t_process
+        return out
+
+    def publish(phase, repeats=(), cfg4_extra=None, cfg4_rec=None):
+        """A milestone: from here on the deadline prints at least this much; `phase` is what runs next."""
+        if rank == 0:
+            state["line"] = make_out(list(repeats), cfg4_extra or {}, cfg4_rec, False)
+        state["phase"] = phase
+        if os.environ.get("LUDVM_BENCH_TEST_HANG") == "1":       # test hook: a phase that never ends (tests/test_gpu_bench.py)
+            state["phase"] = phase + " [test hook: hung on purpose]"
+            while True:
+                time.sleep(1.0)
+
     if world > 1:
         # RCCL builds its communicators on the first collective of each kind: do that outside the measurement
         # even when --warmup is 0
@@ -332,11 +480,9 @@ def main():
         dist.all_reduce(torch.ones(4, dtype=torch.int64, device=device))     # the symmetric variant's collective
         torch.cuda.synchronize()
 
-    coll = coll_note = collective = None
+    coll = coll_note = None
     cfg4_rec = None
     cfg4_extra = {}
-    u_first = w_first = None
-    per_rank_ms = per_rank_coll_ms = None
     if workload == "cfg3":
         dx, dz, dg = (torch.from_numpy(a).to(device) for a in (x, z, g))
         du, dw = torch.empty_like(dx), torch.empty_like(dx)
@@ -347,20 +493,27 @@ def main():
         pairs_per_step = float(n) * float(n)
         pairs_per_launch = pairs_per_step
         desc = f"config 3: synthetic wake N={n}, one induced_velocity all-pairs call per step (targets = sources)"
+        state["phase"] = "warm-up and the reported timed region (config 3)"
         for _ in range(args.warmup):
             step()
         fence()
         elapsed, kernel_ms, launches, _, _ = timed_region(step, args.steps)
+        M.update(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, pairs_per_step=pairs_per_step,
+                 pairs_per_launch=pairs_per_launch, desc=desc, collective=None, coll_note=None, per_rank_ms=[kernel_ms],
+                 per_rank_coll_ms=None, ns_l=n, nt_l=n)
         if cpu_rec is not None:
-            u_first = du[: len(cpu_u)].cpu().numpy().astype(np.float64)
-            w_first = dw[: len(cpu_u)].cpu().numpy().astype(np.float64)
-        repeats = [timed_region(step, args.steps)[0] for _ in range(max(0, args.repeats))]
-        per_rank_ms = [kernel_ms]
-        ns_l = nt_l = n
+            M["u_first"] = du[: len(cpu_u)].cpu().numpy().astype(np.float64)
+            M["w_first"] = dw[: len(cpu_u)].cpu().numpy().astype(np.float64)
+        publish("the repeat regions (config 3)")
+        repeats = []
+        for _ in range(max(0, args.repeats)):
+            repeats.append(timed_region(step, args.steps)[0])
+            publish("the repeat regions (config 3)", repeats)
 
         # N = 1: config 4's workload (N = 8e6, what --gpus 2, 4, 8 run sharded) on this one GPU, so that "8 vs 1" compares the
         # same work; not part of `value`
         if world == 1 and args.cfg4_steps > 0 and not args.vortices:
+            publish("config 4's workload on the one GPU (config4_one_gpu)", repeats)
             n4 = 8_000_000
             x4, z4, g4 = synthetic_wake(n4)
             wake4 = ShardedWake(x4, z4, g4, V_CORE, DT, HipShardKernel(eng), device, symmetric=symmetric)
@@ -370,12 +523,22 @@ def main():
                                     "no collective)", "value": wake4.pairs_per_step * args.cfg4_steps / el4, "unit": "pairs/s",
                         "steps": args.cfg4_steps, "warmup": 0, "ms_per_step": el4 / args.cfg4_steps * 1e3, "pair_kernel_ms": k4}
             if args.check:
+                publish("the result check of config4_one_gpu", repeats, None, dict(cfg4_rec))
                 cfg4_rec["result_check"] = check_wake(wake4, g4, rank, torch)
             del wake4
     else:
         coll = args.collectives if args.collectives != "auto" else ("library" if (backend == "nccl" and world > 1) else "torch")
         if coll == "library":
-            coll, coll_note = join_library_communicator(eng, rank, world, device, backend, dist, torch)
+            state["phase"] = "joining the library's RCCL communicator"
+            coll, coll_note, abandoned = join_library_communicator(eng, rank, world, device, backend, dist, torch,
+                                                                   args.comm_init_timeout)
+            if abandoned:
+                # a join that never returned still holds the old context: a fresh one for the rest of the run, and no
+                # interpreter shutdown at the end (it would wait for the stuck call)
+                eng = Engine(dev_index)
+                eng.set_stream(torch.cuda.current_stream().cuda_stream)
+                eng.set_tuning(args.tpl, args.splits)
+                state["hard_exit"] = True
         # a one-rank run issues its collectives all the same when it can (identities on the real RCCL): the library's
         # communicator always can, torch's needs the process group (LUDVM_BENCH_FORCE_DIST=1)
         force_coll = world == 1 and (coll == "library" or force_dist)
@@ -411,16 +574,19 @@ def main():
             """Seconds of the budget still unspent (the slowest rank's clock: every rank must decide alike)."""
             return args.budget_s - over_ranks(time.perf_counter() - t_process)
 
+        state["phase"] = f"warm-up and the reported timed region (config 4, {variant} variant)"
         wake, main_rec, elapsed, kernel_ms, launches = run_variant(symmetric, args.steps, args.warmup)
-        pairs_per_step = wake.pairs_per_step
-        pairs_per_launch = float(wake.n_pad) * float(wake.n_pad) / world if symmetric else float(wake.n_loc) * float(wake.n_pad)
-        per_rank_ms, per_rank_coll_ms = main_rec["pair_kernel_ms_per_rank"], main_rec["collective_ms_per_rank"]
-        collective = main_rec["collective"]
-        ns_l, nt_l = wake.n_pad, (wake.n_pad if symmetric else wake.n_loc)
         desc = (f"config 4: synthetic wake N={n}, sharded over {world} GPU(s); per step: "
                 + ("symmetric kernel on the rank's I-tile block of the unordered pairs + ONE all-reduce of the 64-bit "
                    "fixed-point sums + replicated Euler update" if symmetric else
                    "all-pairs kernel on own N/G targets + Euler update + ONE all-gather of positions"))
+        M.update(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, pairs_per_step=wake.pairs_per_step,
+                 pairs_per_launch=(float(wake.n_pad) * float(wake.n_pad) / world if symmetric else float(wake.n_loc) * float(wake.n_pad)),
+                 desc=desc, collective=main_rec["collective"], coll_note=coll_note,
+                 per_rank_ms=main_rec["pair_kernel_ms_per_rank"], per_rank_coll_ms=main_rec["collective_ms_per_rank"],
+                 ns_l=wake.n_pad, nt_l=(wake.n_pad if symmetric else wake.n_loc))
+        extra_main = {main_rec["kernel_variant"] + "_variant": dict(main_rec, reported_as_value=True)}
+        publish("the other step variant", (), extra_main)
 
         # the other variant, then the repeats, within the budget; the checks (two steps + the oracle's ~2e9 pairs) keep a reserve
         step_s = elapsed / args.steps
@@ -437,89 +603,33 @@ def main():
                 other_rec = {"kernel_variant": "symmetric" if other_sym else "direct", "skipped":
                              f"budget: {left():.0f} s left of --budget-s {args.budget_s:.0f}, a step takes ~{other_step_s:.1f} s"}
         n_rep = max(0, min(args.repeats, int((left() - reserve) / max(elapsed, 1e-9))))
-
-        eng.set_symmetric(1 if symmetric else 0)
-        repeats = [timed_region(wake.step, args.steps, wake)[0] for _ in range(n_rep)]
-
-        checks = {}
-        if args.check:
-            checks[main_rec["kernel_variant"]] = check_wake(wake, g, rank, torch)
-            if wake_o is not None:
-                eng.set_symmetric(1 if other_sym else 0)
-                checks[other_rec["kernel_variant"]] = check_wake(wake_o, g, rank, torch)
-        cfg4_extra = {main_rec["kernel_variant"] + "_variant": dict(main_rec, reported_as_value=True)}
+        cfg4_extra = dict(extra_main)
         if other_rec is not None:
             cfg4_extra[other_rec["kernel_variant"] + "_variant"] = dict(other_rec, reported_as_value=False)
+        publish("the repeat regions (config 4)", (), cfg4_extra)
+
+        eng.set_symmetric(1 if symmetric else 0)
+        repeats = []
+        for _ in range(n_rep):
+            repeats.append(timed_region(wake.step, args.steps, wake)[0])
+            publish("the repeat regions (config 4)", repeats, cfg4_extra)
+
         if args.check:
+            checks = {}
+            publish(f"the result check of the {main_rec['kernel_variant']} variant", repeats, cfg4_extra)
+            checks[main_rec["kernel_variant"]] = check_wake(wake, g, rank, torch)
+            if wake_o is not None:
+                publish(f"the result check of the {other_rec['kernel_variant']} variant", repeats, dict(cfg4_extra, result_check=dict(checks)))
+                eng.set_symmetric(1 if other_sym else 0)
+                checks[other_rec["kernel_variant"]] = check_wake(wake_o, g, rank, torch)
             cfg4_extra["result_check"] = checks
 
+    state["phase"] = "writing the line"
     if rank == 0:
-        from ludvm_amd.comm import MIN_TARGETS, MIN_WAKE
-        value = pairs_per_step * args.steps / elapsed
-        kern_s = kernel_ms * 1e-3
-        exe = EXECUTED_FLOP_PER_PAIR[variant]
-        alg_tflops = FLOP_PER_PAIR * pairs_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
-        exe_tflops = exe * pairs_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
-        # algorithmic HBM bytes per launch: 12 B per source read, 8 B per target read, 8 B written
-        alg_bytes = 12.0 * ns_l + 16.0 * nt_l
-        quad = symmetric and ns_l > 639 * 512     # (the library's rule)
-        kernel_name = (("ludvm::pair_sym_quad_f32<8> (+ pair_sym_f32<8> on the diagonal tiles), fixed-point accumulation" if quad
-                        else "ludvm::pair_sym_f32<8> fixed-point accumulation") if symmetric
-                       else "ludvm::pair_f32<2,1024> direct, partial slabs")
-        traffic = PMC_TRAFFIC_CFG3.get(kernel_name) if (workload == "cfg3" and n == 1_000_000 and not args.tpl and not args.splits) else None
-        mean = lambda v: sum(v) / len(v)      # noqa: E731
-        out = {
-            "metric": "biot_savart_pair_interactions_per_s", "value": value, "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "repeat_values": [pairs_per_step * args.steps / r for r in repeats],
-            "config": {"workload": desc, "collective_backend": backend if world > 1 else None,
-                       "ranks": dist.get_world_size() if (world > 1 or force_dist) else 1, "collective": collective,
-                       "collective_note": coll_note,
-                       "n_vortices": n, "v_core": V_CORE, "device": info["name"],
-                       "cu_count": info["cu_count"], "kernel_variant": variant, "targets_per_lane": args.tpl or "auto",
-                       "source_splits": args.splits or "auto", "pair_kernel_ms_per_rank": per_rank_ms,
-                       "pair_kernel_ms_max_over_mean": max(per_rank_ms) / mean(per_rank_ms) if mean(per_rank_ms) > 0 else None,
-                       "collective_ms_per_rank": per_rank_coll_ms,
-                       "collective_ms_max_over_mean": (max(per_rank_coll_ms) / mean(per_rank_coll_ms)
-                                                       if per_rank_coll_ms and mean(per_rank_coll_ms) > 0 else None),
-                       # thresholds of the CLASS-level sharding (LUDVM(distributed=...): time_loop / induced_velocity), not
-                       # used by this workload; estimates, not yet measured on xGMI
-                       "class_sharding_thresholds": {"min_wake": MIN_WAKE, "min_targets": MIN_TARGETS}},
-            "roofline": {
-                # per the metric's definition (SURVEY 8(d)): algorithmic FLOPs -- 13 per ordered pair -- over the
-                # dominant kernel's own time.  The symmetric kernel EXECUTES 9 per ordered pair (it shares dx, dz, r^2,
-                # q and the rsqrt between (i,j) and (j,i)): `executed` is the share of the vector ALU's peak that was
-                # actually issued, and the one to read as hardware utilisation
-                "bound": "valu",
-                "kernel": kernel_name + (" (each unordered pair once; packed fp32 vector ALU; no MFMA, not HBM-bound)"
-                                         if symmetric else " (packed fp32 vector ALU; no MFMA, not HBM-bound)"),
-                "achieved": alg_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": alg_tflops / FP32_VECTOR_PEAK_TFLOPS, "flop_per_pair": FLOP_PER_PAIR,
-                "executed": {"flop_per_pair": exe, "achieved": exe_tflops, "frac": exe_tflops / FP32_VECTOR_PEAK_TFLOPS},
-                "pairs_per_launch": pairs_per_launch,
-                "kernel_ms_avg": kernel_ms, "kernel_launches_timed": launches,
-                "hbm_algorithmic_bytes_per_launch": alg_bytes,
-                "hbm_achieved_gbps": alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0, "hbm_peak_gbps": HBM_PEAK_GBPS,
-                "traffic": traffic["bytes"] if traffic else None,
-                "traffic_source": (traffic["source"] + " (separate rocprofv3 --pmc passes of this command; not collected "
-                                   "in this run)") if traffic else "no PMC pass on record for this kernel / size",
-            },
-        }
-        out.update(cfg4_extra)
-        if cfg4_rec is not None:
-            out["config4_one_gpu"] = cfg4_rec
-        if cpu_rec is not None:
-            if u_first is not None:
-                scale = max(np.abs(cpu_u).max(), np.abs(cpu_w).max())
-                cpu_rec["gpu_vs_oracle_max_rel_err"] = float(max(np.abs(u_first - cpu_u).max(), np.abs(w_first - cpu_w).max()) / scale)
-            else:
-                cpu_rec["gpu_vs_oracle_max_rel_err"] = None
-            out["cpu_baseline"] = cpu_rec
-        out["wall_s"] = time.perf_counter() - t_process
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(make_out(repeats, cfg4_extra, cfg4_rec, True))
+    if state["hard_exit"]:
+        sys.stderr.flush()
+        os._exit(0)          # (a communicator join that never returned: do not wait for it at interpreter shutdown)
     if coll == "library":
         torch.cuda.synchronize()
         eng.comm_destroy()

@@ -246,3 +246,42 @@ def test_bench_two_ranks_on_rccl_with_two_gpus():
             assert len(d["config"]["pair_kernel_ms_per_rank"]) == 2 and d["value"] > 1e11
             assert ("libludvm_hip" in d["config"]["collective"]) == (coll == "auto")
             _assert_self_checking_config4(d, 2, main="symmetric" if sym == "1" else "direct")
+
+
+def test_bench_deadline_prints_what_has_been_measured():
+    """--deadline-s: a phase that never ends (here: on purpose, right after the reported region) must not take the measurement
+    with it -- at the deadline rank 0 prints the line as it stands, marked `incomplete`, and the process exits 0."""
+    import time
+    env = dict(os.environ, LUDVM_BENCH_TEST_HANG="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--vortices", "40000", "--steps", "3", "--warmup", "1",
+                        "--cpu-rows", "0", "--deadline-s", "25"], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert 20 < time.time() - t0 < 60
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert "deadline" in d["incomplete"] and "hung on purpose" in d["incomplete"]
+    assert d["value"] > 1e11 and d["steps"] == 3 and d["roofline"]["kernel_launches_timed"] == 3 and d["repeat_values"] == []
+    assert "deadline of 25 s reached" in p.stderr
+
+
+def test_bench_survives_a_communicator_join_that_never_returns():
+    """The library's communicator comes up inside ncclCommInitRank, a collective with no timeout of its own.  bench.py joins in a
+    helper thread: a join that does not return within --comm-init-timeout (here: on purpose) leaves the stuck call its
+    context, the run goes on with torch.distributed's collectives on a fresh engine, says so, and exits cleanly."""
+    env = dict(os.environ, LUDVM_BENCH_TEST_HANG_COMM="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg4", "--vortices", "60000", "--steps", "2",
+                        "--warmup", "1", "--cpu-rows", "0", "--collectives", "library", "--comm-init-timeout", "3"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert "did not return within 3 s" in d["config"]["collective_note"] and "torch.distributed" in d["config"]["collective"]
+    assert "incomplete" not in d and d["value"] > 1e11
+    _assert_self_checking_config4(d, 1, collectives_issued=False)
