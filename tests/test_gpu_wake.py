@@ -668,6 +668,40 @@ def test_march_calls_that_begin_on_a_multiple_of_64(threshold, prec):
         e.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_bits_do_not_depend_on_rows_chunks_or_checkpoints(seed, tmp_path):
+    """Property: whatever rows a sparse-history run keeps, however its march is cut into calls and wherever it writes
+    checkpoints, its loads are the bits of the run that keeps nothing, and every kept row is the dense history's row."""
+    from ludvm_amd import Engine, LUDVM
+    rng = np.random.default_rng(seed)
+    e = Engine(0)
+    try:
+        e.set_symmetric(40)
+        kw = dict(CONFIG1, tf=7)               # 140 steps
+        whole = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse", snapshot_steps=[])
+        dense = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="full")
+        assert np.array_equal(whole.Cl, dense.Cl)
+        for _ in range(3):
+            snaps = sorted(int(v) for v in rng.choice(np.arange(1, 140), size=int(rng.integers(1, 25)), replace=False))
+            LUDVM._march_chunk = int(rng.integers(1, 90))
+            ck = str(tmp_path / f"ck{seed}.npz")
+            try:
+                r = LUDVM(**kw, verbose=False, engine=e, precision="f32", history="sparse", snapshot_steps=snaps,
+                          checkpoint_every=int(rng.integers(7, 60)), checkpoint_path=ck)
+            finally:
+                del LUDVM._march_chunk
+            for name in ("Cl", "Cd", "Cm", "LEV_shed", "LESP"):
+                assert np.array_equal(getattr(whole, name), getattr(r, name)), (name, snaps)
+            for q in snaps:
+                for key in ("TEV", "LEV", "FREE"):
+                    row = np.asarray(r.path[key][q])
+                    assert np.array_equal(row, dense.path[key][q][:, :row.shape[1]]), (key, q)
+            res = LUDVM.resume(ck, engine=e, verbose=False)          # ... and the resumed run ends on the same bits
+            assert np.array_equal(res.Cl, whole.Cl) and np.array_equal(res.path["TEV"][res.nt - 1], whole.path["TEV"][whole.nt - 1])
+    finally:
+        e.close()
+
+
 def test_time_loop_over_an_unordered_cloud_of_free_vortices(eng, tmp_path):
     """A cloud of free vortices in no spatial order (LUDVM.generate_flowfield_turbulence, LUDVM.py:98-130) in an fp32 run:
     the class stores it in the order the engine names (ludvm_spatial_order) and hands every path['FREE'] row back in the
