@@ -73,11 +73,43 @@ def default_rendezvous():
     return os.path.join(_private_dir(), f"rdv_{tag}")
 
 
-def exchange_id(rank, make_id, path, timeout=600.0):
+def _process_start(pid):
+    """Wall-clock start of process `pid` (seconds since the epoch, good to a second) from /proc, or None."""
+    try:
+        with open(f"/proc/{pid}/stat", "rb") as f:
+            ticks = int(f.read().rsplit(b")", 1)[1].split()[19])          # field 22, starttime, after "pid (comm)"
+        with open("/proc/stat", "rb") as f:
+            boot = next(int(line.split()[1]) for line in f if line.startswith(b"btime"))
+        return boot + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, StopIteration, IndexError):
+        return None
+
+
+def launch_epoch():
+    """A moment no identifier of THIS launch can predate: the start of the process that started us (the launcher: torchrun's
+    agent, orted, slurmstepd -- it is older than every rank it starts, rank 0 included), else our own start."""
+    t = _process_start(os.getppid())
+    if t is None:
+        t = _process_start(os.getpid())
+    return t
+
+
+def launch_tag():
+    """What the launcher tells every rank of one launch alike, as bytes (may be empty): travels behind the identifier so that
+    a reader can tell another launch's file by its content too."""
+    job = (os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("SLURM_JOB_ID") or os.environ.get("OMPI_MCA_ess_base_jobid") or "")
+    return f"{job}|{os.environ.get('MASTER_PORT', '')}".encode()
+
+
+def exchange_id(rank, make_id, path, timeout=600.0, not_before=None, tag=None):
     """Rank 0 creates the identifier (make_id() -> bytes) and publishes it atomically at `path`; the others wait for it.
     Rank 0 never writes through a link and first removes whatever a crashed launch left under the name; the readers take
-    only a regular file that belongs to this user."""
+    only a regular file that belongs to this user -- and only one of THIS launch (a non-zero rank that is faster
+    than rank 0 could otherwise read the identifier a crashed launch left under the same name, join a dead communicator and
+    hang in ncclCommInitRank, which has no timeout): a file last written before `not_before` (default: launch_epoch(), less
+    two seconds for /proc's resolution) is waited out, and so is one whose tag (default: launch_tag()) is another launch's."""
     nofollow = getattr(os, "O_NOFOLLOW", 0)
+    tag = launch_tag() if tag is None else bytes(tag)
     if rank == 0:
         uid = make_id()
         try:
@@ -91,19 +123,22 @@ def exchange_id(rank, make_id, path, timeout=600.0):
             pass
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | nofollow, 0o600)
         with os.fdopen(fd, "wb") as f:
-            f.write(uid)
+            f.write(bytes(uid)[:128].ljust(128, b"\0") + tag)
         os.replace(tmp, path)
         return uid
     import stat
+    if not_before is None:
+        le = launch_epoch()
+        not_before = (le - 2.0) if le is not None else 0.0
     t0 = time.monotonic()
     while True:
         try:
             fd = os.open(path, os.O_RDONLY | nofollow)
             with os.fdopen(fd, "rb") as f:
                 st = os.fstat(f.fileno())
-                if stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid():
+                if stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and st.st_mtime >= not_before:
                     uid = f.read()
-                    if len(uid) >= 128:
+                    if len(uid) >= 128 and uid[128:] == tag:
                         return uid[:128]
         except OSError:
             pass

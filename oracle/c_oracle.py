@@ -21,11 +21,18 @@ def _load():
         _lib.pair_oracle_f64.argtypes = [pd, pd, pd, ctypes.c_size_t, pd, pd, ctypes.c_size_t, ctypes.c_double, pd, pd]
         _lib.pair_oracle_f64.restype = None
         _lib.pair_oracle_threads.restype = ctypes.c_int
+        _lib.pair_oracle_set_threads.argtypes = [ctypes.c_int]
+        _lib.pair_oracle_set_threads.restype = None
     return _lib
 
 
 def threads():
     return _load().pair_oracle_threads()
+
+
+def set_threads(n):
+    """OpenMP threads of the following calls (rows are independent: same numbers, other wall time)."""
+    _load().pair_oracle_set_threads(int(n))
 
 
 def induced_velocity(circulation, xw, zw, xp, zp, v_core):

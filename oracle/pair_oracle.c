@@ -37,6 +37,17 @@ void pair_oracle_f64(const double* g, const double* xw, const double* zw, size_t
   }
 }
 
+/* Rows are independent: the thread count changes nothing but the time.  A launcher that starts several ranks per node
+ * pins OMP_NUM_THREADS to 1; the one rank that runs a sampled check while the others wait may ask for more. */
+void pair_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  extern void omp_set_num_threads(int);
+  if (n >= 1) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int pair_oracle_threads(void) {
 #ifdef _OPENMP
   extern int omp_get_max_threads(void);

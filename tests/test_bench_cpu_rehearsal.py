@@ -1,0 +1,90 @@
+"""CPU tier: bench.py's N > 1 control flow with 2 (the deadline test), 4 and 8 ranks, on a machine with no GPU.
+
+`python bench.py --gpus N` without a launcher starts its own ranks; tests/bench_cpu_rig.py runs
+bench.main() with the oracle's arithmetic under gloo in place of the HIP engine, so everything else -- the self-launch, the
+process group, the tile blocks of ShardedWake (at 8 ranks: blocks that are partly or wholly padding), the agreement of the
+ranks on step counts, both step variants, the result checks, the collective micro-sweep, the deadline -- is bench.py's own
+code.  bench.py itself has no CPU path: the last tests show it refusing to run here."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+from bench_checks import assert_self_checking_config4, assert_sweep
+from conftest import ROOT
+
+RIG = os.path.join(ROOT, "tests", "bench_cpu_rig.py")
+
+
+def _env(**extra):
+    env = dict(os.environ, **extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LUDVM_BENCH_BACKEND"):
+        env.pop(k, None)
+    return env
+
+
+def _run(script, *args, env=None, timeout=600):
+    p = subprocess.run([sys.executable, script, *args], capture_output=True, text=True, env=env or _env(), timeout=timeout)
+    return p, [l for l in p.stdout.splitlines() if l.strip()]
+
+
+@pytest.mark.parametrize("ranks,n", [(8, 17000), (4, 16500)])
+def test_self_launched_ranks_rehearse_config4(ranks, n):
+    """Plain `<bench> --gpus N`: N ranks come up, one line comes back.  17 000 vortices on 8 ranks: blocks of 4096 (whole
+    quads of 512-vortex tiles), ranks 5-7 own nothing but padding; the bits are those of any other world size."""
+    p, lines = _run(RIG, "--gpus", str(ranks), "--vortices", str(n), "--steps", "1", "--warmup", "0", "--repeats", "1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["config"]["ranks"] == ranks and d["scaling"] == "strong" and "incomplete" not in d
+    assert "bench.py itself" in d["config"]["launched_by"] and "torch.distributed.run" in p.stderr
+    assert "config 4" in d["config"]["workload"] and d["config"]["collective_backend"] == "gloo"
+    assert abs(d["value"] - float(n) ** 2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert len(d["repeat_values"]) == 1 and "cpu_baseline" not in d and "config4_one_gpu" not in d
+    assert_self_checking_config4(d, ranks, min_value=1e6)
+    assert_sweep(d, ranks, ["torch"])
+    if n == 17000:          # the same wake on any number of ranks: the same bits (integer sums commute)
+        assert d["result_check"]["symmetric"]["checksum"] == ["fffffb8bf2a7c116", "fffdd2756d232694", "fffffb93145d21bd",
+                                                              "fffdddf9817bed81"]
+
+
+def test_self_launch_relays_the_deadline_line():
+    """A phase that never ends (on purpose, after the reported region), two self-launched ranks: at --deadline-s rank 0 prints
+    the line as it stands, every rank exits 0, the launcher exits 0 and the parent passes the one line on."""
+    t0 = time.time()
+    p, lines = _run(RIG, "--gpus", "2", "--vortices", "16384", "--steps", "1", "--warmup", "0", "--deadline-s", "25",
+                    env=_env(LUDVM_BENCH_TEST_HANG="1"), timeout=200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert 20 < time.time() - t0 < 90
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert "deadline" in d["incomplete"] and "hung on purpose" in d["incomplete"] and d["n_gpus"] == 2 and d["value"] > 0
+    assert "deadline of 25 s reached" in p.stderr
+
+
+def test_deadline_before_anything_was_measured_is_an_error():
+    """Nothing measured when the deadline comes: no line, exit status 3 (a harness must not take that for a run)."""
+    env = _env(LUDVM_BENCH_TEST_HANG="1")
+    p = subprocess.run([sys.executable, "-c", "import sys, time; sys.argv = ['x']; import bench; r = bench.Reporter(0, 1.0, "
+                        "time.perf_counter()); time.sleep(30)"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=60)
+    assert p.returncode == 3 and p.stdout == "" and "deadline of 1 s reached during: start-up" in p.stderr
+
+
+def test_launcher_world_that_contradicts_gpus_is_refused():
+    p, lines = _run(RIG, "--gpus", "4", env=dict(_env(), WORLD_SIZE="2", RANK="0"))
+    assert p.returncode == 2 and lines == [] and "WORLD_SIZE is 2" in p.stderr
+
+
+def test_bench_itself_has_no_cpu_path():
+    """The product's bench.py on this GPU-less machine: exit 2, no line -- alone and through its own launcher."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    bench = os.path.join(ROOT, "bench.py")
+    p, lines = _run(bench, "--cpu-rows", "0")
+    assert p.returncode == 2 and lines == [] and "no GPU visible" in p.stderr
+    p, lines = _run(bench, "--gpus", "2", "--vortices", "20000")
+    assert p.returncode != 0 and lines == [] and "no GPU visible" in p.stderr

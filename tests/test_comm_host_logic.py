@@ -76,6 +76,35 @@ def test_rendezvous_does_not_follow_links_nor_trust_stale_files(tmp_path):
     assert comm.exchange_id(0, lambda: bytes(128), path) == bytes(128) and comm.exchange_id(1, None, path, timeout=5) == bytes(128)
 
 
+def test_a_faster_rank_does_not_take_the_identifier_of_an_earlier_launch(tmp_path, monkeypatch):
+    """the file a crashed launch left under the same name (same LUDVM_RENDEZVOUS, or the same parent and port) is
+    still there when a non-zero rank of the next launch looks, BEFORE rank 0 has replaced it.  It is older than this launch
+    (its mtime predates the launcher's start) -- or carries another launch's tag -- and is waited out, not read."""
+    path = str(tmp_path / "rdv")
+    stale, fresh = bytes([7]) * 128, bytes(range(128))
+    assert comm.exchange_id(0, lambda: stale, path) == stale                   # the earlier launch ...
+    past = os.stat(path).st_mtime - 3600
+    os.utime(path, (past, past))                                               # ... an hour ago
+    le = comm.launch_epoch()
+    assert le is not None and past < le <= __import__("time").time() + 1       # our launcher (pytest's parent) started since
+    with pytest.raises(TimeoutError):
+        comm.exchange_id(1, None, path, timeout=0.3)                           # rank 1 is early: it does NOT join the dead one
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault(1, comm.exchange_id(1, None, path, timeout=30)))
+    t.start()
+    __import__("time").sleep(0.2)
+    assert comm.exchange_id(0, lambda: fresh, path) == fresh                   # rank 0 arrives and replaces it
+    t.join(30)
+    assert got == {1: fresh}
+    # the same by content: a file of this very minute, but of a launch with another job identifier / port
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-A")
+    assert comm.exchange_id(0, lambda: stale, path) == stale
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-B")
+    with pytest.raises(TimeoutError):
+        comm.exchange_id(1, None, path, timeout=0.3)
+    assert comm.exchange_id(0, lambda: fresh, path) == fresh and comm.exchange_id(1, None, path, timeout=5) == fresh
+
+
 class _OneRankEngine:
     """Stand-in for Engine's communicator calls with a group of one."""
 

@@ -1,4 +1,4 @@
-"""CPU tier: `LUDVM(..., distributed=True)` under gloo with world_size 2 and 3 -- the sharding of LUDVM.flowfield
+"""CPU tier: `LUDVM(..., distributed=True)` under gloo with world_size 2, 3 and 8 -- the sharding of LUDVM.flowfield
 (grid rows) and LUDVM.induced_velocity (targets) behind the reference's method surface, and the gather that leaves the
 reference's full arrays on every rank.  The pair arithmetic is the oracle's (tests/fake_engine.py); what is under test
 is the partition, the halo rows of the vorticity stencil, ragged blocks and the collectives."""
@@ -35,7 +35,7 @@ def _worker(rank, world, port, out):
         one = LUDVM(**kw, verbose=False, engine=FakeEngine(), precision="f64")
         # time loop: the fake engine has no sharded roll-up, every rank ran the whole loop -> identical results
         assert np.array_equal(sim.Cl, one.Cl)
-        # flow field: 23 rows over 2 or 3 ranks (ragged), 9 columns, three time steps incl. step 0 (free vortices only)
+        # flow field: 23 rows over 2, 3 or 8 ranks (ragged; 8 ranks: blocks of 3 rows, the last one 2), 9 columns, three time steps incl. step 0 (free vortices only)
         args = dict(xmin=-4.0, xmax=1.75, zmin=-1.0, zmax=1.25, dr=0.25, tsteps=[0, 30, 59])
         sim.flowfield(**args)
         one.flowfield(**args)
@@ -57,7 +57,7 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_class_level_sharding_equals_one_rank(tmp_path, world):
     out = str(tmp_path / "u.npy")
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)

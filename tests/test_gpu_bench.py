@@ -7,6 +7,7 @@ import sys
 
 import pytest
 
+from bench_checks import assert_self_checking_config4 as _assert_self_checking_config4, assert_sweep
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
@@ -49,35 +50,6 @@ def test_bench_json_contract(symmetric):
     assert c["gpu_vs_oracle_max_rel_err"] < 1e-5
 
 
-def _assert_self_checking_config4(d, ranks, main="symmetric", collectives_issued=True):
-    """What every config-4 line must carry: the collective's own time per rank beside the pair
-    kernel's, BOTH step variants, and a result check that passed."""
-    c = d["config"]
-    assert len(c["pair_kernel_ms_per_rank"]) == ranks and len(c["collective_ms_per_rank"]) == ranks
-    assert c["pair_kernel_ms_max_over_mean"] >= 1.0
-    assert c["class_sharding_thresholds"] == {"min_wake": 131072, "min_targets": 65536}
-    other = "direct" if main == "symmetric" else "symmetric"
-    for name, reported in ((main, True), (other, False)):
-        v = d[name + "_variant"]
-        assert v["kernel_variant"] == name and v["reported_as_value"] is reported and "skipped" not in v, v
-        assert v["value"] > 1e10 and v["steps"] >= 1 and v["ms_per_step"] > 0
-        assert len(v["pair_kernel_ms_per_rank"]) == ranks and all(t > 0 for t in v["pair_kernel_ms_per_rank"])
-        assert len(v["collective_ms_per_rank"]) == ranks
-        if collectives_issued:
-            assert all(t > 0 for t in v["collective_ms_per_rank"]) and v["collectives_timed_per_rank"] == v["steps"]
-            assert v["collective_ms_max_over_mean"] >= 1.0
-        # the kernel and the collective are both inside the step
-        assert max(v["pair_kernel_ms_per_rank"]) + min(v["collective_ms_per_rank"]) <= v["ms_per_step"] * 1.05
-        assert ("all_reduce" if name == "symmetric" else "all_gather") in v["collective"]
-    assert d[main + "_variant"]["value"] == pytest.approx(d["value"]) and d[main + "_variant"]["steps"] == d["steps"]
-    assert c["collective_ms_per_rank"] == d[main + "_variant"]["collective_ms_per_rank"]
-    for name in (main, other):
-        k = d["result_check"][name]
-        assert "error" not in k, k
-        assert k["ranks_agree"] is True and k["finite"] is True and k["samples"] == 256
-        assert k["gpu_vs_oracle_max_rel_err"] < 1e-5, k
-
-
 def test_bench_config4_shape_on_one_gpu():
     d = _run("--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1", "--cpu-rows", "0")
     assert d["scaling"] == "strong" and "config 4" in d["config"]["workload"] and "cpu_baseline" not in d
@@ -109,6 +81,8 @@ def test_bench_config4_through_the_library_communicator_on_one_rank():
     assert d["config"]["collective_note"] is None, d["config"]["collective_note"]
     assert "inside libludvm_hip.so" in d["config"]["collective"] and d["value"] > 1e11
     _assert_self_checking_config4(d, 1)          # ncclAllReduce AND ncclAllGather issued (one-rank identities), timed, checked
+    assert_sweep(d, 1, ["library"])              # ... and the collective micro-sweep through the library's communicator
+    assert "ONE rank" in d["collective_sweep_us"]["min_wake_rule"]
     ref = _run("--workload", "cfg4", "--vortices", "60000", "--steps", "2", "--warmup", "1", "--cpu-rows", "0",
                "--collectives", "torch")
     assert "torch.distributed" in ref["config"]["collective"] and ref["config"]["collective_note"] is None
@@ -163,6 +137,72 @@ def test_bench_two_ranks_through_the_launcher():
     assert "all_reduce" in d["config"]["collective"]
     assert abs(d["value"] - 120000.0**2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+    assert "a launcher" in d["config"]["launched_by"]
+    _assert_self_checking_config4(d, 2)
+    assert_sweep(d, 2, ["torch"])
+
+
+def _self_launch(nproc, extra_env, *args, timeout=600):
+    """`python bench.py --gpus N ...` with NO launcher: bench.py starts its ranks itself."""
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *args], capture_output=True, text=True,
+                       env=env, timeout=timeout)
+    return p, [l for l in p.stdout.splitlines() if l.strip()]
+
+
+def test_bench_starts_its_own_ranks():
+    """The driver's most natural command for N = 2: plain `python bench.py --gpus 2 ...` (two gloo ranks sharing the one
+    card): one JSON line, two ranks."""
+    p, lines = _self_launch(2, {"LUDVM_BENCH_BACKEND": "gloo"}, "--vortices", "120000", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and "bench.py itself" in d["config"]["launched_by"]
+    assert abs(d["value"] - 120000.0**2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    _assert_self_checking_config4(d, 2)
+    assert_sweep(d, 2, ["torch"])
+
+
+@pytest.mark.parametrize("n", [200000, 18000])
+def test_bench_starts_four_ranks_with_padded_owner_blocks(n):
+    """Four self-launched gloo ranks on the one card (a GPU box allows six processes on its card; the eight-rank rehearsal
+    is tests/test_bench_cpu_rehearsal.py, on the CPU): 200 000 vortices -- the last rank's block is partly padding;
+    18 000 -- blocks of 6144, the last rank owns nothing but padding."""
+    p, lines = _self_launch(4, {"LUDVM_BENCH_BACKEND": "gloo"}, "--vortices", str(n), "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["ranks"] == 4 and len(d["config"]["pair_kernel_ms_per_rank"]) == 4
+    _assert_self_checking_config4(d, 4, min_value=1e9)
+    assert_sweep(d, 4, ["torch"])
+
+
+def test_self_launched_ranks_print_the_deadline_line():
+    """--deadline-s through the self-launch: the phase after the reported region never ends (on purpose); rank 0 prints the
+    line as it stands, both ranks exit 0, so does the launcher, and the parent relays the one line."""
+    import time
+    t0 = time.time()
+    p, lines = _self_launch(2, {"LUDVM_BENCH_BACKEND": "gloo", "LUDVM_BENCH_TEST_HANG": "1"}, "--vortices", "120000", "--steps", "2",
+                            "--warmup", "1", "--deadline-s", "40", timeout=200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert 35 < time.time() - t0 < 120
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert "deadline" in d["incomplete"] and "hung on purpose" in d["incomplete"] and d["n_gpus"] == 2 and d["value"] > 1e10
+
+
+def test_self_launched_ranks_survive_a_communicator_join_that_never_returns():
+    """... and the join watchdog with two ranks: both time out, agree on it through torch, go on with torch.distributed's
+    collectives on fresh engines."""
+    p, lines = _self_launch(2, {"LUDVM_BENCH_BACKEND": "gloo", "LUDVM_BENCH_TEST_HANG_COMM": "1"}, "--vortices", "120000", "--steps", "2",
+                            "--warmup", "1", "--collectives", "library", "--comm-init-timeout", "3")
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert "did not return within 3 s" in d["config"]["collective_note"] and "torch.distributed" in d["config"]["collective"]
+    assert "incomplete" not in d
     _assert_self_checking_config4(d, 2)
 
 
@@ -246,6 +286,11 @@ def test_bench_two_ranks_on_rccl_with_two_gpus():
             assert len(d["config"]["pair_kernel_ms_per_rank"]) == 2 and d["value"] > 1e11
             assert ("libludvm_hip" in d["config"]["collective"]) == (coll == "auto")
             _assert_self_checking_config4(d, 2, main="symmetric" if sym == "1" else "direct")
+            assert_sweep(d, 2, ["library", "torch"] if coll == "auto" else ["torch"])
+    # and as the driver may well type it: no launcher
+    p, lines = _self_launch(2, {}, "--vortices", "200000", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-3000:]
+    assert json.loads(lines[0])["config"]["ranks"] == 2
 
 
 def test_bench_deadline_prints_what_has_been_measured():
@@ -273,6 +318,25 @@ def test_bench_survives_a_communicator_join_that_never_returns():
     helper thread: a join that does not return within --comm-init-timeout (here: on purpose) leaves the stuck call its
     context, the run goes on with torch.distributed's collectives on a fresh engine, says so, and exits cleanly."""
     env = dict(os.environ, LUDVM_BENCH_TEST_HANG_COMM="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg4", "--vortices", "60000", "--steps", "2",
+                        "--warmup", "1", "--cpu-rows", "0", "--collectives", "library", "--comm-init-timeout", "3"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert "did not return within 3 s" in d["config"]["collective_note"] and "torch.distributed" in d["config"]["collective"]
+    assert "incomplete" not in d and d["value"] > 1e11
+    _assert_self_checking_config4(d, 1, collectives_issued=False)
+
+
+def test_bench_leaves_a_communicator_alone_that_joined_late():
+    """a join that is merely SLOW returns after the timeout, when the run has moved on to
+    torch.distributed's collectives on a fresh engine.  The helper thread is told (`abandoned`): it issues no all-reduce on
+    the communicator nobody waits for.  Here: comm_init returns, then the hook sleeps past the timeout."""
+    env = dict(os.environ, LUDVM_BENCH_TEST_HANG_COMM="late")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg4", "--vortices", "60000", "--steps", "2",

@@ -28,3 +28,21 @@ def test_roofline_table_recomputes_from_profiles():
         assert 1.0 <= float(c[5].split("(")[1].split("x")[0]) < 1.2, c      # VALU instructions within 20 % of the model
     # the direct kernel's distance from its 54 % ceiling is the held clock: >= 95 % of the issue model
     assert float(direct[7]) > 0.95
+
+
+def test_bench_break_even_table_is_the_committed_measurement():
+    """bench.py's SHARD_SAVED_US (what `min_wake_suggested` is computed from) is a copy of profiles/r04_shard_break_even.txt."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    rows = {}
+    with open(os.path.join(ROOT, "profiles", "r04_shard_break_even.txt")) as f:
+        for line in f:
+            if line.startswith("{"):
+                r = json.loads(line)
+                rows[r["n"]] = r
+    assert set(bench.SHARD_SAVED_US) <= set(rows)
+    for n, by_g in bench.SHARD_SAVED_US.items():
+        assert rows[n]["allreduce_bytes"] == 16 * n
+        for g, us in by_g.items():
+            assert rows[n][f"G{g}_saved_us"] == us, (n, g)
