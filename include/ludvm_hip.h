@@ -162,10 +162,16 @@ int ludvm_comm_allgather_host(ludvm_ctx* ctx, const void* send, void* recv, size
  * The reference's float64 sum (LUDVM.py:565-569) does not depend on the order of its arrays; LUDVM_PREC_F32 here keeps
  * 1e-5 of max|u| for ANY order: sources and targets that are not stored compactly (a user's array, a turbulence cloud of
  * :98-130 -- unlike a shed wake) are evaluated in Morton order on the device and the results returned in the caller's
- * order (the given order is kept, and with it every result bit, whenever it is already compact); a call with fewer
- * than 2048 sources or targets -- too few to make 128-point origin classes compact -- runs in float64, and a set too
- * sparse for its core (mean class extent > 150 v_core in Morton order, > 300 v_core for a set that is compact as given:
- * fp32 offsets cannot resolve a core that small) takes hi+lo positions as LUDVM_PREC_F32X2 does. */
+ * order (the given order is kept, and with it every result bit, whenever it is already compact: within 3 x of an
+ * area-filling arrangement, or of a line across its bounding box, or within 1.5 x of what Morton order achieves); a call
+ * with fewer than 2048 sources or targets -- too few to make 128-point origin classes compact -- runs in float64 while
+ * ns * nt <= 2^28 (~0.2 ms at most) and on hi+lo positions beyond (a few probe points in a wake of millions: 1.3 x the
+ * fp32 time instead of the float64 rate on every pair); and a set too sparse for its core (mean class extent > 150 v_core
+ * in Morton order, > 300 v_core for a set that is compact as given: fp32 offsets cannot resolve a core that small) takes
+ * hi+lo positions as LUDVM_PREC_F32X2 does.  The arithmetic of a LUDVM_PREC_F32 call, and with it the last bits of its
+ * result, therefore depends on the SIZES and the COMPACTNESS of what is passed (never on anything else: same arrays, same
+ * bits); a set that evolves slowly across one of these thresholds changes route from one call to the next, within the
+ * stated 1e-5 either way. */
 int ludvm_induce_f64(ludvm_ctx* ctx, const double* xs, const double* zs, const double* gs, size_t ns,
                      const double* xt, const double* zt, size_t nt, double vcore, int precision,
                      double* u, double* w);

@@ -729,7 +729,8 @@ int launch_sym(ludvm_ctx* c, SymOperands o, long long n, double vc4, long long* 
 // v_core = 1.3e-3 [MI355X, profiles/r04_unordered_accuracy.txt].  The reference's float64 sum (:565-569) does not depend on
 // the order, so the host-pointer entry points may choose their own: Morton order, when -- and only when -- the given order
 // is not already compact, so that a shed wake's bits are what they were.
-constexpr size_t kOrderMin = 2048;     // below this many points a stateless fp32 call runs in float64 instead (see ludvm_induce_f64)
+constexpr size_t kOrderMin = 2048;     // below this many points on a side a stateless fp32 call does not run on local origins (see ludvm_induce_f64)
+constexpr double kSmallSidePairsF64 = 268435456.0;   // 2^28 pairs: what float64 evaluates in ~0.2 ms [MI355X: 1.2-1.5e12 pairs/s]
 
 struct OrderWs {
   unsigned* order[2];
@@ -791,6 +792,10 @@ int spatial_order_if_needed(ludvm_ctx* c, const OrderWs& w, int slot, const doub
   if (mean_extent) *mean_extent = e_given / nclass;
   const double side = std::sqrt(128.0 * ex * ez / (double)n);        // an area-filling class of 128 points
   if (e_given <= 3.0 * nclass * 2.0 * side) return LUDVM_OK;
+  // a thin set (every shed wake: ez << ex makes `side` tiny, the test above never passes): stored along a line from corner
+  // to corner of its box a class -- 128 of 256 consecutive points -- spans (ex + ez) 256 / n, and no order packs a line
+  // tighter.  Within 3 x of that the given order stays without the keys, the sort and the second pass.
+  if (e_given <= 3.0 * nclass * (ex + ez) * 256.0 / (double)n) return LUDVM_OK;
   const double span = std::max(ex, ez);
   OrderBox box_k{x0, z0, 65535.0 / span, 65535.0 / span};
   HIPCHK(c, spatial_order_sort(dx, dz, n, box_k, w.tmp, w.tmp_bytes, w.order[slot], c->stream));
@@ -1145,10 +1150,14 @@ int ludvm_induce_f64(ludvm_ctx* c, const double* xs, const double* zs, const dou
     return LUDVM_OK;
   }
   // fp32 on local origins needs compact origin classes on BOTH sides.  A side of fewer than kOrderMin points cannot be
-  // made compact by ordering it (a class is 128 points whatever their number) and such a launch is latency- or
-  // f64-rate-bound at well under 2 ms anyway: it runs in float64, whose accuracy does not depend on the order
-  // (the G1 clouds of 257 x 1023 random points: 5e-4 ... 2e-3 of max|u| in fp32 before, rounding now).
-  if (precision == LUDVM_PREC_F32 && std::min(ns, nt) < kOrderMin) precision = LUDVM_PREC_F64;
+  // made compact by ordering it (a class is 128 points whatever their number).  While the call is small as a whole
+  // (<= 2^28 pairs: latency-bound, float64 costs ~0.2 ms at most) it runs in float64, whose accuracy does not depend on
+  // the order (the G1 clouds of 257 x 1023 random points: 5e-4 ... 2e-3 of max|u| in fp32 before, rounding now).  A SMALL
+  // side against a LARGE one (a few probe points in a wake of 1e6 ... 8e6 vortices) would pay the float64 rate on every
+  // pair: it takes hi+lo positions instead (exact differences, no classes needed, 1.3 x the fp32 time, <= 2e-6 of max|u|)
+  // (ADVICE r4).
+  if (precision == LUDVM_PREC_F32 && std::min(ns, nt) < kOrderMin)
+    precision = (double)ns * (double)nt <= kSmallSidePairsF64 ? LUDVM_PREC_F64 : LUDVM_PREC_F32X2;
   const bool f64 = precision == LUDVM_PREC_F64;
   bool hilo = precision == LUDVM_PREC_F32X2;
   // the caller passed the same arrays as sources and targets: self-interaction (the targets are not uploaded twice,

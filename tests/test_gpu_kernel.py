@@ -1099,3 +1099,127 @@ def test_integration_md_binding_drives_the_reference_loop(prec_code, win):
     if prec_code == 2:
         np.testing.assert_allclose(sim.path["TEV"][50], g2["TEV_50"], rtol=0, atol=1e-9)
     ns["_hip"].ludvm_destroy(ns["_ctx"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G3: the reference's own call trace through the HIP path
+# ---------------------------------------------------------------------------------------------------------------------
+def _g3_calls():
+    from conftest import grouped
+    g3 = load_golden("g3_boundary_trace.npz")
+    by = grouped(g3)
+    return [by[str(k)] for k in range(int(g3["ncalls"]))]
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32x2", "f32"])
+def test_g3_boundary_trace_through_the_hip_path(eng, precision):
+    """Every induced_velocity call the unmodified reference made in steps 1-5, 100 and 400 of the README run
+    (tests/golden/g3_boundary_trace.npz: 63 calls at the call sites LUDVM.py:746, :751, :1054, :1105-1124 -- one-vortex and
+    three-vortex wakes, Gamma = 0 phantom slots at (0, 0), the unit TEV with an INTEGER circulation [1], single targets, the
+    80 bound vortices as sources) with the reference's arguments, through Engine.induce -> ludvm_induce_f64, against the
+    reference's returns.  f64: 1e-12 of the call's max|u| (and exact zeros where the reference has them); f32 takes the
+    float64 route at these sizes (< 2048 points a side: ludvm_hip.h) and is held to the same bound; f32x2 runs the fp32 hi+lo
+    kernels: 1e-5 of max|u|, and 2e-6 of the kernel mass per target."""
+    calls = _g3_calls()
+    assert len(calls) == 63 and sorted({int(c["step"]) for c in calls}) == [1, 2, 3, 4, 5, 100, 400]
+    assert sum(c["g"].dtype.kind == "i" for c in calls) == 7 and all(bool(c["viscous"]) for c in calls)
+    compared = 0
+    for k, c in enumerate(calls):
+        u, w = eng.induce(c["g"], c["xw"], c["zw"], c["xp"], c["zp"], 0.065, precision=precision)
+        assert u.dtype == np.float64 and u.shape == c["u"].shape == w.shape, k
+        assert np.array_equal(np.isnan(u), np.isnan(c["u"])) and np.array_equal(np.isnan(w), np.isnan(c["w"])), k
+        scale = max(np.abs(c["u"]).max(), np.abs(c["w"]).max())
+        if scale == 0.0:                       # (a wake of Gamma = 0 slots only: the reference returns exact zeros)
+            assert not u.any() and not w.any(), k
+            continue
+        err = max(np.abs(u - c["u"]).max(), np.abs(w - c["w"]).max()) / scale
+        compared += 1
+        assert err <= (1e-5 if precision == "f32x2" else 1e-12), (k, int(c["step"]), precision, err)
+        if precision == "f32x2":
+            mu, mw = _kernel_mass(c["g"].astype(float), c["xw"], c["zw"], c["xp"], c["zp"], 0.065)
+            assert np.all(np.abs(u - c["u"]) <= 2e-6 * mu + 1e-30) and np.all(np.abs(w - c["w"]) <= 2e-6 * mw + 1e-30), k
+    assert compared == 61                   # (calls 0 and 3: the step-1 wake is one Gamma = 0 slot)
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-12), ("f32x2", 1e-5), ("f32", 1e-5)])
+def test_g3_roll_up_calls_equal_one_resident_wake_advect(eng, precision, tol):
+    """The six roll-up calls of each traced step (LUDVM.py:1105-1124: wake -> TEV / LEV / FREE targets and bound vortices ->
+    the same targets) are ONE ludvm_wake_advect on the resident wake in this build: with the traced sources loaded (phantom
+    slots and all), the velocities it returns are u_wake + u_foil of the reference's calls in wake order, and the positions
+    it leaves are x + dt (u_wake + u_foil) (:1108-1109, :1117-1118, :1126-1127)."""
+    calls = _g3_calls()
+    dt = 5e-2
+    steps = sorted({int(c["step"]) for c in calls})
+    for s in steps:
+        mine = [c for c in calls if int(c["step"]) == s]
+        roll = mine[-6:]                                   # (wake, foil) x (TEV, LEV, FREE)
+        wake, foil = roll[0], roll[1]
+        for a, b in zip(roll[0::2], roll[1::2]):           # the three wake calls share their sources; so do the foil calls
+            assert np.array_equal(a["xw"], wake["xw"]) and np.array_equal(b["xw"], foil["xw"]) and len(b["g"]) == 80
+            assert np.array_equal(a["xp"], b["xp"])
+        xt = np.concatenate([c["xp"] for c in roll[0::2]])
+        zt = np.concatenate([c["zp"] for c in roll[0::2]])
+        assert np.array_equal(xt, wake["xw"]) and np.array_equal(zt, wake["zw"])       # targets = the wake, in its order
+        u_ref = np.concatenate([a["u"] + b["u"] for a, b in zip(roll[0::2], roll[1::2])])
+        w_ref = np.concatenate([a["w"] + b["w"] for a, b in zip(roll[0::2], roll[1::2])])
+        eng.wake_clear()
+        eng.wake_reserve(1024)
+        eng.wake_append(wake["xw"], wake["zw"], wake["g"])
+        u, w = eng.wake_advect(dt, foil["xw"], foil["zw"], foil["g"], 0.065, precision=precision, return_velocity=True)
+        scale = max(np.abs(u_ref).max(), np.abs(w_ref).max())
+        err = max(np.abs(u - u_ref).max(), np.abs(w - w_ref).max()) / scale
+        assert err <= tol, (s, precision, err)
+        x, z = eng.wake_read(0, len(xt))
+        # the Euler update is done on the float64 masters whatever the pair kernels' precision
+        assert np.abs(x - (xt + dt * u)).max() <= 1e-15 * max(1.0, np.abs(xt).max()) and np.abs(z - (zt + dt * w)).max() <= 1e-15, s
+        assert max(np.abs(x - (xt + dt * u_ref)).max(), np.abs(z - (zt + dt * w_ref)).max()) <= tol * scale * dt + 1e-15, s
+    eng.wake_clear()
+
+
+def test_a_few_probe_points_in_a_large_wake_do_not_pay_the_float64_rate(eng):
+    """LUDVM_PREC_F32 with fewer than 2048 points on ONE side used to run in float64 whatever the size of the
+    other side.  1000 probe targets in a wake of 1e6 vortices (1e9 pairs, > 2^28): the call takes hi+lo positions -- the
+    accuracy of the f32 tier (here <= 2e-6 of max|u| against the C oracle) at about a third of the float64 kernel time; with
+    100 000 sources (1e8 pairs, <= 2^28) it still takes the float64 route and its 1e-12."""
+    rng = np.random.default_rng(77)
+    n = 1_000_000
+    xw, zw = rng.uniform(-10, 0, n), rng.uniform(-2, 2, n)
+    g = rng.standard_normal(n) / n
+    xp, zp = rng.uniform(-10, 0, 1000), rng.uniform(-2, 2, 1000)
+    ur, wr = c_oracle.induced_velocity(g, xw, zw, xp, zp, 0.065)
+    ms = {}
+    for prec in ("f64", "f32"):
+        eng.induce(g, xw, zw, xp, zp, 0.065, precision=prec)              # (warm: buffers, first-use costs)
+        eng.kernel_timing(True)
+        eng.kernel_time_ms(reset=True)
+        u, w = eng.induce(g, xw, zw, xp, zp, 0.065, precision=prec)
+        ms[prec], launches = eng.kernel_time_ms(reset=True)
+        eng.kernel_timing(False)
+        assert launches >= 1
+        assert _rel(u, w, ur, wr) <= (1e-12 if prec == "f64" else 2e-6), prec
+    assert ms["f32"] < 0.6 * ms["f64"], ms
+    # the same targets, a tenth of the sources: small as a whole -> float64, as before
+    m = 100_000
+    u, w = eng.induce(g[:m], xw[:m], zw[:m], xp, zp, 0.065, precision="f32")
+    ur, wr = c_oracle.induced_velocity(g[:m], xw[:m], zw[:m], xp, zp, 0.065)
+    assert _rel(u, w, ur, wr) <= 1e-12
+
+
+def test_a_shed_sheet_keeps_its_order_without_a_sort(eng):
+    """a thin, sheet-like set (every shed wake) is compact as stored; the library now sees that from the class
+    extents alone (within 3 x of a line across the bounding box) and keeps the order -- reordered = 0 -- while a shuffled
+    copy of the same sheet is still put in Morton order, and both calls agree to the f32 tier."""
+    n = 40_000
+    s = np.linspace(0.0, 1.0, n)
+    x, z = -30.0 * s, 0.4 * np.sin(9.0 * s)                  # a wavy sheet, 30 chords long, stored in shedding order
+    order, reordered, ext = eng.spatial_order(x, z, with_extent=True)
+    assert reordered is False or reordered == 0
+    assert np.array_equal(order, np.arange(n)) and ext < 3.0 * (30.0 + 0.8) * 256 / n
+    perm = np.random.default_rng(5).permutation(n)
+    order2, reordered2, ext2 = eng.spatial_order(x[perm], z[perm], with_extent=True)
+    assert reordered2 and ext2 < 10.0 * ext
+    g = np.full(n, 1.0 / n)
+    u1, w1 = eng.induce(g, x, z, x, z, 5e-3, precision="f32")
+    u2, w2 = eng.induce(g, x[perm], z[perm], x[perm], z[perm], 5e-3, precision="f32")
+    ur, wr = c_oracle.induced_velocity(g, x, z, x, z, 5e-3)
+    assert _rel(u1, w1, ur, wr) <= 1e-5 and _rel(u2, w2, ur[perm], wr[perm]) <= 1e-5

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-config roofline table of DESIGN.md section 4, recomputed from the rocprofv3 summaries under profiles/ (no GPU needed).
 
-    python tools/roofline_table.py [round_prefix]            # default r04
+    python tools/roofline_table.py [round_prefix]            # default r05
 
 Per kernel: pairs per launch (stated in DESIGN.md section 4), average duration from `*_kernel_stats.csv`, credited fraction =
 13 FLOP x pairs / ns / 157.3e12, issued fraction (the FLOP per ordered pair the kernel really executes), VALU
@@ -50,18 +50,67 @@ def pmc(prefix, which):
     return out
 
 
+def config2_rows(rnd):
+    """Config 2's rows from config 2's OWN run (round 5): `{rnd}_config2_{kernel_stats,pmc_*}.csv` are
+    rocprofv3 passes of the full 50 000-step time loop (tools/run_configs.py cfg2) and `{rnd}_config2_under_rocprof.out` its JSON
+    line with the wake size after every 250th step.  The wake only grows and the launch geometry is a function of the wake size
+    alone, so the symmetric kernel's variants follow each other -- direct (small wakes), <4,.,4>, <4,.,0> (mixed granularity),
+    <8,.,4>, <8,.,0> -- and a variant's call count is a contiguous range of steps; pairs per launch = the mean of n^2 over
+    that range.  Rounds without these files (r04) fall back to the proxy rows in ROWS."""
+    import json
+    import re
+    p = os.path.join(ROOT, "profiles", f"{rnd}_config2")
+    if not os.path.exists(p + "_pmc_sq.csv"):
+        return None
+    with open(p + "_under_rocprof.out") as f:
+        run = json.loads([l for l in f if l.startswith("{")][-1])
+    every = run["wake_size_every_250_steps"]
+    step_of = [1 + 250 * k for k in range(len(every))]                  # sizes[k] is the wake after step k + 1
+
+    def wake_at(step):
+        import bisect
+        k = min(len(every) - 2, max(0, bisect.bisect_right(step_of, step) - 1))
+        t = (step - step_of[k]) / 250.0
+        return every[k] + t * (every[k + 1] - every[k])
+    st = stats(p)
+    order = []           # (sort key, kernel name, calls): the sequence of the roll-up's pair kernels over the run
+    for name, (calls, _) in st.items():
+        m = re.search(r"pair_sym_f32<(\d+), (\w+), (\d+), (\w+)>", name)
+        if m:
+            order.append(((int(m.group(1)), int(m.group(3)) == 0), name, calls))
+        elif "pair_f32<1, 256, false, 0, true>" in name:
+            order.append(((0, False), name, calls))
+    order.sort()
+    rows, step = [], 1
+    for _, name, calls in order:
+        a, b = step, step + calls
+        step = b
+        if "pair_sym_f32" not in name:
+            continue
+        n2 = sum(wake_at(s) ** 2 for s in range(a, b)) / calls
+        short = name.split("ludvm::")[1].split("(")[0]
+        rows.append((f"config 2, steps {a}-{b - 1}: wake {wake_at(a):.0f}-{wake_at(b - 1):.0f} vortices", f"config2", short, n2, 9,
+                     13 / 4, (11 * 4 + 2 * 8) / 4, 28.0 * n2 ** 0.5))
+    assert step - 1 == run["steps"] + 1 or abs(step - 1 - run["steps"]) <= 2, (step, run["steps"])
+    t8 = [r for r in rows if "<8," in r[2]]
+    assert t8 and abs(float(t8[0][0].split("wake ")[1].split("-")[0]) - 34816) < 1500, t8[0][0]     # T = 8 from 34 816 vortices
+    return rows
+
+
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    own = config2_rows(rnd)
+    table = [r for r in ROWS if r[1] != "config2_sizes"] + own if own else ROWS
     print("| kernel (workload) | pairs / launch | avg ms | credited frac (13 FLOP) | issued frac | VALU insts / launch (vs model) | "
-          "held clock GHz | time vs issue model | LDS conflict cycles | HBM traffic / algorithmic bytes |")
-    print("|---|---|---|---|---|---|---|---|---|---|")
-    for label, pre, kern, pairs, exe, ipp, cpp, alg in ROWS:
+          "held clock GHz | time vs issue model | LDS conflict cycles | HBM traffic / algorithmic bytes | source (profiles/) |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    for label, pre, kern, pairs, exe, ipp, cpp, alg in table:
         p = os.path.join(ROOT, "profiles", f"{rnd}_{pre}")
-        ks = [(k, v) for k, v in stats(p).items() if kern in k]
+        ks = [(k, v) for k, v in stats(p).items() if kern + "(" in k]
         assert len(ks) == 1, (kern, ks)
         calls, ns = ks[0][1]
         sq, fe, wr = pmc(p, "sq"), pmc(p, "fetch"), pmc(p, "write")
-        key = [k for k in sq if kern in k[0]][0][0]
+        key = [k for k in sq if k[0].endswith(kern)][0][0]
         valu, gui, lds = sq[(key, "SQ_INSTS_VALU")], sq[(key, "GRBM_GUI_ACTIVE")], sq[(key, "SQ_LDS_BANK_CONFLICT")]
         fetch_kb, write_kb = fe[(key, "FETCH_SIZE")], wr[(key, "WRITE_SIZE")]
         frac = 13 * pairs / (ns * 1e-9) / PEAK
@@ -71,7 +120,7 @@ def main():
         traffic = (2 * fetch_kb + write_kb) * 1024
         print(f"| `{kern}` ({label}) | {pairs:.4g} | {ns * 1e-6:.3f} ({calls} launches) | **{frac:.3f}** | {frac * exe / 13:.3f} | "
               f"{valu:.4g} ({valu / model_insts:.3f} x) | {clock * 1e-9:.2f} | {model_s / (ns * 1e-9):.3f} | {lds:.3g} | "
-              f"{traffic / 1e6:.0f} MB / {alg / 1e6:.1f} MB = {traffic / alg:.1f} x |")
+              f"{traffic / 1e6:.0f} MB / {alg / 1e6:.1f} MB = {traffic / alg:.1f} x | `{rnd}_{pre}_*` |")
 
 
 if __name__ == "__main__":

@@ -79,7 +79,11 @@ def cfg2(args):
                       "path": "per-step round trips" if args.no_march else "device-resident march",
                       "wall_s": el, "setup_s": t_setup, "time_loop_s": el - t_setup, "final_wake": int(sizes[-1]), "tev": int(ntev), "lev": int(nlev),
                       "rollup_pairs": pairs, "pairs_per_s_wall": pairs / el, "kernel_launches": nl,
-                      "kernel_ms_total": kms * nl, "Cl_last": float(sim.Cl[-1]), "Cl_mean_last_period": float(np.mean(sim.Cl[-10000:])),
+                      "kernel_ms_total": kms * nl,
+                      # the wake size after every 250th step (the wake only grows: tools/roofline_table.py turns the call
+                      # counts of a kernel-statistics file into step ranges and mean pairs per launch with it)
+                      "wake_size_every_250_steps": [int(v) for v in sizes[::250]],
+                      "Cl_last": float(sim.Cl[-1]), "Cl_mean_last_period": float(np.mean(sim.Cl[-10000:])),
                       "max_abs_LESP": float(np.abs(sim.LESP).max())}))
 
 
