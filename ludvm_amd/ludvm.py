@@ -364,25 +364,63 @@ class LUDVM:
         Gamma_LEV when |A0| reaches LESPcrit), rebuild the bound vorticity, integrate the loads and
         convect the wake.  `BCcheck` is accepted for signature compatibility; the reference's check
         (:1144-1161) raises a shape error and has no effect on the results.  `_resume` is the state a
-        checkpoint holds (see `resume`)."""
-        pi, U, c, rho, dt = np.pi, self.Uinf, self.chord, self.rho, self.dt
-        eng, vc = self.engine, self.v_core
+        checkpoint holds (see `resume`).
+
+        The loop itself: every step is MARCHED on the device where the engine offers it (`_march_call`: stretches of steps
+        in one ludvm_march_run); the per-step path (`_host_step`: one device round trip, solve on the host) serves
+        march=False and engines without the march."""
+        S = self._loop_begin()
+        if _resume is not None:
+            self._loop_restore(S, _resume)
+        self._free_slot = S.fslot
+        S.fsl = slice(0, S.nf) if S.fslot is None else S.fslot
+        self._loop_prepare_engine(S)
+        eng, nt = self.engine, self.nt
+        try:
+            if self._shard is not None:
+                # the roll-up's unordered pairs in tile blocks over the ranks, one integer all-reduce per step (attached
+                # inside the try: whatever goes wrong from here on, the engine is left unsharded)
+                self._shard.attach(eng, S.nf + 2 * (nt - 1) + self.Npoints - 1 + 2)
+            i = S.first_step
+            while i < nt:
+                if S.can_march:
+                    j, rec_i = self._march_extent(S, i)
+                    if j > i:
+                        self._march_call(S, i, j, rec_i, print_dt)
+                        i = j
+                        continue
+                self._host_step(S, i, print_dt)
+                i += 1
+        finally:
+            if self._shard is not None:
+                self._shard.detach(eng)
+        return None
+
+    # ---- the state a time loop carries, and its set-up --------------------------------------------------------------------
+    class _Loop:
+        """Scalars carried from step to step (counters, Kelvin sums, the newest shed vortices, the slot maps of the resident
+        wake) and the constant tables of a run."""
+
+    def _loop_begin(self):
+        """Result arrays (LUDVM.py:615-641), projection tables, the device wake with the free vortices in it."""
+        pi, U, c = np.pi, self.Uinf, self.chord
+        eng = self.engine
         nt, nv, nf, npan = self.nt, self.nt - 1, self.n_freevort, self.Npoints - 1
-        th = self.airfoil['theta']
-        thp = self.airfoil['theta_panel']
-        x_gamma = self.airfoil['x_panel']
-        detadx = self.airfoil['detadx_panel']
-        gpts = self.path['airfoil_gamma_points']
-        foil = self.path['airfoil']
+        S = LUDVM._Loop()
+        S.nf = nf
+        th, thp = self.airfoil['theta'], self.airfoil['theta_panel']
+        S.x_gamma = self.airfoil['x_panel']
+        S.detadx = self.airfoil['detadx_panel']
+        S.gpts = self.path['airfoil_gamma_points']
+        S.foil = self.path['airfoil']
         self._setup_projection()
-        wq, cproj, cm1, ssin = self._wq, self._cproj, self._cm1, self._ssin
         dth = th[1:] - th[:-1]
-        one_plus_cos_over_sin = (1 + np.cos(thp)) / np.sin(thp)
-        half_c_sin_dth = c / 2 * np.sin(thp) * dth
-        wx = np.zeros(npan)                       # trapezoid weights on x_gamma (loads, :1071, :1090)
-        dxg = np.diff(x_gamma)
-        wx[:-1] += dxg / 2
-        wx[1:] += dxg / 2
+        S.one_plus_cos_over_sin = (1 + np.cos(thp)) / np.sin(thp)
+        S.half_c_sin_dth = c / 2 * np.sin(thp) * dth
+        S.wx = np.zeros(npan)                       # trapezoid weights on x_gamma (loads, :1071, :1090)
+        dxg = np.diff(S.x_gamma)
+        S.wx[:-1] += dxg / 2
+        S.wx[1:] += dxg / 2
 
         full = self.history == 'full'
         P = self.path
@@ -410,8 +448,8 @@ class LUDVM:
         A0, A1 = np.sin(self.alpha_m), 0
         self.fourier[0, 0, :2] = A0, A1
         g_free = np.asarray(self.circulation_freevort, dtype=float)
-        sum_free = np.sum(C['FREE'])
-        C['IC'] = sum_free + U * c * pi * (A0 + A1 / 2)
+        S.sum_free = np.sum(C['FREE'])
+        C['IC'] = S.sum_free + U * c * pi * (A0 + A1 / 2)
 
         # device wake, in shedding order: FREE first, then each step's TEV (and LEV when shed)
         eng.wake_clear()
@@ -430,7 +468,7 @@ class LUDVM:
                 warnings.warn(f"LUDVM: the free-vortex cloud is too sparse for v_core = {self.v_core:g} to keep 1e-5 of max|u| "
                               f"in fp32 on local origins (mean 128-vortex class extent {extent:.3g} > {150 if reordered else 300} v_core); "
                               "the wake-on-wake sums of this run use hi+lo positions (precision='f32x2')",
-                              RuntimeWarning, stacklevel=3)
+                              RuntimeWarning, stacklevel=4)
                 self.precision, reordered = 'f32x2', False
             if reordered:
                 fslot = np.empty(nf, dtype=np.int64)
@@ -438,308 +476,139 @@ class LUDVM:
                 eng.wake_append(free0[0][order], free0[1][order], g_free[order])
         if fslot is None:
             eng.wake_append(free0[0], free0[1], g_free)
-        tev_slot = np.zeros(nv, dtype=np.int64)
-        lev_slot = np.zeros(nv, dtype=np.int64)
-        sum_tev = sum_lev = 0.0                   # running Kelvin sums (:758-760)
-        last_tev = last_lev = None                # newest shed vortices after their convection
-        itev = ilev = 0
-        lesp_crit = self.LESPcrit
-        LEV_shed = -1 * np.ones(nt)
-        first_step = 1
-        if _resume is not None:
-            R = _resume
-            first_step, itev, ilev = int(R['next_step']), int(R['itev']), int(R['ilev'])
-            lesp_crit, sum_tev, sum_lev = float(R['lesp_crit']), float(R['sum_tev']), float(R['sum_lev'])
-            last_tev = None if np.isnan(R['last_tev']).any() else R['last_tev'].copy()
-            last_lev = None if np.isnan(R['last_lev']).any() else R['last_lev'].copy()
-            LEV_shed, tev_slot, lev_slot = R['LEV_shed'].copy(), R['tev_slot'].copy(), R['lev_slot'].copy()
-            for key in ('TEV', 'LEV', 'bound', 'airfoil', 'gamma_airfoil', 'Gamma_airfoil'):
-                C[key][...] = R['circ_' + key]
-            for name in ('Fn', 'Fs', 'L', 'D', 'T', 'M', 'fourier', 'LESP', 'LESP_prev'):
-                getattr(self, name)[...] = R[name]
-            for key in ('TEV', 'LEV', 'FREE'):
-                if full:
-                    P[key][:first_step] = R['path_' + key]
-                else:
-                    for srow in R['rows_steps']:
-                        P[key].store(int(srow), R[f'row_{key}_{int(srow)}'])
-            eng.wake_clear()
-            eng.wake_append(R['wake_x'], R['wake_z'], R['wake_g'])        # (in the stored order, free vortices included)
-            fslot = R['free_slot'].astype(np.int64) if ('free_slot' in R.files and R['free_slot'].size == nf) else None
-            self.ilev, self.itev, self.LEV_shed = int(R['self_ilev']), int(R['self_itev']), LEV_shed
-        self._free_slot = fslot
-        fsl = slice(0, nf) if fslot is None else fslot
+        S.fslot = fslot
+        S.tev_slot = np.zeros(nv, dtype=np.int64)
+        S.lev_slot = np.zeros(nv, dtype=np.int64)
+        S.sum_tev = S.sum_lev = 0.0                 # running Kelvin sums (:758-760)
+        S.last_tev = S.last_lev = None              # newest shed vortices after their convection
+        S.itev = S.ilev = 0
+        S.lesp_crit = self.LESPcrit
+        S.LEV_shed = -1 * np.ones(nt)
+        S.first_step = 1
+        return S
 
+    def _loop_restore(self, S, R):
+        """The loop's state as a checkpoint holds it (`_write_checkpoint_file`)."""
+        C, P, eng, nf = self.circulation, self.path, self.engine, S.nf
+        S.first_step, S.itev, S.ilev = int(R['next_step']), int(R['itev']), int(R['ilev'])
+        S.lesp_crit, S.sum_tev, S.sum_lev = float(R['lesp_crit']), float(R['sum_tev']), float(R['sum_lev'])
+        S.last_tev = None if np.isnan(R['last_tev']).any() else R['last_tev'].copy()
+        S.last_lev = None if np.isnan(R['last_lev']).any() else R['last_lev'].copy()
+        S.LEV_shed, S.tev_slot, S.lev_slot = R['LEV_shed'].copy(), R['tev_slot'].copy(), R['lev_slot'].copy()
+        for key in ('TEV', 'LEV', 'bound', 'airfoil', 'gamma_airfoil', 'Gamma_airfoil'):
+            C[key][...] = R['circ_' + key]
+        for name in ('Fn', 'Fs', 'L', 'D', 'T', 'M', 'fourier', 'LESP', 'LESP_prev'):
+            getattr(self, name)[...] = R[name]
+        for key in ('TEV', 'LEV', 'FREE'):
+            if self.history == 'full':
+                P[key][:S.first_step] = R['path_' + key]
+            else:
+                for srow in R['rows_steps']:
+                    P[key].store(int(srow), R[f'row_{key}_{int(srow)}'])
+        eng.wake_clear()
+        eng.wake_append(R['wake_x'], R['wake_z'], R['wake_g'])        # (in the stored order, free vortices included)
+        S.fslot = R['free_slot'].astype(np.int64) if ('free_slot' in R.files and R['free_slot'].size == nf) else None
+        self.ilev, self.itev, self.LEV_shed = int(R['self_ilev']), int(R['self_itev']), S.LEV_shed
+
+    def _loop_prepare_engine(self, S):
+        """Host buffers of the per-step path; tables and kinematics of the device-resident march."""
+        eng, C = self.engine, self.circulation
+        npan = self.Npoints - 1
         # preallocated host buffers for the two device calls of a step (engines that offer them)
-        sb = eng.step_buffers(npan) if hasattr(eng, 'step_buffers') else None
-        prec_code = {'f32': 0, 'f32x2': 1, 'f64': 2}[self.precision]
-        vc_f, dt_f = float(vc), float(dt)
-        have_next = False     # sb already holds step i's placement and chord sums (from the previous wake_step)
+        S.sb = eng.step_buffers(npan) if hasattr(eng, 'step_buffers') else None
+        S.prec_code = {'f32': 0, 'f32x2': 1, 'f64': 2}[self.precision]
+        S.have_next = False     # sb already holds step i's placement and chord sums (from the previous wake_step)
 
-        # Device-resident march (ludvm_march_setup / ludvm_march_run): stretches of steps whose history row is
-        # not recorded run without a host round trip per step; the per-step path below serves recorded steps
-        # and engines without the march.
-        can_march = (self.march and self.method in ('Faure', 'Ramesh') and hasattr(eng, 'march_run') and npan <= 256
-                     and 4 <= self.Ncoeffs <= 64)
-        if can_march:
-            tables = np.concatenate([detadx, self.airfoil['eta_panel'], x_gamma, cm1, wq, one_plus_cos_over_sin,
-                                     half_c_sin_dth, wx, cproj.ravel(), ssin.ravel()])
-            kin = np.concatenate([self.alpha[:, None], self.alpha_dot[:, None], self.h_dot[:, None], foil[:, :, -1],
-                                  foil[:, :, 0], gpts[:, 0, :], gpts[:, 1, :]], axis=1)
-            eng.march_setup(npan, self.Ncoeffs, [U, c, rho, dt, self.piv, vc, C['IC'], sum_free,
+        # Device-resident march (ludvm_march_setup / ludvm_march_run): stretches of steps run without a host round trip
+        # per step; the per-step path serves march=False and engines without the march.
+        S.can_march = (self.march and self.method in ('Faure', 'Ramesh') and hasattr(eng, 'march_run') and npan <= 256
+                       and 4 <= self.Ncoeffs <= 64)
+        if S.can_march:
+            tables = np.concatenate([S.detadx, self.airfoil['eta_panel'], S.x_gamma, self._cm1, self._wq, S.one_plus_cos_over_sin,
+                                     S.half_c_sin_dth, S.wx, self._cproj.ravel(), self._ssin.ravel()])
+            kin = np.concatenate([self.alpha[:, None], self.alpha_dot[:, None], self.h_dot[:, None], S.foil[:, :, -1],
+                                  S.foil[:, :, 0], S.gpts[:, 0, :], S.gpts[:, 1, :]], axis=1)
+            eng.march_setup(npan, self.Ncoeffs, [self.Uinf, self.chord, self.rho, self.dt, self.piv, self.v_core, C['IC'], S.sum_free,
                                                   float(self.method == 'Ramesh'), self.maxerror, self.maxiter, self.epsilon], tables, kin)
         # with the dense history every step's row is recorded: the march then keeps a snapshot of the wake per step on
         # the device (shorter calls, the snapshots are [steps, 2, wake size])
-        dense_march = can_march and full
-        march_chunk = int(getattr(self, '_march_chunk', 512 if dense_march else 32768))   # steps per ludvm_march_run call
+        S.dense_march = S.can_march and self.history == 'full'
+        S.march_chunk = int(getattr(self, '_march_chunk', 512 if S.dense_march else 32768))   # steps per ludvm_march_run call
 
-        try:
-            if self._shard is not None:
-                # the roll-up's unordered pairs in tile blocks over the ranks, one integer all-reduce per step (attached
-                # inside the try: whatever goes wrong from here on, the engine is left unsharded)
-                self._shard.attach(eng, nf + 2 * nv + npan + 2)
-            i = first_step
-            while i < nt:
-                if can_march:
-                    # Every step is marched, whatever the history mode: a step whose row is recorded (sparse history) is a
-                    # call of its own that also returns the wake's positions after it -- so a run's bits do not depend on
-                    # which rows it keeps (rounds 1-3 took recorded steps through the per-step path, whose launches are
-                    # sized from the exact wake size instead of the march's anchor bound: fp32 rounding differed from the
-                    # first recorded step on)
-                    rec_i = (not dense_march) and self._record_row(i)
-                    j = i
-                    if rec_i:
-                        # a run of consecutive recorded steps is one call (its snapshots are [steps, 2, wake size] doubles:
-                        # at most 256 MB of them)
-                        n_now = nf + itev + ilev
-                        most = max(1, min(512, int(256e6 / (16.0 * (n_now + 1024)))))
-                        while j < nt and self._record_row(j) and j - i < most:
-                            j += 1
-                            if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
-                                break
-                    while (not rec_i) and j < nt and (dense_march or not self._record_row(j)) and j - i < march_chunk:
-                        j += 1
-                        if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
-                            break
-                    if j > i:
-                        if have_next:
-                            place = [sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1]]
-                        else:
-                            te, le = foil[i, :, -1], foil[i, :, 0]
-                            tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
-                            lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
-                            place = [tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]]
-                        (itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev) = self._march_stretch(
-                            i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed, tev_slot,
-                            lev_slot, prec_code, record=dense_march or rec_i)
-                        have_next = False
-                        if self.verbose == True:  # noqa: E712
-                            for q in range(i, j):
-                                if q == 1 or q == nt - 1 or q / print_dt == int(q / print_dt):
-                                    print('Step {} out of {}. Elapsed time {}'.format(q, nt - 1,
-                                                                                       timeit.default_timer() - self.start_time))
-                        if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0 and j - 1 < nt - 1:
-                            self._write_checkpoint(j, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
-                                                   tev_slot, lev_slot)
-                        i = j
-                        continue
-                if (i == 1 or i == nt - 1 or i / print_dt == int(i / print_dt)) and self.verbose == True:  # noqa: E712
-                    print('Step {} out of {}. Elapsed time {}'.format(i, nt - 1, timeit.default_timer() - self.start_time))
-                xg, zg = gpts[i, 0, :], gpts[i, 1, :]
-                te, le = foil[i, :, -1], foil[i, :, 0]
+    def _progress(self, q, print_dt):
+        if (q == 1 or q == self.nt - 1 or q / print_dt == int(q / print_dt)) and self.verbose == True:  # noqa: E712
+            print('Step {} out of {}. Elapsed time {}'.format(q, self.nt - 1, timeit.default_timer() - self.start_time))
 
-                # new TEV: first one half a step behind the initial trailing edge, then 1/3 of the way
-                # from the trailing edge to the previous TEV (:672-681)
-                # candidate LEV position: only geometry and the previous LEV enter (:788-800), so it is known
-                # before the solve and its unit influence rides in the same device call as the TEV's
-                n_wake = nf + itev + ilev
-                if have_next:
-                    # placed on the device right after the previous roll-up, sums already here
-                    tev_xy = np.array([sb.unit[0, 0], sb.unit[1, 0]])
-                    lev_xy = np.array([sb.unit[0, 1], sb.unit[1, 1]])
-                else:
-                    tev_xy = foil[0, :, -1] + np.array([0.5 * U * dt, 0.0]) if itev == 0 else te + (last_tev - te) / 3
-                    lev_xy = le + (last_lev - le) / 3 if (ilev > 0 and LEV_shed[i - 1] != -1) else le.copy()
+    def _next_placement(self, S, i):
+        """New TEV: the first one half a step behind the initial trailing edge, then 1/3 of the way from the trailing edge to
+        the previous TEV (:672-681).  Candidate LEV: only geometry and the previous LEV enter (:788-800), so it is known
+        before the solve."""
+        foil = S.foil
+        te, le = foil[i, :, -1], foil[i, :, 0]
+        tev_xy = foil[0, :, -1] + np.array([0.5 * self.Uinf * self.dt, 0.0]) if S.itev == 0 else te + (S.last_tev - te) / 3
+        lev_xy = le + (S.last_lev - le) / 3 if (S.ilev > 0 and S.LEV_shed[i - 1] != -1) else le.copy()
+        return tev_xy, lev_xy
 
-                # existing wake -> chord (T1), unit new TEV -> chord (T2), unit candidate LEV -> chord (T3):
-                # one round trip (:743-754, :924-934)
-                if have_next:
-                    u1, w1, ut1, wt1, ul1, wl1 = sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1]
-                elif sb is not None:
-                    sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1] = tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]
-                    eng.wake_chord_sums_into(sb, n_wake, xg, zg, vc_f)
-                    u1, w1, ut1, wt1, ul1, wl1 = sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1]
-                else:
-                    u1, w1, uu, wu = eng.wake_chord_sums(0, n_wake, xg, zg, [tev_xy[0], lev_xy[0]], [tev_xy[1], lev_xy[1]], vc)
-                    ut1, wt1, ul1, wl1 = uu[0], wu[0], uu[1], wu[1]
-                T1 = self._downwash_from(u1, w1, i)
-                ut, un = self._chord_frame(ut1, wt1, i)
-                T2 = detadx * ut - un
-                I1, I2 = T1 @ cm1, T2 @ cm1
-                kelvin = sum_tev + sum_lev + sum_free - C['IC']
-                if self.method == 'Ramesh':
-                    g_tev = self._newton_tev(T1, T2, kelvin)                         # :683-739
-                elif self.method == 'Faure':
-                    g_tev = -(I1 + kelvin) / (1 + I2)                                # :758-760
-                else:
-                    raise ValueError("method must be 'Faure' or 'Ramesh'")
-                g_lev = 0.0
-                W = T1 + g_tev * T2
-                A = cproj @ (W / U)
-                C['bound'][itev] = I1 + g_tev * I2 if self.method == 'Faure' else U * c * pi * (A[0] + A[1] / 2)
-                self.fourier[i, 0, :] = A
-                self.fourier[i, 1, :] = (A - self.fourier[i - 1, 0, :]) / dt          # :772-773
-                self.LESP_prev[itev] = A[0]
+    # ---- marched stretches --------------------------------------------------------------------------------------------------
+    def _march_extent(self, S, i):
+        """-> (j, rec_i): the stretch [i, j) the next ludvm_march_run call covers.  Every step is marched, whatever the
+        history mode: a step whose row is recorded (sparse history) is a call of its own that also returns the wake's
+        positions after it -- so a run's bits do not depend on which rows it keeps (rounds 1-3 took recorded steps through
+        the per-step path, whose launches are sized from the exact wake size instead of the march's anchor bound: fp32
+        rounding differed from the first recorded step on)."""
+        nt = self.nt
+        rec_i = (not S.dense_march) and self._record_row(i)
+        j = i
+        if rec_i:
+            # a run of consecutive recorded steps is one call (its snapshots are [steps, 2, wake size] doubles:
+            # at most 256 MB of them)
+            n_now = S.nf + S.itev + S.ilev
+            most = max(1, min(512, int(256e6 / (16.0 * (n_now + 1024)))))
+            while j < nt and self._record_row(j) and j - i < most:
+                j += 1
+                if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
+                    break
+        while (not rec_i) and j < nt and (S.dense_march or not self._record_row(j)) and j - i < S.march_chunk:
+            j += 1
+            if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0:
+                break
+        return j, rec_i
 
-                shed = abs(A[0]) >= abs(lesp_crit)                                    # :781
-                if shed:
-                    LEV_shed[i] = ilev
-                    lesp_crit = -abs(lesp_crit) if A[0] < 0 else abs(lesp_crit)       # :802-805
-                    ult, uln = self._chord_frame(ul1, wl1, i)
-                    T3 = detadx * ult - uln
-                    I3 = T3 @ cm1
-                    J1, J2, J3 = (-1 / pi * (T @ wq) for T in (T1, T2, T3))
-                    if self.method == 'Ramesh':
-                        g_tev, g_lev = self._newton_tev_lev(T1, T2, T3, kelvin, lesp_crit, g_tev)   # :807-914
-                    else:
-                        g_tev, g_lev = np.linalg.solve(np.array([[1 + I2, 1 + I3], [J2, J3]]),
-                                                       np.array([-(I1 + kelvin), lesp_crit - J1]))  # :944-954
-                    W = T1 + g_tev * T2 + g_lev * T3
-                    A = cproj @ (W / U)
-                    if self.method == 'Faure':
-                        C['bound'][itev] = I1 + g_tev * I2 + g_lev * I3
-                        A[0] = J1 + g_tev * J2 + g_lev * J3                           # :959
-                    else:
-                        C['bound'][itev] = U * c * pi * (A[0] + A[1] / 2)
-                    self.fourier[i, 0, :] = A       # derivatives keep their pre-LEV values (:963-966)
-                    C['LEV'][ilev] = g_lev
-                C['TEV'][itev] = g_tev
-                self.LESP[itev] = A[0]
+    def _march_call(self, S, i, j, rec_i, print_dt):
+        sb = S.sb
+        if S.have_next:
+            place = [sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1]]
+        else:
+            tev_xy, lev_xy = self._next_placement(S, i)
+            place = [tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]]
+        self._march_stretch(S, i, j, place, record=S.dense_march or rec_i)
+        S.have_next = False
+        if self.verbose == True:  # noqa: E712
+            for q in range(i, j):
+                self._progress(q, print_dt)
+        if self.checkpoint_every and (j - 1) % self.checkpoint_every == 0 and j - 1 < self.nt - 1:
+            self._write_checkpoint(S, j)
 
-                # bound vorticity per panel (:987-1010)
-                A0, A1, A2 = A[0], A[1], A[2]
-                A0d, A1d, A2d, A3d = self.fourier[i, 1, :4]
-                gamma = 2 * U * (A0 * one_plus_cos_over_sin + A[1:] @ ssin)
-                dGamma = gamma * half_c_sin_dth
-                C['airfoil'][itev], C['gamma_airfoil'][itev] = dGamma, gamma
-                C['Gamma_airfoil'][itev] = np.cumsum(dGamma)
-
-                # loads (:1035-1090).  The tangential velocity on the chord from the full wake (incl. the
-                # new TEV/LEV with their solved circulations) follows by linearity from u1 and the unit
-                # influences already evaluated: no further pair sum.
-                uc1, wc1 = u1 + g_tev * ut1, w1 + g_tev * wt1
-                if shed:
-                    uc1, wc1 = uc1 + g_lev * ul1, wc1 + g_lev * wl1
-                u, _ = self._chord_frame(uc1, wc1, i)
-                a, hd = self.alpha[i], self.h_dot[i]
-                Ueff = U * np.cos(a) + hd * np.sin(a)
-                self.Fn[i] = rho * pi * c * U * (Ueff * (A0 + 0.5 * A1) + c * (3 / 4 * A0d + 1 / 4 * A1d + 1 / 8 * A2d)) \
-                    + rho * ((u * gamma) @ wx)
-                self.Fs[i] = rho * pi * c * U**2 * A0**2
-                self.L[i] = self.Fn[i] * np.cos(a) + self.Fs[i] * np.sin(a)
-                self.D[i] = self.Fn[i] * np.sin(a) - self.Fs[i] * np.cos(a)
-                self.T[i] = -self.D[i]
-                self.M[i] = self.piv * self.Fn[i] - rho * pi * c**2 * U * (
-                    Ueff * (1 / 4 * A0 + 1 / 4 * A1 - 1 / 8 * A2)
-                    + c * (7 / 16 * A0d + 3 / 16 * A1d + 1 / 16 * A2d - 1 / 64 * A3d)) \
-                    - rho * ((u * gamma * x_gamma) @ wx)
-
-                # wake roll-up (:1095-1127): shed vortices join the resident wake, then one fused launch
-                # (wake + bound vortices -> every wake vortex, explicit Euler update on the device)
-                record = self._record_row(i)
-                new_x, new_z, new_g = [tev_xy[0]], [tev_xy[1]], [g_tev]
-                tev_slot[itev] = n_wake
-                if shed:
-                    lev_slot[ilev] = n_wake + 1
-                    new_x.append(lev_xy[0]); new_z.append(lev_xy[1]); new_g.append(g_lev)
-                elif record:
-                    # the reference also convects LEV slot `ilev` (zero strength, at the origin) on a
-                    # non-shedding step and stores it in path['LEV'][i]; reproduce that row entry
-                    new_x.append(0.0); new_z.append(0.0); new_g.append(0.0)
-                n_after = n_wake + len(new_x)
-                one_trip = (not record) and sb is not None and i < nt - 1 and hasattr(eng, 'wake_step_into')
-                if not one_trip:
-                    eng.wake_append(new_x, new_z, new_g)
-
-                if record:
-                    have_next = False
-                    eng.wake_advect(dt, xg, zg, dGamma, vc, precision=self.precision)
-                    xs, zs = eng.wake_read(0, n_after)
-                    row_t = np.stack([xs[tev_slot[:itev + 1]], zs[tev_slot[:itev + 1]]])
-                    lslots = lev_slot[:ilev + 1] if shed else np.append(lev_slot[:ilev], n_after - 1)
-                    row_l = np.stack([xs[lslots], zs[lslots]])
-                    row_f = np.stack([xs[fsl], zs[fsl]])
-                    if full:
-                        P['TEV'][i, :, :itev + 1] = row_t
-                        P['LEV'][i, :, :ilev + 1] = row_l
-                        P['FREE'][i] = row_f
-                    else:
-                        P['TEV'].store(i, row_t)
-                        P['LEV'].store(i, row_l)
-                        P['FREE'].store(i, row_f)
-                    last_tev = row_t[:, -1].copy()
-                    if shed:
-                        last_lev = row_l[:, -1].copy()
-                    elif len(new_x) == 2:
-                        eng.wake_truncate(n_after - 1)   # drop the phantom LEV slot
-                else:
-                    # only the newest TEV / LEV come back: they place the next ones (:680-681, :797-798)
-                    k = 2 if shed else 1
-                    have_next = False
-                    if one_trip:
-                        # append of the shed vortices + roll-up of this step + placement and chord sums of the
-                        # next one: one packed upload, one download
-                        eng.wake_step_into(sb, np.array(new_x), np.array(new_z), np.array(new_g, dtype=float), dt_f, xg, zg,
-                                           dGamma, vc_f, prec_code, np.ascontiguousarray(foil[i + 1, :, -1]),
-                                           np.ascontiguousarray(foil[i + 1, :, 0]), shed, k, gpts[i + 1, 0, :],
-                                           gpts[i + 1, 1, :])
-                        xs, zs = sb.tail[0], sb.tail[1]
-                        have_next = True
-                    elif sb is not None:
-                        eng.wake_advect_tail_into(sb, dt_f, xg, zg, dGamma, vc_f, k, prec_code)
-                        xs, zs = sb.tail[0], sb.tail[1]
-                    else:
-                        xs, zs = eng.wake_advect_tail(dt, xg, zg, dGamma, vc, k, precision=self.precision)
-                    last_tev = np.array([xs[0], zs[0]])
-                    if shed:
-                        last_lev = np.array([xs[1], zs[1]])
-
-                sum_tev += g_tev
-                self.ilev, self.itev, self.LEV_shed = ilev, itev, LEV_shed
-                if shed:
-                    sum_lev += g_lev
-                    ilev += 1
-                itev += 1
-                if self.checkpoint_every and i % self.checkpoint_every == 0 and i < nt - 1:
-                    self._write_checkpoint(i + 1, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
-                                           tev_slot, lev_slot)
-                i += 1
-        finally:
-            if self._shard is not None:
-                self._shard.detach(eng)
-        return None
-
-    def _march_stretch(self, i, j, place, nf, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
-                       tev_slot, lev_slot, prec_code, record=False):
+    def _march_stretch(self, S, i, j, place, record=False):
         """Time steps [i, j) as one device-resident march (Engine.march_run) and everything the per-step path
         would have stored for them (LUDVM.py:765-1090): circulations, Fourier rows, LESP, loads, slot maps -- and,
         with `record` (dense history), the path[...] rows of every step (:1108-1127).
-        `place` = [tev_x, lev_x, tev_z, lev_z] of step i.  LEV_shed, tev_slot, lev_slot and the result arrays
-        are updated in place; returns the loop's scalars after step j - 1."""
+        `place` = [tev_x, lev_x, tev_z, lev_z] of step i.  The loop state S and the result arrays are updated in place."""
         C, nc, npan, cnt = self.circulation, self.Ncoeffs, self.Npoints - 1, j - i
+        nf, itev, ilev, LEV_shed, tev_slot, lev_slot = S.nf, S.itev, S.ilev, S.LEV_shed, S.tev_slot, S.lev_slot
         H = self.engine.MARCH_ROW_HEAD
         n_wake = nf + itev + ilev
         st = np.zeros(16 + nc)
-        st[:11] = [n_wake, itev, ilev, float(LEV_shed[i - 1] != -1), lesp_crit, sum_tev, sum_lev] + list(place)
+        st[:11] = [n_wake, itev, ilev, float(LEV_shed[i - 1] != -1), S.lesp_crit, S.sum_tev, S.sum_lev] + list(place)
         # wake sizes after the four anchor steps before this call (ludvm_march_run, `anchors`): the launch geometry of
         # every step then follows from the step number and the run itself, not from where the stretches begin
         shed_before = np.cumsum(LEV_shed[:i] != -1)            # LEVs shed in steps 0 .. q (step 0 sheds none)
         anchors = [nf + a + int(shed_before[a]) for a in self.engine.march_anchor_steps(i)]      # (all of them < i)
         st[16:] = self.fourier[i - 1, 0, :]
         if record:
-            R, hist = self.engine.march_run(i, cnt, prec_code, st, hist_nmax=n_wake + 2 * cnt, anchors=anchors)
+            R, hist = self.engine.march_run(i, cnt, S.prec_code, st, hist_nmax=n_wake + 2 * cnt, anchors=anchors)
         else:
-            R = self.engine.march_run(i, cnt, prec_code, st, anchors=anchors)
+            R = self.engine.march_run(i, cnt, S.prec_code, st, anchors=anchors)
         steps = np.arange(i, j)
         tix = itev + np.arange(cnt)
         shed_v = R[:, 2] != 0
@@ -767,59 +636,244 @@ class LUDVM:
         C['airfoil'][tix] = R[:, H + 2 * nc + npan:]
         C['Gamma_airfoil'][tix] = np.cumsum(C['airfoil'][tix], axis=1)
         if record:
-            # rows of the dense history from the per-step snapshots (wake order -> TEV / LEV / FREE slots); on a step
-            # without LEV shedding the reference's zero-strength LEV slot lands at dt * (velocity at the origin)
-            P = self.path
-            fsl = slice(0, nf) if self._free_slot is None else self._free_slot
-            for r in range(cnt):
-                q, it, il = i + r, itev + r, int(levs_before[r])
-                xs, zs = hist[r, 0], hist[r, 1]
-                ts = tev_slot[:it + 1]
-                ls = lev_slot[:il + 1] if shed_v[r] else lev_slot[:il]
-                if self.history == 'full':
-                    P['TEV'][q, 0, :it + 1], P['TEV'][q, 1, :it + 1] = xs[ts], zs[ts]
-                    P['LEV'][q, 0, :len(ls)], P['LEV'][q, 1, :len(ls)] = xs[ls], zs[ls]
-                    if not shed_v[r]:
-                        P['LEV'][q, :, il] = self.dt * R[r, 10:12]
-                    P['FREE'][q, 0, :], P['FREE'][q, 1, :] = xs[fsl], zs[fsl]
-                elif self._record_row(q):
-                    # sparse history: the rows the per-step path would have stored (LEV row with the zero-strength slot)
-                    row_l = np.stack([xs[ls], zs[ls]])
-                    if not shed_v[r]:
-                        row_l = np.concatenate([row_l, (self.dt * R[r, 10:12])[:, None]], axis=1)
-                    P['TEV'].store(q, np.stack([xs[ts], zs[ts]]))
-                    P['LEV'].store(q, row_l)
-                    P['FREE'].store(q, np.stack([xs[fsl], zs[fsl]]))
+            self._store_marched_rows(S, i, cnt, R, hist, shed_v, levs_before)
         last_shed = bool(shed_v[-1])
         # as the per-step path leaves them: the counters before the last step's increment
         self.itev, self.ilev, self.LEV_shed = itev + cnt - 1, ilev + n_shed - int(last_shed), LEV_shed
         if last_shed:       # newest TEV at size - 2, newest LEV at size - 1
-            last_tev, last_lev = np.array([st[12], st[14]]), np.array([st[13], st[15]])
+            S.last_tev, S.last_lev = np.array([st[12], st[14]]), np.array([st[13], st[15]])
         else:
-            last_tev = np.array([st[13], st[15]])
-        return itev + cnt, ilev + n_shed, float(st[4]), float(st[5]), float(st[6]), last_tev, last_lev
+            S.last_tev = np.array([st[13], st[15]])
+        S.itev, S.ilev = itev + cnt, ilev + n_shed
+        S.lesp_crit, S.sum_tev, S.sum_lev = float(st[4]), float(st[5]), float(st[6])
+
+    def _store_marched_rows(self, S, i, cnt, R, hist, shed_v, levs_before):
+        """History rows from the march's per-step snapshots (wake order -> TEV / LEV / FREE slots); on a step without LEV
+        shedding the reference's zero-strength LEV slot lands at dt * (velocity at the origin)."""
+        P, tev_slot, lev_slot, fsl = self.path, S.tev_slot, S.lev_slot, S.fsl
+        for r in range(cnt):
+            q, it, il = i + r, S.itev + r, int(levs_before[r])
+            xs, zs = hist[r, 0], hist[r, 1]
+            ts = tev_slot[:it + 1]
+            ls = lev_slot[:il + 1] if shed_v[r] else lev_slot[:il]
+            if self.history == 'full':
+                P['TEV'][q, 0, :it + 1], P['TEV'][q, 1, :it + 1] = xs[ts], zs[ts]
+                P['LEV'][q, 0, :len(ls)], P['LEV'][q, 1, :len(ls)] = xs[ls], zs[ls]
+                if not shed_v[r]:
+                    P['LEV'][q, :, il] = self.dt * R[r, 10:12]
+                P['FREE'][q, 0, :], P['FREE'][q, 1, :] = xs[fsl], zs[fsl]
+            elif self._record_row(q):
+                # sparse history: the rows the per-step path would have stored (LEV row with the zero-strength slot)
+                row_l = np.stack([xs[ls], zs[ls]])
+                if not shed_v[r]:
+                    row_l = np.concatenate([row_l, (self.dt * R[r, 10:12])[:, None]], axis=1)
+                P['TEV'].store(q, np.stack([xs[ts], zs[ts]]))
+                P['LEV'].store(q, row_l)
+                P['FREE'].store(q, np.stack([xs[fsl], zs[fsl]]))
+
+    # ---- the per-step path: one device round trip, solve on the host --------------------------------------------------------
+    def _host_step(self, S, i, print_dt):
+        self._progress(i, print_dt)
+        n_wake = S.nf + S.itev + S.ilev
+        tev_xy, lev_xy, sums = self._chord_sums(S, i, n_wake)
+        g_tev, g_lev, shed, A = self._solve_circulations(S, i, sums)
+        dGamma = self._bound_vorticity_and_loads(S, i, sums, g_tev, g_lev, shed, A)
+        self._roll_up(S, i, n_wake, tev_xy, lev_xy, g_tev, g_lev, shed, dGamma)
+        S.sum_tev += g_tev
+        self.ilev, self.itev, self.LEV_shed = S.ilev, S.itev, S.LEV_shed
+        if shed:
+            S.sum_lev += g_lev
+            S.ilev += 1
+        S.itev += 1
+        if self.checkpoint_every and i % self.checkpoint_every == 0 and i < self.nt - 1:
+            self._write_checkpoint(S, i + 1)
+
+    def _chord_sums(self, S, i, n_wake):
+        """Existing wake -> chord (T1), unit new TEV -> chord (T2), unit candidate LEV -> chord (T3): one round trip
+        (:743-754, :924-934).  -> (tev_xy, lev_xy, (u1, w1, ut1, wt1, ul1, wl1)) in the global frame."""
+        eng, sb = self.engine, S.sb
+        xg, zg = S.gpts[i, 0, :], S.gpts[i, 1, :]
+        if S.have_next:
+            # placed on the device right after the previous roll-up, sums already here
+            tev_xy = np.array([sb.unit[0, 0], sb.unit[1, 0]])
+            lev_xy = np.array([sb.unit[0, 1], sb.unit[1, 1]])
+            return tev_xy, lev_xy, (sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1])
+        tev_xy, lev_xy = self._next_placement(S, i)
+        if sb is not None:
+            sb.unit[0, 0], sb.unit[0, 1], sb.unit[1, 0], sb.unit[1, 1] = tev_xy[0], lev_xy[0], tev_xy[1], lev_xy[1]
+            eng.wake_chord_sums_into(sb, n_wake, xg, zg, float(self.v_core))
+            return tev_xy, lev_xy, (sb.u, sb.w, sb.uu[0], sb.wu[0], sb.uu[1], sb.wu[1])
+        u1, w1, uu, wu = eng.wake_chord_sums(0, n_wake, xg, zg, [tev_xy[0], lev_xy[0]], [tev_xy[1], lev_xy[1]], self.v_core)
+        return tev_xy, lev_xy, (u1, w1, uu[0], wu[0], uu[1], wu[1])
+
+    def _solve_circulations(self, S, i, sums):
+        """Gamma_TEV from Kelvin's condition (:758-760, or Ramesh's Newton :683-739), the Fourier projection (:765-773), the
+        LESP test (:781) and, when it trips, Gamma_TEV / Gamma_LEV together (:944-954, :807-914).
+        -> (g_tev, g_lev, shed, A)."""
+        pi, U, c, dt = np.pi, self.Uinf, self.chord, self.dt
+        C, itev, ilev = self.circulation, S.itev, S.ilev
+        wq, cproj, cm1, detadx = self._wq, self._cproj, self._cm1, S.detadx
+        u1, w1, ut1, wt1, ul1, wl1 = sums
+        T1 = self._downwash_from(u1, w1, i)
+        ut, un = self._chord_frame(ut1, wt1, i)
+        T2 = detadx * ut - un
+        I1, I2 = T1 @ cm1, T2 @ cm1
+        kelvin = S.sum_tev + S.sum_lev + S.sum_free - C['IC']
+        if self.method == 'Ramesh':
+            g_tev = self._newton_tev(T1, T2, kelvin)                         # :683-739
+        elif self.method == 'Faure':
+            g_tev = -(I1 + kelvin) / (1 + I2)                                # :758-760
+        else:
+            raise ValueError("method must be 'Faure' or 'Ramesh'")
+        g_lev = 0.0
+        W = T1 + g_tev * T2
+        A = cproj @ (W / U)
+        C['bound'][itev] = I1 + g_tev * I2 if self.method == 'Faure' else U * c * pi * (A[0] + A[1] / 2)
+        self.fourier[i, 0, :] = A
+        self.fourier[i, 1, :] = (A - self.fourier[i - 1, 0, :]) / dt          # :772-773
+        self.LESP_prev[itev] = A[0]
+
+        shed = abs(A[0]) >= abs(S.lesp_crit)                                  # :781
+        if shed:
+            S.LEV_shed[i] = ilev
+            S.lesp_crit = -abs(S.lesp_crit) if A[0] < 0 else abs(S.lesp_crit)   # :802-805
+            ult, uln = self._chord_frame(ul1, wl1, i)
+            T3 = detadx * ult - uln
+            I3 = T3 @ cm1
+            J1, J2, J3 = (-1 / pi * (T @ wq) for T in (T1, T2, T3))
+            if self.method == 'Ramesh':
+                g_tev, g_lev = self._newton_tev_lev(T1, T2, T3, kelvin, S.lesp_crit, g_tev)   # :807-914
+            else:
+                g_tev, g_lev = np.linalg.solve(np.array([[1 + I2, 1 + I3], [J2, J3]]),
+                                               np.array([-(I1 + kelvin), S.lesp_crit - J1]))  # :944-954
+            W = T1 + g_tev * T2 + g_lev * T3
+            A = cproj @ (W / U)
+            if self.method == 'Faure':
+                C['bound'][itev] = I1 + g_tev * I2 + g_lev * I3
+                A[0] = J1 + g_tev * J2 + g_lev * J3                           # :959
+            else:
+                C['bound'][itev] = U * c * pi * (A[0] + A[1] / 2)
+            self.fourier[i, 0, :] = A       # derivatives keep their pre-LEV values (:963-966)
+            C['LEV'][ilev] = g_lev
+        C['TEV'][itev] = g_tev
+        self.LESP[itev] = A[0]
+        return g_tev, g_lev, shed, A
+
+    def _bound_vorticity_and_loads(self, S, i, sums, g_tev, g_lev, shed, A):
+        """Bound vorticity per panel (:987-1010) and the loads (:1035-1090).  The tangential velocity on the chord from the
+        full wake (incl. the new TEV/LEV with their solved circulations) follows by linearity from u1 and the unit
+        influences already evaluated: no further pair sum.  -> dGamma, the panel circulations."""
+        pi, U, c, rho = np.pi, self.Uinf, self.chord, self.rho
+        C, itev = self.circulation, S.itev
+        u1, w1, ut1, wt1, ul1, wl1 = sums
+        A0, A1, A2 = A[0], A[1], A[2]
+        A0d, A1d, A2d, A3d = self.fourier[i, 1, :4]
+        gamma = 2 * U * (A0 * S.one_plus_cos_over_sin + A[1:] @ self._ssin)
+        dGamma = gamma * S.half_c_sin_dth
+        C['airfoil'][itev], C['gamma_airfoil'][itev] = dGamma, gamma
+        C['Gamma_airfoil'][itev] = np.cumsum(dGamma)
+
+        uc1, wc1 = u1 + g_tev * ut1, w1 + g_tev * wt1
+        if shed:
+            uc1, wc1 = uc1 + g_lev * ul1, wc1 + g_lev * wl1
+        u, _ = self._chord_frame(uc1, wc1, i)
+        a, hd = self.alpha[i], self.h_dot[i]
+        Ueff = U * np.cos(a) + hd * np.sin(a)
+        self.Fn[i] = rho * pi * c * U * (Ueff * (A0 + 0.5 * A1) + c * (3 / 4 * A0d + 1 / 4 * A1d + 1 / 8 * A2d)) \
+            + rho * ((u * gamma) @ S.wx)
+        self.Fs[i] = rho * pi * c * U**2 * A0**2
+        self.L[i] = self.Fn[i] * np.cos(a) + self.Fs[i] * np.sin(a)
+        self.D[i] = self.Fn[i] * np.sin(a) - self.Fs[i] * np.cos(a)
+        self.T[i] = -self.D[i]
+        self.M[i] = self.piv * self.Fn[i] - rho * pi * c**2 * U * (
+            Ueff * (1 / 4 * A0 + 1 / 4 * A1 - 1 / 8 * A2)
+            + c * (7 / 16 * A0d + 3 / 16 * A1d + 1 / 16 * A2d - 1 / 64 * A3d)) \
+            - rho * ((u * gamma * S.x_gamma) @ S.wx)
+        return dGamma
+
+    def _roll_up(self, S, i, n_wake, tev_xy, lev_xy, g_tev, g_lev, shed, dGamma):
+        """Wake roll-up (:1095-1127): shed vortices join the resident wake, then one fused launch (wake + bound vortices ->
+        every wake vortex, explicit Euler update on the device); the history row of a recorded step."""
+        eng, sb, P, nt = self.engine, S.sb, self.path, self.nt
+        itev, ilev, tev_slot, lev_slot = S.itev, S.ilev, S.tev_slot, S.lev_slot
+        dt, vc = self.dt, self.v_core
+        xg, zg = S.gpts[i, 0, :], S.gpts[i, 1, :]
+        record = self._record_row(i)
+        new_x, new_z, new_g = [tev_xy[0]], [tev_xy[1]], [g_tev]
+        tev_slot[itev] = n_wake
+        if shed:
+            lev_slot[ilev] = n_wake + 1
+            new_x.append(lev_xy[0]); new_z.append(lev_xy[1]); new_g.append(g_lev)
+        elif record:
+            # the reference also convects LEV slot `ilev` (zero strength, at the origin) on a
+            # non-shedding step and stores it in path['LEV'][i]; reproduce that row entry
+            new_x.append(0.0); new_z.append(0.0); new_g.append(0.0)
+        n_after = n_wake + len(new_x)
+        one_trip = (not record) and sb is not None and i < nt - 1 and hasattr(eng, 'wake_step_into')
+        if not one_trip:
+            eng.wake_append(new_x, new_z, new_g)
+
+        if record:
+            S.have_next = False
+            eng.wake_advect(dt, xg, zg, dGamma, vc, precision=self.precision)
+            xs, zs = eng.wake_read(0, n_after)
+            row_t = np.stack([xs[tev_slot[:itev + 1]], zs[tev_slot[:itev + 1]]])
+            lslots = lev_slot[:ilev + 1] if shed else np.append(lev_slot[:ilev], n_after - 1)
+            row_l = np.stack([xs[lslots], zs[lslots]])
+            row_f = np.stack([xs[S.fsl], zs[S.fsl]])
+            if self.history == 'full':
+                P['TEV'][i, :, :itev + 1] = row_t
+                P['LEV'][i, :, :ilev + 1] = row_l
+                P['FREE'][i] = row_f
+            else:
+                P['TEV'].store(i, row_t)
+                P['LEV'].store(i, row_l)
+                P['FREE'].store(i, row_f)
+            S.last_tev = row_t[:, -1].copy()
+            if shed:
+                S.last_lev = row_l[:, -1].copy()
+            elif len(new_x) == 2:
+                eng.wake_truncate(n_after - 1)   # drop the phantom LEV slot
+            return
+        # only the newest TEV / LEV come back: they place the next ones (:680-681, :797-798)
+        k = 2 if shed else 1
+        S.have_next = False
+        dt_f, vc_f = float(dt), float(vc)
+        if one_trip:
+            # append of the shed vortices + roll-up of this step + placement and chord sums of the
+            # next one: one packed upload, one download
+            foil, gpts = S.foil, S.gpts
+            eng.wake_step_into(sb, np.array(new_x), np.array(new_z), np.array(new_g, dtype=float), dt_f, xg, zg,
+                               dGamma, vc_f, S.prec_code, np.ascontiguousarray(foil[i + 1, :, -1]),
+                               np.ascontiguousarray(foil[i + 1, :, 0]), shed, k, gpts[i + 1, 0, :],
+                               gpts[i + 1, 1, :])
+            xs, zs = sb.tail[0], sb.tail[1]
+            S.have_next = True
+        elif sb is not None:
+            eng.wake_advect_tail_into(sb, dt_f, xg, zg, dGamma, vc_f, k, S.prec_code)
+            xs, zs = sb.tail[0], sb.tail[1]
+        else:
+            xs, zs = eng.wake_advect_tail(dt, xg, zg, dGamma, vc, k, precision=self.precision)
+        S.last_tev = np.array([xs[0], zs[0]])
+        if shed:
+            S.last_lev = np.array([xs[1], zs[1]])
 
     # ------------------------------------------------------------------------------------------
     # checkpoint / resume (not in the reference; SURVEY 8(f)3)
     # ------------------------------------------------------------------------------------------
-    def _write_checkpoint(self, next_step, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
-                          tev_slot, lev_slot):
-        import json
-        import os
+    def _write_checkpoint(self, S, next_step):
         # one simulation shared by several ranks: every rank holds the same state, rank 0 alone writes it (they would race on
         # the temporary file), and nobody goes on before the file is in place
         sh = self._shard if (self._shard is not None and self._shard.world > 1) else None
         if sh is None:
-            return self._write_checkpoint_file(next_step, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
-                                               tev_slot, lev_slot)
+            return self._write_checkpoint_file(S, next_step)
         # The ranks meet in all_ok() -- the barrier -- and learn there whether the file is in place: if rank 0 could not
         # write it (disk full, bad path) everybody raises, instead of rank 0 raising alone and the others waiting for it in
         # a collective that has no timeout (ADVICE r3)
         err = None
         if sh.rank == 0:
             try:
-                self._write_checkpoint_file(next_step, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
-                                            tev_slot, lev_slot)
+                self._write_checkpoint_file(S, next_step)
             except Exception as e:          # noqa: BLE001  (re-raised below, on every rank)
                 err = e
         if not sh.all_ok(err is None):
@@ -827,11 +881,12 @@ class LUDVM:
                 raise err
             raise RuntimeError(f"rank 0 could not write the checkpoint {self.checkpoint_path}")
 
-    def _write_checkpoint_file(self, next_step, itev, ilev, lesp_crit, sum_tev, sum_lev, last_tev, last_lev, LEV_shed,
-                               tev_slot, lev_slot):
+    def _write_checkpoint_file(self, S, next_step):
         import json
         import os
         C, P = self.circulation, self.path
+        itev, ilev, lesp_crit, sum_tev, sum_lev = S.itev, S.ilev, S.lesp_crit, S.sum_tev, S.sum_lev
+        last_tev, last_lev, LEV_shed, tev_slot, lev_slot = S.last_tev, S.last_lev, S.LEV_shed, S.tev_slot, S.lev_slot
         n = self.engine.wake_size()
         wx, wz, wg = self.engine.wake_read(0, n, gamma=True)
         nan2 = np.full(2, np.nan)

@@ -433,13 +433,14 @@ def test_fp32_accuracy_does_not_depend_on_the_callers_order(eng, n, vc, route):
             err = max(np.abs(u[sel] - ur).max(), np.abs(w[sel] - wr).max()) / scale
             assert err < 1e-5, (n, sym, err)
         eng.set_symmetric(1)
-        # separate targets: 4096 of them (too sparse in any order: hi+lo) and 512 (fewer than 2048: float64)
+        # separate targets: 4096 of them (too sparse in any order: hi+lo) and 512 (fewer than 2048: float64, or hi+lo at 1e6 sources)
         big = rng.choice(n, 4096, replace=False)
         ub, wb = c_oracle.induced_velocity(g, x, z, x[big], z[big], vc)
         u, w = eng.induce(g, x, z, x[big].copy(), z[big].copy(), vc, precision="f32")
         assert max(np.abs(u - ub).max(), np.abs(w - wb).max()) / scale < 1e-5
         u, w = eng.induce(g, x, z, x[sel].copy(), z[sel].copy(), vc, precision="f32")
-        assert max(np.abs(u - ur).max(), np.abs(w - wr).max()) / scale < 1e-11
+        # 512 targets: float64 while the call is small as a whole (<= 2^28 pairs), hi+lo positions beyond (round 5)
+        assert max(np.abs(u - ur).max(), np.abs(w - wr).max()) / scale < (1e-11 if 512 * n <= 2**28 else 2e-6)
         # the resident wake keeps the caller's slots, so the caller stores the cloud in the order the engine names
         # (and picks hi+lo positions when even that order leaves the classes too wide for the core, as LUDVM.time_loop does)
         order, reordered, extent = eng.spatial_order(x, z, with_extent=True)
