@@ -164,6 +164,7 @@ def launch_ranks(n, argv, deadline_s):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(sys.argv[0]), *argv]
     env = dict(os.environ, LUDVM_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (this pool's hosts support dmabuf IPC only: RCCL across processes needs it)
     print(f"bench.py: --gpus {n} without a launcher: starting {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
 

@@ -562,20 +562,6 @@ finish_sum(const T* part, long long nt, long long nt_pad, int nsplit, T* u, T* w
   w[i] = sw;
 }
 
-// fp32 device SoA Euler step: x_out[i] = x[t_first + i] + dt * u_i  (LUDVM.py:1108-1109).
-// src_u/src_w are either the partial slabs (nsplit > 1) or the direct results (nsplit == 1,
-// nt_pad == stride between u and w rows is irrelevant then: pass part = u, and w separately).
-__global__ void __launch_bounds__(kBlock)
-finish_advect_f32(const float* part, long long nt, long long nt_pad, int nsplit, const float* x, const float* z,
-                  long long t_first, float dt, float* x_out, float* z_out) {
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= nt) return;
-  float su, sw;
-  sum_splits(part, i, nt_pad, nsplit, su, sw);
-  x_out[i] = __builtin_fmaf(dt, su, x[t_first + i]);
-  z_out[i] = __builtin_fmaf(dt, sw, z[t_first + i]);
-}
-
 // Split a float64 master position into the fp32 (hi, lo) pair the kernels read.
 __device__ __forceinline__ void split_hilo(double v, float& hi, float& lo) {
   hi = (float)v;
@@ -705,261 +691,6 @@ finish_wake_advect(const T* part, long long nt, long long nt_pad, int nsplit, do
   z64[i] = zn;
   store_mirrors(m, i, xn, zn, org[i & 1], org[2 + (i & 1)]);
   tail_duty(td, i, nt, xn, zn);
-}
-
-// Rebuild the fp32 mirrors of every origin block that intersects [first, first + count) from the float64
-// masters (after a host write): the block's two origins are re-taken (origin_index over the `stored` entries), so the
-// whole block is refreshed.  Entries of a touched block that lie beyond the stored range are computed from whatever
-// the master arrays hold there and are never read.  `limit` = allocated capacity.
-__global__ void __launch_bounds__(kBlock)
-refresh_mirrors(long long first, long long count, long long stored, long long limit, const double* x64, const double* z64,
-                const double* g64, Mirrors m, float* g32) {
-  const long long lo = (first >> kOriginShift) << kOriginShift;
-  const long long i = lo + (long long)blockIdx.x * kBlock + threadIdx.x;
-  long long hi = ((first + count + kOriginBlock - 1) >> kOriginShift) << kOriginShift;
-  if (hi > limit) hi = limit;
-  if (i >= hi) return;
-  const long long b = i >> kOriginShift;
-  const int p = (int)(i & 1);
-  const long long oi = origin_index(b, p, stored);
-  const float ox = (float)x64[oi], oz = (float)z64[oi];
-  if ((i & (kOriginBlock - 1)) < 2) { m.cx[2 * b + p] = ox; m.cz[2 * b + p] = oz; }      // the first thread of each class
-  store_mirrors(m, i, x64[i], z64[i], ox, oz);
-  g32[i] = (float)g64[i];
-}
-
-// float64 -> float32 staging conversion for the stateless host API.
-__global__ void __launch_bounds__(kBlock)
-cvt_f64_to_f32(const double* in, float* hi, float* lo, long long n) {
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  float h, l;
-  split_hilo(in[i], h, l);
-  hi[i] = h;
-  if (lo) lo[i] = l;
-}
-
-__global__ void __launch_bounds__(kBlock)
-cvt_f32_to_f64(const float* in, double* out, long long n) {
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) out[i] = (double)in[i];
-}
-
-// float64 -> local-origin fp32 for the stateless host API: off[i] = (float)(in[i] - org[origin_slot(i)]) with
-// org[2 b + p] = (float)in[origin_index(b, p, n)].  n is rounded up to whole blocks by the grid: the threads of a
-// class without a member still write its record (a number: the kernels read both records of every block they stage).
-__global__ void __launch_bounds__(kBlock)
-cvt_f64_to_local(const double* in, float* off, float* org, long long n) {
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  const long long b = i >> kOriginShift;
-  if ((b << kOriginShift) >= n) return;
-  const int p = (int)(i & 1);
-  const float o = (float)in[origin_index(b, p, n)];
-  if ((i & (kOriginBlock - 1)) < 2) org[2 * b + p] = o;
-  if (i < n) off[i] = (float)(in[i] - (double)o);
-}
-
-// Small stateless calls: the five float64 input arrays arrive in one packed upload, in = xs[ns] | zs[ns] | gs[ns] |
-// xt[nt] | zt[nt]; one launch splits them into the fp32 (hi, lo) arrays the kernels read.
-__global__ void __launch_bounds__(kBlock)
-cvt_packed_inputs(const double* in, long long ns, long long nt, float* xs, float* xsl, float* zs, float* zsl, float* gs,
-                  float* xt, float* xtl, float* zt, float* ztl) {
-  const long long k = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= 3 * ns + 2 * nt) return;
-  const double v = in[k];
-  float h, l;
-  split_hilo(v, h, l);
-  if (k < ns) { xs[k] = h; xsl[k] = l; }
-  else if (k < 2 * ns) { zs[k - ns] = h; zsl[k - ns] = l; }
-  else if (k < 3 * ns) { gs[k - 2 * ns] = h; }
-  else if (k < 3 * ns + nt) { xt[k - 3 * ns] = h; xtl[k - 3 * ns] = l; }
-  else { zt[k - 3 * ns - nt] = h; ztl[k - 3 * ns - nt] = l; }
-}
-
-// The same packed block as local-origin fp32: offsets from the origins of each array's own origin classes (256-element
-// block x index parity; origin = fp32 value of the class's middle element).  nt = 0 when the targets are the sources
-// themselves.
-__global__ void __launch_bounds__(kBlock)
-cvt_packed_inputs_local(const double* in, long long ns, long long nt, float* xs, float* zs, float* gs, float* sox, float* soz,
-                        float* xt, float* zt, float* tox, float* toz) {
-  const long long k = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= 3 * ns + 2 * nt) return;
-  const double v = in[k];
-  auto local = [&](long long base, long long i, long long len, float* off, float* org) {
-    const long long b = i >> kOriginShift;
-    const int p = (int)(i & 1);
-    // (a class whose middle member is not a number -- a NaN target poisons only itself in the reference's sum -- takes 0)
-    const float o_raw = (float)in[base + origin_index(b, p, len)];
-    const float o = __builtin_fabsf(o_raw) < __builtin_inff() ? o_raw : 0.0f;
-    if ((i & (kOriginBlock - 1)) < 2) org[2 * b + p] = o;
-    // (a block that holds a single element: its odd class has no member to write the record, which the kernels still read)
-    if ((i & (kOriginBlock - 1)) == 0 && i + 1 >= len) org[2 * b + 1] = o;
-    off[i] = (float)(v - (double)o);
-  };
-  if (k < ns) local(0, k, ns, xs, sox);
-  else if (k < 2 * ns) local(ns, k - ns, ns, zs, soz);
-  else if (k < 3 * ns) gs[k - 2 * ns] = (float)v;
-  else if (k < 3 * ns + nt) local(3 * ns, k - 3 * ns, nt, xt, tox);
-  else local(3 * ns + nt, k - 3 * ns - nt, nt, zt, toz);
-}
-
-// ... and the two fp32 results leave as one float64 block out = u[nt] | w[nt].
-__global__ void __launch_bounds__(kBlock)
-cvt_packed_outputs(const float* u, const float* w, double* out, long long nt) {
-  const long long k = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= 2 * nt) return;
-  out[k] = k < nt ? (double)u[k] : (double)w[k - nt];
-}
-
-// Velocity induced at nt points by n_unit unit-strength vortices (the new TEV / LEV of a time step,
-// LUDVM.py:751, :926, :931), fp64: out[(k*2 + 0)*nt + p] = u, out[(k*2 + 1)*nt + p] = w.
-__global__ void __launch_bounds__(kBlock)
-unit_influence_f64(const double* xt, const double* zt, long long nt, const double* ux, const double* uz, int n_unit,
-                   double vc4, double* out) {
-  const long long idx = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= nt * n_unit) return;
-  const long long k = idx / nt, p = idx - k * nt;
-  const double dx = xt[p] - ux[k];
-  const double dz = zt[p] - uz[k];
-  const double r2 = __builtin_fma(dz, dz, dx * dx);
-  const double s = kInv2PiD * rsqrt_f64(__builtin_fma(r2, r2, vc4));
-  out[(k * 2 + 0) * nt + p] = dz * s;
-  out[(k * 2 + 1) * nt + p] = -dx * s;
-}
-
-// One kernel stages everything a time step uploads: `n_new` shed vortices appended at wake index n0 and
-// `n_foil` bound vortices behind them (sources of the roll-up only), from one packed host->device copy
-// pack = [new_x | new_z | new_g | foil_x | foil_z | foil_g]; float64 masters and fp32 mirrors are written.
-// An origin class (block x index parity) whose first member lies inside the staged range takes its origin from the
-// vortex staged there (the other classes keep the origin the last Euler finisher gave them).
-__global__ void __launch_bounds__(kBlock)
-stage_step_inputs(const double* pack, long long n0, int n_new, int n_foil, double* x64, double* z64, double* g64, Mirrors m,
-                  float* g32) {
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k >= n_new + n_foil) return;
-  auto staged = [&](int q, double& x, double& z, double& g) {
-    const double* base = q < n_new ? pack : pack + 3 * n_new;
-    const int cnt = q < n_new ? n_new : n_foil;
-    const int j = q < n_new ? q : q - n_new;
-    x = base[j]; z = base[cnt + j]; g = base[2 * cnt + j];
-  };
-  double x, z, g;
-  staged(k, x, z, g);
-  const long long i = n0 + k;
-  const long long b = i >> kOriginShift, cs = (b << kOriginShift) + (i & 1), slot = origin_slot(i);   // cs: first member of i's class
-  float ox, oz;
-  if (cs >= n0) {
-    double bx, bz, bg;
-    staged((int)(cs - n0), bx, bz, bg);
-    ox = (float)bx; oz = (float)bz;
-    if (i == cs) { m.cx[slot] = ox; m.cz[slot] = oz; }
-    // a block opened by the last staged entry: give its still empty odd class a number too
-    if (i == cs && (i & 1) == 0 && k + 1 == n_new + n_foil) { m.cx[slot + 1] = ox; m.cz[slot + 1] = oz; }
-  } else {
-    ox = m.cx[slot]; oz = m.cz[slot];
-  }
-  x64[i] = x; z64[i] = z; g64[i] = g;
-  store_mirrors(m, i, x, z, ox, oz);
-  g32[i] = (float)g;
-}
-
-// One launch for the three small jobs that follow a time step's roll-up (ludvm_wake_step):
-//   (a) sum the fp64 wake->chord partial slabs                        -> out_sums[0 .. 2 nt)
-//   (b) report the newest `tail` wake vortices and place the next time step's TEV and candidate LEV from
-//       them (LUDVM.py:680-681, :797-800): one third of the way from the shedding edge to the newest TEV /
-//       LEV.  geo = [te_x, te_z, le_x, le_z]; the newest TEV is vortex n - tail, the newest LEV vortex
-//       n - 1 (when tail == 2 and lev_from_prev), else the candidate sits on the leading edge
-//                                                       -> out_head = [tail x | tail z | tev_x, lev_x, tev_z, lev_z]
-//   (c) velocities induced at the chord points by those two unit vortices (as unit_influence_f64)
-//                                                                     -> out_sums[2 nt .. 6 nt)
-// One WAVEFRONT per output column (k, p), k = 0: u / unit TEV, k = 1: w / unit LEV: lane l sums the
-// splits s = l, l + 64, ... and the 64 partials are combined by a fixed shuffle tree (deterministic;
-// a column of ~500 splits costs ~8 loads per lane instead of 500 dependent ones).  Lane 0 of the column
-// also evaluates (c); the placements are recomputed by whoever needs them (a handful of flops).
-// grid covers 2 * nt * 64 threads.
-__global__ void __launch_bounds__(kBlock)
-chord_finish_f64(const double* part, long long nt_pad, int nsplit, const double* direct_u, const double* xt, const double* zt,
-                 long long nt, const double* x64, const double* z64, long long n, int tail, int lev_from_prev,
-                 const double* geo, double vc4, double* out_head, double* out_sums) {
-  const long long gtid = (long long)blockIdx.x * kBlock + threadIdx.x;
-  const long long col = gtid >> 6;
-  const int lane = threadIdx.x & 63;
-  const double tex = geo[0], tez = geo[1], lex = geo[2], lez = geo[3];
-  const long long it = n - tail;
-  double ux[2], uz[2];
-  ux[0] = tex + (x64[it] - tex) / 3;
-  uz[0] = tez + (z64[it] - tez) / 3;
-  if (lev_from_prev && tail == 2) {
-    ux[1] = lex + (x64[n - 1] - lex) / 3;
-    uz[1] = lez + (z64[n - 1] - lez) / 3;
-  } else {
-    ux[1] = lex;
-    uz[1] = lez;
-  }
-  if (gtid == 0) {
-    for (int t = 0; t < tail; ++t) { out_head[t] = x64[n - tail + t]; out_head[tail + t] = z64[n - tail + t]; }
-    double* unit = out_head + 2 * tail;
-    unit[0] = ux[0]; unit[1] = ux[1]; unit[2] = uz[0]; unit[3] = uz[1];
-  }
-  if (col >= 2 * nt) return;   // whole wavefronts leave together
-  const long long k = col / nt, p = col - k * nt;
-  // (a) component k (0: u, 1: w) of the wake sum at chord point p
-  double acc = 0.0;
-  if (part != nullptr) {
-    const double* c0 = part + k * nt_pad + p;
-    for (int sidx = lane; sidx < nsplit; sidx += 64) acc += c0[(long long)sidx * 2 * nt_pad];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  } else if (nsplit == 1) {          // one split: the pair kernel wrote u | w directly
-    acc = direct_u[k * nt_pad + p];
-  }
-  if (lane != 0) return;
-  out_sums[k * nt + p] = acc;
-  // (c) unit vortex k at chord point p
-  const double dx = xt[p] - ux[k];
-  const double dz = zt[p] - uz[k];
-  const double r2 = __builtin_fma(dz, dz, dx * dx);
-  const double s = kInv2PiD * rsqrt_f64(__builtin_fma(r2, r2, vc4));
-  out_sums[2 * nt + (k * 2 + 0) * nt + p] = dz * s;
-  out_sums[2 * nt + (k * 2 + 1) * nt + p] = -dx * s;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Vorticity stencil of LUDVM.flowfield (LUDVM.py:1224-1292): ome = dw/dx - du/dz on the uniform
-// grid, centred in the interior, one-sided on edges and corners.  u, w, ome are [nx][nz], z fastest.
-// HBM-bound (reads ~4 neighbours from L2, writes one float).
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-vorticity_f32(const float* u, const float* w, long long nx, long long nz, float dr, float* ome) {
-  const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= nx * nz) return;
-  const long long i = p / nz, j = p - i * nz;
-  const long long ip = i + 1 < nx ? i + 1 : i, im = i > 0 ? i - 1 : i;
-  const long long jp = j + 1 < nz ? j + 1 : j, jm = j > 0 ? j - 1 : j;
-  // the reference takes dx, dz from the mesh itself: (ip - im) * dr, (jp - jm) * dr
-  const float dxm = (float)(ip - im) * dr;
-  const float dzm = (float)(jp - jm) * dr;
-  const float dw = w[ip * nz + j] - w[im * nz + j];
-  const float du = u[i * nz + jp] - u[i * nz + jm];
-  ome[p] = dw / dxm - du / dzm;
-}
-
-// The same stencil in float64 on rows [row0, row0 + nx) of the grid, with the mesh differences taken from the mesh
-// values themselves as the reference does (x[i+1, j] - x[i-1, j] with x = xmin + i dr, LUDVM.py:1193, :1228-1229): the
-// float64 flow field then equals the reference's to rounding.
-__global__ void __launch_bounds__(kBlock)
-vorticity_f64(const double* u, const double* w, long long nx, long long nz, long long row0, double xmin, double zmin, double dr,
-              double* ome) {
-  const long long p = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= nx * nz) return;
-  const long long i = p / nz, j = p - i * nz;
-  const long long ip = i + 1 < nx ? i + 1 : i, im = i > 0 ? i - 1 : i;
-  const long long jp = j + 1 < nz ? j + 1 : j, jm = j > 0 ? j - 1 : j;
-  const double dxm = (xmin + (double)(row0 + ip) * dr) - (xmin + (double)(row0 + im) * dr);
-  const double dzm = (zmin + (double)jp * dr) - (zmin + (double)jm * dr);
-  const double dw = w[ip * nz + j] - w[im * nz + j];
-  const double du = u[i * nz + jp] - u[i * nz + jm];
-  ome[p] = dw / dxm - du / dzm;
 }
 
 }  // namespace ludvm

@@ -263,12 +263,6 @@ __device__ __forceinline__ void fx_add(long long* acc, float v, float scale) {
   atomicAdd(reinterpret_cast<unsigned long long*>(acc), fx_units(v, scale));
 }
 
-// measurement / test probe (ludvm_fixed_point_probe): out[i] = the integer fx_add would add for v[i]
-__global__ void __launch_bounds__(kBlock) fx_probe(const float* v, long long n, float scale, long long* out) {
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) out[i] = (long long)fx_units(v[i], scale);
-}
-
 // lane l receives the value of lane l+1 (wrapping): data moves one lane down
 __device__ __forceinline__ float dpp_rol1(float v) {
   const int i = __builtin_bit_cast(int, v);
@@ -1137,26 +1131,6 @@ __device__ __forceinline__ double block_abs_sum(const float* g, long long first,
 // Fixed-point scale of a launch from sum |Gamma|.  Up to kPrepChunk vortices: one workgroup does it all.  Beyond:
 // gridDim.x workgroups each sum a contiguous chunk into partial[blockIdx.x] and sym_prepare_final adds those in order.
 constexpr long long kPrepChunk = 65536;
-__global__ void __launch_bounds__(kPrepBlock)
-sym_prepare(const float* g, long long n, double vc4, SymScale* out, long long* bad, double* partial) {
-  if (gridDim.x == 1) {
-    const double tot = block_abs_sum(g, 0, n);
-    if (threadIdx.x == 0) { *bad = 0; sym_scale_from_sum(tot, vc4, out, bad); }
-    return;
-  }
-  const long long first = (long long)blockIdx.x * kPrepChunk;
-  const long long cnt = n - first < kPrepChunk ? n - first : kPrepChunk;
-  const double tot = block_abs_sum(g, first, cnt);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-__global__ void __launch_bounds__(64)
-sym_prepare_final(const double* partial, int nparts, double vc4, SymScale* out, long long* bad) {
-  if (threadIdx.x != 0) return;
-  double tot = 0.0;
-  for (int k = 0; k < nparts; ++k) tot += partial[k];
-  *bad = 0;
-  sym_scale_from_sum(tot, vc4, out, bad);
-}
 
 // fixed-point raw sum -> fp32 raw sum (NaN when the launch met a non-finite partial sum)
 __device__ __forceinline__ float fx_read(const long long* acc, long long i, const SymScale* sc, bool bad) {
@@ -1165,28 +1139,6 @@ __device__ __forceinline__ float fx_read(const long long* acc, long long i, cons
 }
 __device__ __forceinline__ float fx_read(const long long* acc, long long i, const SymScale* sc, const long long* bad) {
   return fx_read(acc, i, sc, *bad != 0);
-}
-
-// acc -> velocities
-__global__ void __launch_bounds__(kBlock)
-finish_sym(const long long* acc_u, const long long* acc_w, const SymScale* sc, const long long* bad, long long n, float* u,
-           float* w) {
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const float s = (float)kInv2PiD;
-  u[i] = fx_read(acc_u, i, sc, bad) * s;
-  w[i] = -fx_read(acc_w, i, sc, bad) * s;
-}
-
-// raw sums of targets [t_first, t_first + nt) (sum_u[i], sum_w[i] belong to target t_first + i) -> Euler step
-__global__ void __launch_bounds__(kBlock)
-finish_sym_advect(const long long* sum_u, const long long* sum_w, const SymScale* sc, const long long* bad, const float* x,
-                  const float* z, long long t_first, long long nt, float dt, float* x_out, float* z_out) {
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= nt) return;
-  const float s = (float)kInv2PiD;
-  x_out[i] = __builtin_fmaf(dt, fx_read(sum_u, i, sc, bad) * s, x[t_first + i]);
-  z_out[i] = __builtin_fmaf(dt, -fx_read(sum_w, i, sc, bad) * s, z[t_first + i]);
 }
 
 // What `nsrc` extra sources staged in the float64 master arrays at [first, first + nsrc) -- the bound vortices of a
@@ -1232,38 +1184,6 @@ __device__ __forceinline__ void staged_sources_on(bool on, double xi, double zi,
       }
     }
   }
-}
-
-// Resident-wake Euler step from the symmetric kernel's raw sums, plus the velocity induced by the nfoil bound
-// vortices staged behind the wake at index nt: float64 update of the master copy, refresh of the fp32 mirrors
-// (LUDVM.py:1108-1127).  One workgroup = one origin block (see finish_wake_advect).
-__global__ void __launch_bounds__(kFinBlock)
-finish_wake_advect_sym(const long long* acc_u, const long long* acc_w, const SymScale* sc, const long long* bad, long long nt,
-                       int nfoil, float vc4, double dt, double* x64, double* z64, Mirrors m, const float* g32, double* u_out,
-                       double* w_out, const long long* n_dev = nullptr, TailDuty td = TailDuty{}) {
-  __shared__ float org[4];
-  if (n_dev) nt = *n_dev;          // device-resident march: the wake size lives on the device
-  tail_duty_block0(td, nt);
-  const long long i = (long long)blockIdx.x * kFinBlock + threadIdx.x;
-  const bool on = i < nt;
-  const double xo = on ? x64[i] : 0.0, zo = on ? z64[i] : 0.0;
-  float fu, fw;
-  staged_sources_on(on, xo, zo, x64, z64, g32, nt, nfoil, vc4, fu, fw);
-  double xn = 0.0, zn = 0.0;
-  if (on) {
-    const float s = (float)kInv2PiD;
-    const float su = (fx_read(acc_u, i, sc, bad) + fu) * s, sw = -(fx_read(acc_w, i, sc, bad) + fw) * s;
-    if (u_out) { u_out[i] = (double)su; w_out[i] = (double)sw; }
-    xn = xo + dt * (double)su;
-    zn = zo + dt * (double)sw;
-    publish_origins(m, i, nt, xn, zn, org);
-  }
-  __syncthreads();
-  if (!on) return;
-  x64[i] = xn;
-  z64[i] = zn;
-  store_mirrors(m, i, xn, zn, org[i & 1], org[2 + (i & 1)]);
-  tail_duty(td, i, nt, xn, zn);
 }
 
 }  // namespace ludvm

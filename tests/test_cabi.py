@@ -49,11 +49,15 @@ def test_production_library_reads_no_experiment_switch():
     exp_lib = _ffi.load(_ffi.EXP_LIB_PATH)
     assert exp_lib.ludvm_abi_version() == _ffi.ABI_VERSION
     # the source reads the environment through the one macro (plus the two production variables)
-    src = open(os.path.join(ROOT, "ludvm_amd", "csrc", "ludvm_hip.hip")).read()
-    direct = re.findall(r'std::getenv\("(\w+)"\)', src)
+    import glob
+    csrc = os.path.join(ROOT, "ludvm_amd", "csrc")
+    units = sorted(glob.glob(os.path.join(csrc, "*.hip")))
+    assert len(units) == 9          # context, launch, comm, order, induce, wake, march, flowfield + spatial_order (ctx.hpp)
+    direct = [v for u in units for v in re.findall(r'std::getenv\("(\w+)"\)', open(u).read())]
     assert sorted(direct) == ["LUDVM_COMM_FORCE", "LUDVM_RCCL_LIB"], direct
-    for hdr in ("pair_kernels.hpp", "pair_sym_kernels.hpp", "march_kernels.hpp"):
-        assert "getenv" not in open(os.path.join(ROOT, "ludvm_amd", "csrc", hdr)).read(), hdr
+    for hdr in glob.glob(os.path.join(csrc, "*.hpp")):
+        text = open(hdr).read()
+        assert "getenv" not in text.replace("#define LUDVM_EXP_ENV(name) std::getenv(name)", ""), hdr
 
 
 def test_every_entry_point_cites_the_reference():
@@ -147,7 +151,7 @@ def test_inline_asm_keeps_clear_of_the_transcendental_hazard(tmp_path):
     the compiler's hazard pass does not look inside inline assembly (pair_sym_kernels.hpp, pk_mul_sel): check the ISA."""
     import re
     import subprocess
-    src = os.path.join(ROOT, "ludvm_amd", "csrc", "ludvm_hip.hip")
+    src = os.path.join(ROOT, "ludvm_amd", "csrc", "launch.hip")          # (the unit that instantiates every pair kernel)
     out = tmp_path / "ludvm.s"
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
                     "--cuda-device-only", "-S", "-o", str(out), src], check=True, capture_output=True)
@@ -171,7 +175,7 @@ def test_hot_kernels_do_not_spill():
     registers with spills inside its rotation loop: profiles/r02_packed_targets_ab.txt.)"""
     import re
     import subprocess
-    src = os.path.join(ROOT, "ludvm_amd", "csrc", "ludvm_hip.hip")
+    src = os.path.join(ROOT, "ludvm_amd", "csrc", "launch.hip")          # (the unit that instantiates every pair kernel)
     out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
                           "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", src, "-o", os.devnull],
                          check=True, capture_output=True, text=True).stderr
@@ -195,3 +199,39 @@ def test_hot_kernels_do_not_spill():
     assert len(t8) == 4        # mixed granularity (default), and 1, 2, 4 waves per work item
     for name, r in t8.items():
         assert int(r["VGPRs"]) <= 168 and int(r["Occupancy [waves/SIMD]"]) >= 3, (name, r)
+
+
+def test_library_exports_the_c_abi_and_nothing_else():
+    """The library is several translation units (ctx.hpp lists them) built with -fvisibility=hidden: the functions the units
+    offer each other (launch_pair, wake_grow, reduce_accumulators ...) must not leak into the dynamic symbol table -- every
+    exported FUNCTION is an entry point include/ludvm_hip.h declares.  (Kernel handles are data objects.)"""
+    import subprocess
+    for lib in (_ffi.LIB_PATH, _ffi.EXP_LIB_PATH):
+        out = subprocess.run(["nm", "-D", "--defined-only", lib], check=True, capture_output=True, text=True).stdout
+        # strong definitions (weak ones are inline instantiations of the standard library and the context's destructor)
+        funcs = {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T"}
+        extra = funcs - _declared_symbols() - {"_init", "_fini"}
+        assert not extra, sorted(extra)[:10]
+        assert _declared_symbols() <= funcs
+
+
+def test_every_non_template_kernel_header_belongs_to_one_unit():
+    """A non-template __global__ function defined in a header that two units include would be defined twice.  Templates and
+    device helpers live in pair_kernels.hpp / pair_sym_kernels.hpp (includable anywhere, no plain kernel inside); each of the
+    other kernel headers is included by exactly one .hip file."""
+    import glob
+    csrc = os.path.join(ROOT, "ludvm_amd", "csrc")
+    units = {os.path.basename(u): open(u).read() for u in glob.glob(os.path.join(csrc, "*.hip"))}
+    owners = {"sym_prepare_kernels.hpp": "launch.hip", "induce_kernels.hpp": "induce.hip", "wake_kernels.hpp": "wake.hip",
+              "march_kernels.hpp": "march.hip", "field_kernels.hpp": "flowfield.hip", "order_kernels.hpp": "order.hip"}
+    for hdr, owner in owners.items():
+        users = sorted(u for u, text in units.items() if f'#include "{hdr}"' in text)
+        assert users == [owner], (hdr, users)
+        assert f'#include "{hdr}"' not in open(os.path.join(csrc, "ctx.hpp")).read()
+    for shared in ("pair_kernels.hpp", "pair_sym_kernels.hpp", "march_types.hpp"):
+        text = open(os.path.join(csrc, shared)).read()
+        # every kernel in a shared header is a template (its __global__ line is preceded by a template line)
+        lines = text.splitlines()
+        for i, l in enumerate(lines):
+            if l.startswith("__global__"):
+                assert lines[i - 1].startswith("template"), (shared, i + 1, l)

@@ -1,5 +1,5 @@
 """CPU tier: DESIGN.md section 5's per-kernel roofline table is recomputable from the committed rocprofv3 summaries
-(tools/roofline_table.py over profiles/r04_*), and the figures the docs quote follow from those files."""
+(tools/roofline_table.py over profiles/r05_*; r04_* for round 4's), and the figures the docs quote follow from those files."""
 import os
 import subprocess
 import sys
@@ -7,13 +7,19 @@ import sys
 from conftest import ROOT
 
 
-def test_roofline_table_recomputes_from_profiles():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), "r04"], capture_output=True, text=True,
+def _table(rnd):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), rnd], capture_output=True, text=True,
                        timeout=120)
     assert p.returncode == 0, p.stderr[-2000:]
     rows = [l for l in p.stdout.splitlines() if l.startswith("| `")]
-    assert len(rows) == 5, p.stdout
-    cells = [[c.strip() for c in r.strip("|").split("|")] for r in rows]
+    return [[c.strip() for c in r.strip("|").split("|")] for r in rows], p.stdout
+
+
+def test_roofline_table_recomputes_from_profiles():
+    """Round 5's table: configs 3 / 4 / 5 as before, and config 2's rows from config 2's OWN full run (no
+    proxy) -- one row per variant of the symmetric kernel the 50 000 steps went through."""
+    cells, out = _table("r05")
+    assert len(cells) == 7, out
     by = {c[0].split("`")[1]: c for c in cells}
     quad = by["pair_sym_quad_f32<8>"]
     direct = by["pair_f32<2, 1024, false, 0, false>"]
@@ -23,11 +29,40 @@ def test_roofline_table_recomputes_from_profiles():
     assert 0.70 < frac(quad) < 0.80 and 0.45 < frac(direct) < 0.54 and 0.62 < frac(patch) < 0.703
     for c in cells:
         assert float(c[4]) <= frac(c) + 1e-9 and frac(c) > 0.40, c
-        assert 0.6 < float(c[7]) <= 1.0, c                 # measured time never beats the issue model
-        assert c[8] == "0", c                              # no LDS bank conflict in any pair kernel (round 4)
+        assert 0.5 < float(c[7]) <= 1.0, c                 # measured time never beats the issue model
+        assert c[8] == "0", c                              # no LDS bank conflict in any pair kernel
+        assert c[10].startswith("`r05_"), c                # every row names the files (and thereby the box) it comes from
+    for c in (quad, direct, patch):
         assert 1.0 <= float(c[5].split("(")[1].split("x")[0]) < 1.2, c      # VALU instructions within 20 % of the model
     # the direct kernel's distance from its 54 % ceiling is the held clock: >= 95 % of the issue model
     assert float(direct[7]) > 0.95
+    # config 2: the rows ARE the run -- their kernels are the symmetric kernels of the full run's statistics file, their
+    # launches add up to the steps the symmetric kernel served, the step ranges are contiguous and end at step 50 000
+    import csv
+    import re
+    cfg2 = [c for c in cells if "config 2, steps" in c[0]]
+    assert [c[0].split("`")[1] for c in cfg2] == ["pair_sym_f32<4, false, 4, true>", "pair_sym_f32<4, false, 0, true>",
+                                                  "pair_sym_f32<8, false, 4, true>", "pair_sym_f32<8, false, 0, true>"]
+    with open(os.path.join(ROOT, "profiles", "r05_config2_kernel_stats.csv")) as f:
+        stats = {r["Name"]: (int(r["Calls"]), float(r["AverageNs"]), float(r["Percentage"])) for r in csv.DictReader(f)}
+    sym = {k: v for k, v in stats.items() if "pair_sym_f32<" in k}
+    assert len(sym) == 4 and sum(v[2] for v in sym.values()) > 60.0          # > 60 % of the run's kernel time
+    prev_end = None
+    for c in cfg2:
+        name = c[0].split("`")[1]
+        calls, avg_ns, _ = next(v for k, v in sym.items() if name + "(" in k)
+        a, b = (int(v) for v in re.search(r"steps (\d+)-(\d+)", c[0]).groups())
+        assert b - a + 1 == calls and (prev_end is None or a == prev_end + 1)
+        assert abs(float(c[2].split()[0]) - avg_ns * 1e-6) < 1e-3            # the row's duration IS the full run's
+        prev_end = b
+    assert prev_end == 50000
+    # the T = 8 tile takes over at 34 816 vortices (launch.hip, kSymT8MinN), whatever the proxy once showed
+    assert abs(int(re.search(r"wake (\d+)-", cfg2[2][0]).group(1)) - 34816) < 1500
+
+
+def test_round_4_table_still_recomputes():
+    cells, out = _table("r04")
+    assert len(cells) == 5, out
 
 
 def test_bench_break_even_table_is_the_committed_measurement():

@@ -8,8 +8,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def resources(extra=()):
-    src = os.path.join(ROOT, "ludvm_amd", "csrc", "ludvm_hip.hip")
+def resources(extra=(), unit="launch.hip"):
+    """unit: launch.hip instantiates every pair kernel; wake.hip / march.hip / induce.hip / flowfield.hip / order.hip hold the
+    O(N) kernels of their parts of the ABI."""
+    src = os.path.join(ROOT, "ludvm_amd", "csrc", unit)
     out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
                           "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", src, "-o", os.devnull, *extra],
                          check=True, capture_output=True, text=True).stderr
