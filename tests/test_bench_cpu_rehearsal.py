@@ -46,12 +46,13 @@ def test_self_launched_ranks_rehearse_config4(ranks, n):
     assert d["repeat_values"] == [] and "cpu_baseline" not in d and "config4_one_gpu" not in d
     assert_self_checking_config4(d, ranks, min_value=1e6)
     assert_sweep(d, ranks, ["torch"])
-    if n == 17000:          # the same wake on any number of ranks: the same bits (integer sums commute)
-        # (what two ranks print for the same arguments; both variants)
-        assert d["result_check"]["symmetric"]["checksum"] == ["fffffb8c6fee2a8d", "fffdd2ba91f6f04d", "fffffb9313f5814e",
-                                                              "fffdddf94821cdaf"]
-        assert d["result_check"]["direct"]["checksum"] == ["fffffb8bf2a7d803", "fffdd2756d2f2786", "fffffb93145d3055",
-                                                           "fffdddf98180aa11"]
+    # the same wake on any number of ranks: the same bits (integer sums commute) -- what two ranks print for the same arguments
+    p2, lines2 = _run(RIG, "--gpus", "2", "--vortices", str(n), "--steps", "1", "--warmup", "0", "--repeats", "0", "--other-variant", "0",
+                      "--sweep", "0")
+    assert p2.returncode == 0 and len(lines2) == 1, p2.stderr[-3000:]
+    d2 = json.loads(lines2[0])
+    assert d2["config"]["ranks"] == 2 and "collective_sweep_us" not in d2 and "direct_variant" not in d2
+    assert d2["result_check"]["symmetric"]["checksum"] == d["result_check"]["symmetric"]["checksum"]
 
 
 def test_self_launch_relays_the_deadline_line():
