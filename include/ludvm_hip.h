@@ -200,7 +200,12 @@ int ludvm_induce_dev_f32(ludvm_ctx* ctx, const float* d_xs, const float* d_zs, c
 int ludvm_advect_dev_f32(ludvm_ctx* ctx, const float* d_xs, const float* d_zs, const float* d_gs, size_t ns,
                          size_t t_first, size_t nt, float vcore, float dt, float* d_x_out, float* d_z_out);
 
-/* Multi-GPU building blocks of the symmetric roll-up (ludvm_amd/sharded.py).  Vortices are cut into
+/* Multi-GPU building blocks of the symmetric roll-up (ludvm_amd/sharded.py: BASELINE config 4, bench.py's N > 1 line).
+ * Reading the benchmark across GPU counts: bench.py's `value` at N = 1 is config 3 (N = 1e6, one ludvm_induce_dev_f32 call per
+ * step); at N > 1 it is config 4 (N = 8e6, these entry points + one collective per step).  The same-work denominator of
+ * "8 GPUs vs 1" is the N = 1 line's `config4_one_gpu.value` (config 4's step on one GPU), which every N > 1 line names in
+ * `scaling_denominator` -- not the N = 1 line's `value`.
+ * Vortices are cut into
  * tiles of LUDVM_SYM_TILE; the caller owns tiles [tile_first, tile_first + tile_count) of the
  * ceil(n / LUDVM_SYM_TILE) tiles.
  *   ludvm_sym_scale_dev_f32 derives the fixed-point scale of the raw sums from sum|Gamma| / v_core (summed in a

@@ -25,7 +25,10 @@ import numpy as np
 #       262 144        4   MB        3843 / 5897 / 6930 us
 # The collective's own time over xGMI is NOT yet measured (no multi-GPU box has been available to this build): 131 072 leaves
 # it a 10-30x margin over the tens of microseconds RCCL usually needs at that size; 65 536 would leave 3-8x.  Both are
-# constructor arguments of ShardGroup / LibraryGroup.
+# constructor arguments of ShardGroup / LibraryGroup.  The first `bench.py --gpus N` run on a multi-GPU node measures it:
+# its JSON line carries `collective_sweep_us` (the int64 all-reduce at exactly the sizes tabulated above, and the all-gather of
+# induced_velocity's blocks) and `min_wake_suggested` (the smallest tabulated wake whose all-reduce costs less than half of
+# what the split saves) -- set MIN_WAKE from that key.
 MIN_TARGETS = 65536
 MIN_WAKE = 131072
 

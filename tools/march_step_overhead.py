@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""What a marched time step costs beyond its symmetric pair kernel, at a given wake size (GPU box).  A cloud of `nf` weak
-free vortices behind the foil stands for an old wake; `steps` steps of config 2's dt are marched (sparse history, fp32) and
-timed as a whole; the pair kernel's own time comes from HIP events around it (ludvm_kernel_timing) in a second, equal run.
+"""What a marched time step costs beyond its symmetric pair kernel, at a given wake size (GPU box).  A SHEET of `nf` weak
+free vortices behind the foil, stored in order along itself, stands for an old wake (round 5: rounds 3-4 used a random cloud,
+which the order-independent fp32 tier of round 4 turned into another case -- too sparse for its core, hi+lo positions, other
+kernels than a shed wake takes); `steps` steps of config 2's dt are marched (sparse history, fp32) and timed as a whole; the pair
+kernel's own time comes from HIP events around it (ludvm_kernel_timing) in a second, equal run.  NOT the source of DESIGN.md's
+config-2 roofline rows any more: those come from config 2's own run (tools/r05_profile_batch.sh, tools/roofline_table.py).
     python tools/march_step_overhead.py [nf ...]        STEPS=600"""
 import json
 import os
@@ -19,7 +22,8 @@ dt = 1e-3
 eng = Engine(0)
 for nf in [int(a) for a in sys.argv[1:]] or [20000, 32768, 49152, 65536]:
     rng = np.random.default_rng(5)
-    xy = np.stack([rng.uniform(2.0, 12.0, nf), rng.uniform(-1.5, 1.5, nf)])
+    sline = np.linspace(0.0, 1.0, nf)
+    xy = np.stack([2.0 + 48.0 * sline, 0.5 * np.sin(40.0 * sline)])          # 48 chords of wavy sheet, in shedding order
     gam = rng.standard_normal(nf) * 1e-4
     kw = dict(t0=0, tf=(steps - 0.5) * dt, dt=dt, verbose=False, engine=eng, precision="f32", history="sparse",
               circulation_freevort=gam, xy_freevort=xy)
