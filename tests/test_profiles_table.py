@@ -81,3 +81,21 @@ def test_bench_break_even_table_is_the_committed_measurement():
         assert rows[n]["allreduce_bytes"] == 16 * n
         for g, us in by_g.items():
             assert rows[n][f"G{g}_saved_us"] == us, (n, g)
+
+
+def test_bench_traffic_constants_are_the_committed_counter_passes():
+    """bench.py's roofline.traffic (HBM-side bytes per launch of the dominant kernel at config 3) is a constant looked up by
+    kernel: 2 x FETCH_SIZE + WRITE_SIZE (KB) of the counter passes the entry names, summed over the kernels of one launch."""
+    import csv
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def kb(prefix, which, counter, kernels):
+        with open(os.path.join(ROOT, f"{prefix}_pmc_{which}.csv")) as f:
+            return sum(float(r["mean_per_dispatch"]) for r in csv.DictReader(f)
+                       if r["counter"] == counter and any(k in r["kernel"] for k in kernels))
+    for name, rec in bench.PMC_TRAFFIC_CFG3.items():
+        prefix = rec["source"].split("_pmc_")[0]
+        kernels = ("pair_sym_quad_f32<8>", "pair_sym_f32<8, false, 1, false>") if "quad" in name else ("pair_f32<2, 1024, false, 0, false>",)
+        want = (2 * kb(prefix, "fetch", "FETCH_SIZE", kernels) + kb(prefix, "write", "WRITE_SIZE", kernels)) * 1024
+        assert abs(rec["bytes"] - want) / want < 1e-4, (name, rec["bytes"], want)
