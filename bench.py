@@ -166,7 +166,16 @@ def launch_ranks(n, argv, deadline_s):
     env = dict(os.environ, LUDVM_BENCH_SELF_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (this pool's hosts support dmabuf IPC only: RCCL across processes needs it)
     print(f"bench.py: --gpus {n} without a launcher: starting {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
-    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+
+    def die_with_parent():
+        # a harness that ends THIS process with SIGKILL (no handler runs) must not leave eight ranks on the GPUs: the launcher
+        # gets SIGTERM when its parent dies and takes its ranks down (Linux prctl PR_SET_PDEATHSIG = 1)
+        try:
+            import ctypes
+            ctypes.CDLL(None).prctl(1, int(signal.SIGTERM), 0, 0, 0)
+        except Exception:       # noqa: BLE001
+            pass
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, preexec_fn=die_with_parent)
 
     def end_group(sig=signal.SIGTERM):
         try:

@@ -29,8 +29,11 @@ import numpy as np
 # its JSON line carries `collective_sweep_us` (the int64 all-reduce at exactly the sizes tabulated above, and the all-gather of
 # induced_velocity's blocks) and `min_wake_suggested` (the smallest tabulated wake whose all-reduce costs less than half of
 # what the split saves) -- set MIN_WAKE from that key.
-MIN_TARGETS = 65536
-MIN_WAKE = 131072
+# LUDVM_MIN_WAKE / LUDVM_MIN_TARGETS (environment) override the defaults for a whole launch -- e.g. with the bench line's
+# `min_wake_suggested` -- without touching code: they move the size from which a step is split, never a result bit (the sharded
+# roll-up's integer sums equal the one-GPU sums; every rank must see the same values, as with any launcher variable).
+MIN_TARGETS = int(os.environ.get("LUDVM_MIN_TARGETS", "") or 65536)
+MIN_WAKE = int(os.environ.get("LUDVM_MIN_WAKE", "") or 131072)
 
 
 def _env_int(*names, default=None):

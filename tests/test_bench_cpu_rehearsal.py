@@ -92,3 +92,41 @@ def test_bench_itself_has_no_cpu_path():
     assert p.returncode == 2 and lines == [] and "no GPU visible" in p.stderr
     p, lines = _run(bench, "--gpus", "2", "--vortices", "20000")
     assert p.returncode != 0 and lines == [] and "no GPU visible" in p.stderr
+
+
+def test_ranks_do_not_outlive_a_killed_parent():
+    """A harness that ends `python bench.py --gpus N` with SIGKILL must not leave ranks behind on the GPUs: the launcher the
+    parent started gets SIGTERM when its parent dies (PR_SET_PDEATHSIG) and takes its ranks down."""
+    import signal
+    p = subprocess.Popen([sys.executable, RIG, "--gpus", "2", "--vortices", "16384", "--steps", "1", "--warmup", "0", "--deadline-s", "120"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=_env(LUDVM_BENCH_TEST_HANG="1"))
+
+    def descendants(pid):
+        out = subprocess.run(["ps", "-e", "-o", "pid=,ppid=,args="], capture_output=True, text=True).stdout
+        rows = [l.split(None, 2) for l in out.splitlines() if len(l.split(None, 2)) == 3]
+        kids, frontier = [], {str(pid)}
+        while frontier:
+            nxt = {r[0] for r in rows if r[1] in frontier}
+            kids += [r for r in rows if r[1] in frontier]
+            frontier = nxt
+        return kids
+    try:
+        t0 = time.time()
+        while time.time() - t0 < 60:                     # until the two ranks exist (they hang on purpose after their region)
+            ranks = [r for r in descendants(p.pid) if "bench_cpu_rig.py" in r[2] and "torch.distributed.run" not in r[2]]
+            if len(ranks) >= 2:
+                break
+            time.sleep(0.5)
+        assert len(ranks) >= 2, descendants(p.pid)
+        pids = [int(r[0]) for r in descendants(p.pid)]
+        p.send_signal(signal.SIGKILL)
+        p.wait(10)
+        t0 = time.time()
+        alive = pids
+        while alive and time.time() - t0 < 45:
+            time.sleep(0.5)
+            alive = [q for q in pids if os.path.exists(f"/proc/{q}") and "Z" not in open(f"/proc/{q}/stat").read().split(")")[1].split()[0]]
+        assert not alive, alive
+    finally:
+        if p.poll() is None:
+            p.kill()

@@ -105,6 +105,18 @@ def test_a_faster_rank_does_not_take_the_identifier_of_an_earlier_launch(tmp_pat
     assert comm.exchange_id(0, lambda: fresh, path) == fresh and comm.exchange_id(1, None, path, timeout=5) == fresh
 
 
+def test_thresholds_can_be_set_for_a_launch_from_the_environment():
+    """`min_wake_suggested` of a bench line applied without editing code: LUDVM_MIN_WAKE / LUDVM_MIN_TARGETS, read at import."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = "from ludvm_amd import comm; print(comm.MIN_WAKE, comm.MIN_TARGETS)"
+    env = {k: v for k, v in os.environ.items() if k not in ("LUDVM_MIN_WAKE", "LUDVM_MIN_TARGETS")}
+    run = lambda e: subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, cwd=ROOT, timeout=120).stdout.split()   # noqa: E731
+    assert run(env) == ["131072", "65536"]
+    assert run(dict(env, LUDVM_MIN_WAKE="65536", LUDVM_MIN_TARGETS="")) == ["65536", "65536"]
+
+
 class _OneRankEngine:
     """Stand-in for Engine's communicator calls with a group of one."""
 
