@@ -164,6 +164,8 @@ def launch_ranks(n, argv, deadline_s):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(sys.argv[0]), *argv]
     env = dict(os.environ, LUDVM_BENCH_SELF_LAUNCHED="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):          # (the launcher sets them per rank)
+        env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (this pool's hosts support dmabuf IPC only: RCCL across processes needs it)
     print(f"bench.py: --gpus {n} without a launcher: starting {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
 
@@ -906,7 +908,8 @@ def main(argv=None, rig_factory=HipRig):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
     t_process = time.perf_counter()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+    no_launcher = "RANK" not in os.environ and os.environ.get("WORLD_SIZE", "1") in ("", "1")     # (a bare WORLD_SIZE=1 some shells
+    if args.gpus > 1 and no_launcher:                                                          #  export is no launcher either)
         # no launcher: be one (before torch is imported or the GPU touched in any way; a child process, never an exec)
         sys.exit(launch_ranks(args.gpus, argv, args.deadline_s))
 

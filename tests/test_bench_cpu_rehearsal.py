@@ -80,6 +80,10 @@ def test_deadline_before_anything_was_measured_is_an_error():
 def test_launcher_world_that_contradicts_gpus_is_refused():
     p, lines = _run(RIG, "--gpus", "4", env=dict(_env(), WORLD_SIZE="2", RANK="0"))
     assert p.returncode == 2 and lines == [] and "WORLD_SIZE is 2" in p.stderr
+    # ... while a bare WORLD_SIZE=1 that some shell exports is no launcher: the ranks are started all the same
+    p, lines = _run(RIG, "--gpus", "2", "--vortices", "16384", "--steps", "1", "--warmup", "0", "--repeats", "0", "--other-variant", "0",
+                    "--sweep", "0", "--check", "0", env=dict(_env(), WORLD_SIZE="1"))
+    assert p.returncode == 0 and len(lines) == 1 and json.loads(lines[0])["config"]["ranks"] == 2, p.stderr[-2000:]
 
 
 def test_bench_itself_has_no_cpu_path():
