@@ -1,5 +1,5 @@
 // O(N) helpers around the spatial order (spatial_order.hpp): how compact are the origin classes of an array in a given
-// order, and the gathers / scatters that apply an order.  See ludvm_hip.hip, spatial_order_if_needed.
+// order, and the gathers / scatters that apply an order.  See order.hip, spatial_order_if_needed (the only unit that includes this header).
 #pragma once
 #include "pair_kernels.hpp"
 

@@ -506,7 +506,7 @@ def test_flowfield_over_an_unordered_cloud_keeps_1e5(eng, vc, tol):
     """LUDVM.flowfield over a turbulence cloud (sources in no order).  v_core = 0.01: the host entry takes the sources in
     Morton order (the sum over sources does not care), the float64 grid points are referred to compact source classes.
     v_core = 1.3e-3: 2e5 sources in a 10 x 4 box are too sparse for that core in ANY order (mean class extent ~600 v_core;
-    ludvm_hip.hip, too_sparse) and the grid kernels have no hi+lo variant: the rows are evaluated in float64 and
+    ctx.hpp, too_sparse) and the grid kernels have no hi+lo variant: the rows are evaluated in float64 and
     returned as float32."""
     x, z, g = _cloud(200_000, seed=9)
     xmin, zmin, dr, nx, nz = -55.3, -0.2, 0.004, 48, 64

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Calibration of the sparse rule (ludvm_hip.hip, too_sparse: 150 v_core for a reordered cloud, 300 for a set compact as given) [GPU box; uses the oracle as the checker]: fp32 on
+"""Calibration of the sparse rule (ctx.hpp, too_sparse: 150 v_core for a reordered cloud, 300 for a set compact as given) [GPU box; uses the oracle as the checker]: fp32 on
 local origins in Morton order -- through the resident wake, which has no hi+lo fallback of its own -- for clouds of several
 densities and cores: max error on 512 sampled targets / their max|u| against (mean class extent) / v_core.
     python tests/tools/extent_rule_calibration.py"""
