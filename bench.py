@@ -951,6 +951,12 @@ def main(argv=None, rig_factory=HipRig):
         R.dist.barrier()
         R.dist.destroy_process_group()
     R.rep.finish()
+    if R.world > 1:
+        # the line is out and both communicators are down: leave without the interpreter's shutdown (library destructors at
+        # exit are the one place left where a rank could hang unwatched, and a launcher waits for its slowest rank)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
