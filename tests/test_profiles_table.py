@@ -99,3 +99,20 @@ def test_bench_traffic_constants_are_the_committed_counter_passes():
         kernels = ("pair_sym_quad_f32<8>", "pair_sym_f32<8, false, 1, false>") if "quad" in name else ("pair_f32<2, 1024, false, 0, false>",)
         want = (2 * kb(prefix, "fetch", "FETCH_SIZE", kernels) + kb(prefix, "write", "WRITE_SIZE", kernels)) * 1024
         assert abs(rec["bytes"] - want) / want < 1e-4, (name, rec["bytes"], want)
+
+
+def test_scaling_table_divides_by_the_same_work_figure():
+    """tools/scaling_table.py on committed lines (the N = 1 line of the profiled box and the two-gloo-rank rehearsal on one card):
+    the speed-up of an N > 1 line is taken against the N = 1 line's config4_one_gpu.value, not against its `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import json
+    import scaling_table
+    one = scaling_table.load(os.path.join(ROOT, "profiles", "r05_bench_cfg3_sym_bench.json"))
+    two = scaling_table.load(os.path.join(ROOT, "profiles", "r05_bench_two_gloo_ranks_full_size.json"))
+    rows = scaling_table.table(one + two)
+    assert [r["n_gpus"] for r in rows] == [1, 2] and rows[0]["workload"] == "config 3" and rows[1]["workload"] == "config 4"
+    base = one[0]["config4_one_gpu"]["value"]
+    assert rows[1]["speedup_vs_config4_one_gpu"] == two[0]["value"] / base != two[0]["value"] / one[0]["value"]
+    assert abs(rows[1]["efficiency"] - 0.5) < 0.05          # two ranks SHARING one card: the rehearsal, as it must, scales by 1.0
+    assert rows[1]["symmetric_check"]["ranks_agree"] is True and rows[1]["min_wake_suggested"] == two[0]["min_wake_suggested"]
+    assert "config4_one_gpu.value" in two[0]["scaling_denominator"]
