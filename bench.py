@@ -578,7 +578,7 @@ class Run:
 
     # ---- the JSON line, from what is known once the reported timed region is over (later phases add to it) ----------------
     def make_out(self, repeats, extra, cfg4_rec):
-        from ludvm_amd.comm import MIN_TARGETS, MIN_WAKE
+        from ludvm_amd.comm import MIN_PAIRS, MIN_TARGETS, MIN_WAKE
         args, M, n, world = self.args, self.M, self.n, self.world
         elapsed, kernel_ms, launches = M["elapsed"], M["kernel_ms"], M["launches"]
         pairs_per_step, pairs_per_launch = M["pairs_per_step"], M["pairs_per_launch"]
@@ -621,7 +621,7 @@ class Run:
                        # thresholds of the CLASS-level sharding (LUDVM(distributed=...): time_loop / induced_velocity), not
                        # used by this workload; what the collectives cost at those sizes on THIS machine is
                        # `collective_sweep_us` (N > 1 lines), and `min_wake_suggested` what follows for min_wake
-                       "class_sharding_thresholds": {"min_wake": MIN_WAKE, "min_targets": MIN_TARGETS}},
+                       "class_sharding_thresholds": {"min_wake": MIN_WAKE, "min_targets": MIN_TARGETS, "min_pairs": MIN_PAIRS}},
             "roofline": {
                 # per the metric's definition: algorithmic FLOPs -- 13 per ordered pair -- over the
                 # dominant kernel's own time.  The symmetric kernel EXECUTES 9 per ordered pair (it shares dx, dz, r^2,

@@ -29,10 +29,16 @@ import numpy as np
 # its JSON line carries `collective_sweep_us` (the int64 all-reduce at exactly the sizes tabulated above, and the all-gather of
 # induced_velocity's blocks) and `min_wake_suggested` (the smallest tabulated wake whose all-reduce costs less than half of
 # what the split saves) -- set MIN_WAKE from that key.
-# LUDVM_MIN_WAKE / LUDVM_MIN_TARGETS (environment) override the defaults for a whole launch -- e.g. with the bench line's
-# `min_wake_suggested` -- without touching code: they move the size from which a step is split, never a result bit (the sharded
-# roll-up's integer sums equal the one-GPU sums; every rank must see the same values, as with any launcher variable).
+# An induced_velocity call is split over the ranks when it has at least MIN_TARGETS targets AND at least MIN_PAIRS pairs: the
+# (u, w) blocks come back through one all-gather plus host staging (a few hundred microseconds), which 65 536 targets against
+# the 80 bound vortices (5e6 pairs: a microsecond of kernel) can never repay; 2^30 pairs are ~0.2 ms of one GPU's direct kernel.
+# LUDVM_MIN_WAKE / LUDVM_MIN_TARGETS / LUDVM_MIN_PAIRS (environment) override the defaults for a whole launch -- e.g. with the
+# bench line's `min_wake_suggested` -- without touching code; every rank must see the same values, as with any launcher
+# variable.  MIN_WAKE never moves a result bit (the sharded roll-up's integer sums equal the one-GPU sums); a split
+# induced_velocity call agrees with the unsplit one within the precision's tolerance, not bit for bit (the partition of a launch
+# into partial sums follows its target count).
 MIN_TARGETS = int(os.environ.get("LUDVM_MIN_TARGETS", "") or 65536)
+MIN_PAIRS = int(os.environ.get("LUDVM_MIN_PAIRS", "") or 2**30)
 MIN_WAKE = int(os.environ.get("LUDVM_MIN_WAKE", "") or 131072)
 
 
@@ -162,12 +168,12 @@ class LibraryGroup:
                           # order, so the count names the file (a rank must not pick up the identifier of the previous group)
 
     def __init__(self, engine, rank=None, world=None, rendezvous=None, unique_id=None, min_targets=MIN_TARGETS, min_wake=MIN_WAKE,
-                 timeout=600.0):
+                 timeout=600.0, min_pairs=MIN_PAIRS):
         r, w, _ = launcher_rank()
         self.engine = engine
         self.rank = r if rank is None else int(rank)
         self.world = w if world is None else int(world)
-        self.min_targets, self.min_wake = int(min_targets), int(min_wake)
+        self.min_targets, self.min_wake, self.min_pairs = int(min_targets), int(min_wake), int(min_pairs)
         self._path = None
         if unique_id is None:
             if rendezvous is None:

@@ -8,7 +8,7 @@ One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm
                            internally); one all-gather of the finished (u, w, omega) rows per requested time step, so
                            that every rank ends up with the reference's full u_ff / w_ff / ome_ff arrays.
   LUDVM.induced_velocity   targets in contiguous blocks (sources replicated: every rank was handed them), one all-gather
-    (LUDVM.py:549-570)     of the (u, w) blocks; calls with fewer than `min_targets` targets stay on the calling GPU.
+    (LUDVM.py:549-570)     of the (u, w) blocks; calls with fewer than `min_targets` targets or `min_pairs` pairs stay on the calling GPU.
   LUDVM.time_loop          every rank holds the whole wake and runs the whole loop, but evaluates only its tile block of
     (LUDVM.py:1095-1127)   the symmetric roll-up kernel's unordered pairs; ONE integer all-reduce of the fixed-point sums
                            per time step (ludvm_set_shard), from `min_wake` vortices on.  Integer sums commute: every
@@ -21,13 +21,13 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .comm import MIN_TARGETS, MIN_WAKE
+from .comm import MIN_PAIRS, MIN_TARGETS, MIN_WAKE
 
 
 class ShardGroup:
     """The ranks that share one simulation (a torch.distributed process group; None = the default group)."""
 
-    def __init__(self, group=None, device=None, min_targets=MIN_TARGETS, min_wake=MIN_WAKE):
+    def __init__(self, group=None, device=None, min_targets=MIN_TARGETS, min_wake=MIN_WAKE, min_pairs=MIN_PAIRS):
         if not dist.is_initialized():
             raise RuntimeError("LUDVM(distributed=...) needs torch.distributed to be initialised (one process per GPU, "
                                "e.g. torchrun; backend 'nccl' = RCCL)")
@@ -38,7 +38,7 @@ class ShardGroup:
         # RCCL moves device tensors; gloo (CPU tests, one-GPU rehearsals) host tensors
         self.device = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
                                                          if self.backend == "nccl" else torch.device("cpu"))
-        self.min_targets, self.min_wake = int(min_targets), int(min_wake)
+        self.min_targets, self.min_wake, self.min_pairs = int(min_targets), int(min_wake), int(min_pairs)
         self._acc = None
 
     # ---- blocks ------------------------------------------------------------------------------------------------

@@ -311,8 +311,9 @@ class LUDVM:
         in, two new float64 arrays out; evaluated on the GPU in `self.precision`."""
         v_core = self.v_core if viscous == True else 0  # noqa: E712  (the reference's comparison, :562)
         sh = self._shard
-        if sh is not None and sh.world > 1 and len(xp) >= sh.min_targets:
-            # targets in contiguous blocks over the ranks (sources replicated), one all-gather of the (u, w) blocks
+        if sh is not None and sh.world > 1 and len(xp) >= sh.min_targets and len(xp) * len(xw) >= getattr(sh, 'min_pairs', 0):
+            # targets in contiguous blocks over the ranks (sources replicated), one all-gather of the (u, w) blocks -- for calls
+            # large enough to repay it (many targets AND enough pairs: comm.py, MIN_TARGETS / MIN_PAIRS)
             xt, zt = np.asarray(xp, dtype=float).reshape(-1), np.asarray(zp, dtype=float).reshape(-1)
             lo, hi, _ = sh.block(len(xt))
             ul, wl = self.engine.induce(circulation, xw, zw, xt[lo:hi], zt[lo:hi], v_core, precision=self.precision)

@@ -9,7 +9,7 @@ def assert_self_checking_config4(d, ranks, main="symmetric", collectives_issued=
     c = d["config"]
     assert len(c["pair_kernel_ms_per_rank"]) == ranks and len(c["collective_ms_per_rank"]) == ranks
     assert c["pair_kernel_ms_max_over_mean"] >= 1.0
-    assert c["class_sharding_thresholds"] == {"min_wake": 131072, "min_targets": 65536}
+    assert c["class_sharding_thresholds"] == {"min_wake": 131072, "min_targets": 65536, "min_pairs": 2**30}
     other = "direct" if main == "symmetric" else "symmetric"
     for name, reported in ((main, True), (other, False)):
         v = d[name + "_variant"]

@@ -29,7 +29,7 @@ def _worker(rank, world, port, out):
         from ludvm_amd import LUDVM
         from ludvm_amd.distributed import ShardGroup
         kw = dict(CONFIG1, tf=3)
-        sg = ShardGroup(min_targets=50)
+        sg = ShardGroup(min_targets=50, min_pairs=0)
         assert (sg.world, sg.rank, sg.backend) == (world, rank, "gloo")
         sim = LUDVM(**kw, verbose=False, engine=FakeEngine(), precision="f64", distributed=sg)
         one = LUDVM(**kw, verbose=False, engine=FakeEngine(), precision="f64")
@@ -51,6 +51,16 @@ def _worker(rank, world, port, out):
             u, w = sim.induced_velocity(g, xw, zw, xp, zp)
             ur, wr = one.induced_velocity(g, xw, zw, xp, zp)
             assert u.shape == (nt,) and np.array_equal(u, ur) and np.array_equal(w, wr)
+        # ... and many targets against few sources stay local too: min_pairs (default 2^30) -- the gather is never issued
+        few = ShardGroup(min_targets=50)
+        assert few.min_pairs == 2**30
+        simf = LUDVM(**dict(kw, tf=0.2), verbose=False, engine=FakeEngine(), precision="f64", distributed=few)
+        calls = []
+        few.gather_blocks = lambda *a, **k: calls.append(a) or (_ for _ in ()).throw(AssertionError("split a call of 1.2e5 pairs"))
+        xp, zp = rng.uniform(-3, 0, 601), rng.uniform(-1, 1, 601)
+        u, w = simf.induced_velocity(g, xw, zw, xp, zp)
+        ur, wr = one.induced_velocity(g, xw, zw, xp, zp)
+        assert not calls and np.array_equal(u, ur) and np.array_equal(w, wr)
         if rank == 0:
             np.save(out, sim.u_ff)
     finally:

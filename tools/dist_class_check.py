@@ -24,7 +24,13 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ludvm_amd import LUDVM, Engine  # noqa: E402
-from ludvm_amd.distributed import ShardGroup  # noqa: E402
+from ludvm_amd.distributed import ShardGroup as _TorchShardGroup  # noqa: E402
+
+
+def ShardGroup(min_targets, min_wake):        # noqa: N802  (the checks run at small sizes: no lower bound on the pairs of a split call)
+    return _TorchShardGroup(min_targets=min_targets, min_wake=min_wake, min_pairs=0)
+
+
 
 backend = os.environ.get("LUDVM_DIST_BACKEND", "nccl")
 library = os.environ.get("LUDVM_DIST_COLLECTIVES", "torch") == "library"
@@ -37,7 +43,7 @@ if library:
     backend = "library"
 
     def ShardGroup(min_targets, min_wake):        # noqa: N802  (same call below; bound to the engine of the moment)
-        return LibraryGroup(eng, min_targets=min_targets, min_wake=min_wake)
+        return LibraryGroup(eng, min_targets=min_targets, min_wake=min_wake, min_pairs=0)
 elif backend == "nccl":
     dist.init_process_group(backend="nccl", device_id=dev)
 else:
