@@ -401,6 +401,12 @@ class LUDVM:
     class _Loop:
         """Scalars carried from step to step (counters, Kelvin sums, the newest shed vortices, the slot maps of the resident
         wake) and the constant tables of a run."""
+        __slots__ = (
+            # constants of the run
+            'nf', 'x_gamma', 'detadx', 'gpts', 'foil', 'one_plus_cos_over_sin', 'half_c_sin_dth', 'wx', 'sum_free', 'first_step',
+            'fslot', 'fsl', 'sb', 'prec_code', 'can_march', 'dense_march', 'march_chunk',
+            # carried from step to step
+            'itev', 'ilev', 'lesp_crit', 'sum_tev', 'sum_lev', 'last_tev', 'last_lev', 'LEV_shed', 'tev_slot', 'lev_slot', 'have_next')
 
     def _loop_begin(self):
         """Result arrays (LUDVM.py:615-641), projection tables, the device wake with the free vortices in it."""
