@@ -505,6 +505,16 @@ class Run:
         # one-GPU box); the single-rank workload and its code path are unchanged
         self.force_dist = self.world == 1 and os.environ.get("LUDVM_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
         if self.world > 1 or self.force_dist:
+            if self.backend == "nccl" and rig.name == "hip":
+                # RCCL ranks cannot share a card: say so before the process group is built (LUDVM_BENCH_BACKEND=gloo rehearses
+                # several ranks on one card).  One visible device per rank is fine: the launcher isolated the cards.
+                ndev, local_world = torch.cuda.device_count(), int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
+                if 1 < ndev < local_world or (ndev == 1 and local_world > 1 and "ROCR_VISIBLE_DEVICES" not in os.environ
+                                              and "HIP_VISIBLE_DEVICES" not in os.environ and "CUDA_VISIBLE_DEVICES" not in os.environ):
+                    if self.rank == 0:
+                        print(f"bench.py: --gpus {self.world} on the nccl (RCCL) backend needs one GPU per rank; {ndev} visible "
+                              f"for {local_world} local ranks", file=sys.stderr)
+                    sys.exit(2)
             if self.backend == "nccl":
                 dist.init_process_group(backend="nccl", device_id=self.device)
             else:

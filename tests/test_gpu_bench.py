@@ -349,3 +349,13 @@ def test_bench_leaves_a_communicator_alone_that_joined_late():
     assert "did not return within 3 s" in d["config"]["collective_note"] and "torch.distributed" in d["config"]["collective"]
     assert "incomplete" not in d and d["value"] > 1e11
     _assert_self_checking_config4(d, 1, collectives_issued=False)
+
+
+def test_rccl_ranks_that_would_share_a_card_are_refused_with_a_message():
+    """`python bench.py --gpus 2` on a ONE-GPU box, default (nccl = RCCL) backend: two ranks cannot share a card -- each rank says
+    so and exits 2 before any process group is built (no hang, no RCCL error trace), no line is printed."""
+    import torch
+    if torch.cuda.device_count() != 1 or any(k in os.environ for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        pytest.skip("needs a one-GPU box whose card was not selected through *_VISIBLE_DEVICES (one device per rank then means isolation)")
+    p, lines = _self_launch(2, {}, "--vortices", "120000", "--steps", "2", "--warmup", "1", timeout=200)
+    assert p.returncode != 0 and lines == [] and "needs one GPU per rank; 1 visible for 2 local ranks" in p.stderr
