@@ -157,6 +157,14 @@ def launch_ranks(n, argv, deadline_s):
     import signal
     import socket
     import subprocess
+    if os.environ.get("LUDVM_BENCH_BACKEND", "nccl") == "nccl":
+        # every rank will inherit THIS environment: a *_VISIBLE_DEVICES list shorter than N means RCCL ranks sharing a card
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            listed = [d for d in os.environ.get(var, "").split(",") if d.strip()]
+            if listed and len(listed) < n:
+                print(f"bench.py: --gpus {n} on the nccl (RCCL) backend needs one GPU per rank; {var}={os.environ[var]} shows "
+                      f"{len(listed)} (LUDVM_BENCH_BACKEND=gloo rehearses several ranks on one card)", file=sys.stderr)
+                return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

@@ -134,3 +134,12 @@ def test_ranks_do_not_outlive_a_killed_parent():
     finally:
         if p.poll() is None:
             p.kill()
+
+
+def test_a_visible_devices_list_shorter_than_the_ranks_is_refused_before_anything_starts():
+    """bench.py (the product's, nccl backend) with --gpus 4 and HIP_VISIBLE_DEVICES=0: every rank would inherit the one card.
+    The parent refuses at once -- no launcher, no torch import."""
+    t0 = time.time()
+    p, lines = _run(os.path.join(ROOT, "bench.py"), "--gpus", "4", env=_env(HIP_VISIBLE_DEVICES="0"))
+    assert p.returncode == 2 and lines == [] and "needs one GPU per rank; HIP_VISIBLE_DEVICES=0 shows 1" in p.stderr
+    assert "torch.distributed.run" not in p.stderr and time.time() - t0 < 10

@@ -352,10 +352,13 @@ def test_bench_leaves_a_communicator_alone_that_joined_late():
 
 
 def test_rccl_ranks_that_would_share_a_card_are_refused_with_a_message():
-    """`python bench.py --gpus 2` on a ONE-GPU box, default (nccl = RCCL) backend: two ranks cannot share a card -- each rank says
-    so and exits 2 before any process group is built (no hang, no RCCL error trace), no line is printed."""
+    """`python bench.py --gpus 2` on a ONE-GPU box, default (nccl = RCCL) backend: two ranks cannot share a card.  Refused with
+    exit 2 and a message -- by the parent when a *_VISIBLE_DEVICES list (which every rank would inherit) is shorter than N, by
+    each rank before any process group is built otherwise; no hang, no RCCL error trace, no line."""
     import torch
-    if torch.cuda.device_count() != 1 or any(k in os.environ for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
-        pytest.skip("needs a one-GPU box whose card was not selected through *_VISIBLE_DEVICES (one device per rank then means isolation)")
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a one-GPU box")
+    t0 = __import__("time").time()
     p, lines = _self_launch(2, {}, "--vortices", "120000", "--steps", "2", "--warmup", "1", timeout=200)
-    assert p.returncode != 0 and lines == [] and "needs one GPU per rank; 1 visible for 2 local ranks" in p.stderr
+    assert p.returncode != 0 and lines == [] and "needs one GPU per rank" in p.stderr, p.stderr[-2000:]
+    assert __import__("time").time() - t0 < 120
