@@ -419,8 +419,14 @@ def join_library_communicator(eng, rank, world, rig, backend, dist, timeout_s=90
                 return
             chk = torch.arange(1, 9, dtype=torch.int64, device=device) * (rank + 1)
             rig.sync()
+            # the proof runs on a stream of its own: should the ranks ever disagree at the edge of the timeout (some abandon the
+            # communicator, some issue this all-reduce), the kernel that waits for its peers must not sit on the stream the
+            # measurement runs on
+            side = torch.cuda.Stream(device=device)
+            eng.set_stream(side.cuda_stream)
             eng.comm_allreduce_i64_dev(chk.data_ptr(), chk.numel())
-            rig.sync()
+            side.synchronize()
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
             want = torch.arange(1, 9, dtype=torch.int64) * (world * (world + 1) // 2)
             if torch.equal(chk.cpu(), want):
                 res.update(ok=1, why="")
