@@ -48,6 +48,8 @@ def test_bench_json_contract(symmetric):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "pairs/s" and c["value"] > 1e6
     assert c["gpu_vs_oracle_max_rel_err"] < 1e-5
+    a = c["all_cores"]                      # the same sample by the C restatement on every core: reported beside, never instead
+    assert "error" not in a and a["cores"] >= 1 and a["value"] > 1e6 and a["vs_numpy_max_rel_diff"] < 1e-12
 
 
 def test_bench_config4_shape_on_one_gpu():
