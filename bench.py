@@ -160,6 +160,13 @@ def cpu_baseline(x, z, g, rows, budget_s):
     return rec, u[:done], w[:done]
 
 
+def multi_process_gpu_environment(env=os.environ):
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 unless the caller chose a value (ludvm_amd.comm.prepare_ipc_environment: where the
+    default comes from and why it must precede the first HIP call).  Imported lazily: ludvm_amd/comm.py imports no GPU code."""
+    from ludvm_amd.comm import prepare_ipc_environment
+    return prepare_ipc_environment(env, force=True)
+
+
 # ======================================================================================================================
 # --gpus N without a launcher: start the ranks as a child process
 # ======================================================================================================================
@@ -190,7 +197,7 @@ def launch_ranks(n, argv, deadline_s):
     env = dict(os.environ, LUDVM_BENCH_SELF_LAUNCHED="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):          # (the launcher sets them per rank)
         env.pop(k, None)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (this pool's hosts support dmabuf IPC only: RCCL across processes needs it)
+    multi_process_gpu_environment(env)                      # (the ranks set it again themselves: ludvm_amd/comm.py has the why)
     print(f"bench.py: --gpus {n} without a launcher: starting {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
 
     def die_with_parent():
@@ -279,6 +286,14 @@ class HipRig:
 
     def bind_thread(self):
         self.torch.cuda.set_device(self.dev_index)            # (the current device is per thread)
+
+    # Two places where a TEST rig can make the run misbehave on purpose (tests/bench_hang_rig.py, tests/bench_cpu_rig.py: a
+    # phase that never ends, a communicator join that never returns or returns late).  The machine itself does nothing here.
+    def at_milestone(self, reporter, phase):
+        pass
+
+    def at_comm_join(self, stage, timeout_s):
+        pass
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -419,17 +434,13 @@ def join_library_communicator(eng, rank, world, rig, backend, dist, timeout_s=90
     # torch (one rank falling back alone would leave the others inside a collective)
     res = {"ok": 0, "why": f"ludvm_comm_init did not return within {timeout_s:.0f} s"}
     abandoned = threading.Event()
-    hook = os.environ.get("LUDVM_BENCH_TEST_HANG_COMM", "")      # test hooks: "1" a join that never returns; "late" one that
-                                                                 # returns after the timeout
 
     def join():
         try:
             rig.bind_thread()
-            while hook == "1":
-                time.sleep(1.0)
+            rig.at_comm_join("before", timeout_s)
             eng.comm_init(rank, world, uid[0], min_vortices=1 << 62)
-            if hook == "late":
-                time.sleep(timeout_s + 2.0)
+            rig.at_comm_join("after", timeout_s)
             if abandoned.is_set():                      # the run has moved on without this communicator: touch nothing
                 res.update(ok=0, why="joined after the timeout; left alone", late=True)
                 return
@@ -440,9 +451,15 @@ def join_library_communicator(eng, rank, world, rig, backend, dist, timeout_s=90
             # measurement runs on
             side = torch.cuda.Stream(device=device)
             eng.set_stream(side.cuda_stream)
-            eng.comm_allreduce_i64_dev(chk.data_ptr(), chk.numel())
-            side.synchronize()
-            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            try:
+                rig.at_comm_join("proof", timeout_s)
+                eng.comm_allreduce_i64_dev(chk.data_ptr(), chk.numel())
+                side.synchronize()
+            finally:
+                # whatever the proof did -- an RCCL error on this first collective is what the fallback below exists for -- the
+                # engine goes back to the stream the run measures on (unless the run has already moved on to a fresh engine)
+                if not abandoned.is_set():
+                    eng.set_stream(torch.cuda.current_stream().cuda_stream)
             want = torch.arange(1, 9, dtype=torch.int64) * (world * (world + 1) // 2)
             if torch.equal(chk.cpu(), want):
                 res.update(ok=1, why="")
@@ -523,6 +540,8 @@ class Run:
             if self.rank == 0:
                 print(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {self.world}", file=sys.stderr)
             sys.exit(2)
+        if self.world > 1:
+            multi_process_gpu_environment()       # before torch is imported and before the first HIP call of this process
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -648,6 +667,8 @@ class Run:
             "config": {"workload": M["desc"], "collective_backend": self.backend if world > 1 else None,
                        "ranks": self.dist.get_world_size() if dist_on else 1, "collective": M["collective"],
                        "collective_note": M["coll_note"],
+                       # the IPC mode the ranks' HSA runtimes were started with (N > 1: ludvm_amd/comm.py::prepare_ipc_environment)
+                       "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "launched_by": ("bench.py itself (python bench.py --gpus N: a child torch.distributed.run)"
                                        if os.environ.get("LUDVM_BENCH_SELF_LAUNCHED") == "1" else
                                        ("a launcher (RANK / WORLD_SIZE in the environment)" if "WORLD_SIZE" in os.environ else "python")),
@@ -706,10 +727,7 @@ class Run:
             self.rep.line = self.make_out(list(repeats), extra or {}, cfg4_rec)
         self.rep.published = True
         self.rep.phase = phase
-        if os.environ.get("LUDVM_BENCH_TEST_HANG") == "1":       # test hook: a phase that never ends (tests/test_gpu_bench.py)
-            self.rep.phase = phase + " [test hook: hung on purpose]"
-            while True:
-                time.sleep(1.0)
+        self.rig.at_milestone(self.rep, phase)
 
 
 # ======================================================================================================================

@@ -7,10 +7,14 @@
 The package holds only what the hot path needs: csrc/ (HIP kernels + the C ABI of
 include/ludvm_hip.h), the ctypes binding, and the host-side mirror of the reference class.
 """
-from ._ffi import LudvmHipError  # noqa: F401
-from .engine import Engine  # noqa: F401
-from .ludvm import LUDVM, SparseHistory  # noqa: F401
-from .freevort import (generate_free_vortices, generate_free_single_vortex, generate_flowfield_vortices,  # noqa: F401
+from .comm import prepare_ipc_environment as _prepare_ipc_environment
+
+_prepare_ipc_environment()      # (a launcher announced several ranks: the IPC mode RCCL needs, before any HIP call -- comm.py)
+
+from ._ffi import LudvmHipError  # noqa: F401,E402
+from .engine import Engine  # noqa: F401,E402
+from .ludvm import LUDVM, SparseHistory  # noqa: F401,E402
+from .freevort import (generate_free_vortices, generate_free_single_vortex, generate_flowfield_vortices,  # noqa: F401,E402
                        generate_flowfield_turbulence)
 
 __version__ = "0.1.0"

@@ -42,6 +42,28 @@ MIN_PAIRS = int(os.environ.get("LUDVM_MIN_PAIRS", "") or 2**30)
 MIN_WAKE = int(os.environ.get("LUDVM_MIN_WAKE", "") or 131072)
 
 
+# HSA_ENABLE_IPC_MODE_LEGACY.  Where the default comes from: the description of this build's GPU pool (the ROCm 7.2 image
+# notes every build round is given; the variable is exported as 0 in the build container and on the GPU boxes): "the host
+# driver only supports dmabuf IPC, and without it RCCL / CUDA-tensor sharing across processes fails with `hipIpcGetMemHandle:
+# invalid argument`".  RCCL's intra-node transport maps the peers' buffers through HIP IPC handles, so a process-per-GPU launch
+# needs the dmabuf mode there.  No run with two RCCL processes has been possible in this build (one GPU per lease), so the
+# claim is the pool's, not a measurement of ours: hence `setdefault` -- a value the user or the launcher exported wins, e.g.
+# HSA_ENABLE_IPC_MODE_LEGACY=1 on a host whose driver predates dmabuf IPC (docs/MULTI_GPU_RUNBOOK.md, "If something goes
+# wrong").  The HSA runtime reads it when it is initialised, i.e. at the first HIP call of the process: it has to be in the
+# environment BEFORE the engine (or torch.cuda) touches the GPU, which is why the package sets it at import time whenever a
+# launcher announces more than one rank, bench.py before it imports torch, and its self-launch in the ranks' environment.
+IPC_MODE_VAR = "HSA_ENABLE_IPC_MODE_LEGACY"
+
+
+def prepare_ipc_environment(env=None, force=False):
+    """Default HSA_ENABLE_IPC_MODE_LEGACY to "0" (dmabuf IPC) in `env` (default: this process's environment) when a launcher
+    announces more than one rank, or always with force=True (an environment being built for ranks).  -> the effective value."""
+    env = os.environ if env is None else env
+    if force or launcher_rank()[1] > 1:
+        env.setdefault(IPC_MODE_VAR, "0")
+    return env.get(IPC_MODE_VAR)
+
+
 def _env_int(*names, default=None):
     for n in names:
         v = os.environ.get(n)
@@ -79,10 +101,24 @@ def default_rendezvous():
     directory."""
     if os.environ.get("LUDVM_RENDEZVOUS"):
         return os.environ["LUDVM_RENDEZVOUS"]
-    job = (os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("SLURM_JOB_ID") or os.environ.get("OMPI_MCA_ess_base_jobid")
-           or "")
-    tag = f"{job}_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
-    return os.path.join(_private_dir(), f"rdv_{tag}")
+    job = launch_name()
+    # (ranks with a launch name need no common parent: one ssh / srun step per rank still agrees on the file)
+    tag = f"{job}_{os.environ.get('MASTER_PORT', '0')}" if job else f"_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
+    return os.path.join(_private_dir(), "rdv_" + "".join(ch if ch.isalnum() or ch in "._-" else "-" for ch in tag))
+
+
+def launch_name():
+    """A string every rank of ONE launch is told alike and no other launch is: LUDVM_LAUNCH_ID (set it when the ranks are
+    started one by one with a shared LUDVM_RENDEZVOUS), torchrun's run identifier unless it is the default "none", the SLURM
+    job AND step, Open MPI's job identifier; "" when there is none (a rendezvous port is reused by the next launch: no name)."""
+    e = os.environ
+    if e.get("LUDVM_LAUNCH_ID"):
+        return e["LUDVM_LAUNCH_ID"]
+    if e.get("TORCHELASTIC_RUN_ID") and e["TORCHELASTIC_RUN_ID"] != "none":
+        return e["TORCHELASTIC_RUN_ID"]
+    if e.get("SLURM_JOB_ID"):
+        return f"{e['SLURM_JOB_ID']}.{e.get('SLURM_STEP_ID', '')}"
+    return e.get("OMPI_MCA_ess_base_jobid") or ""
 
 
 def _process_start(pid):
@@ -98,19 +134,26 @@ def _process_start(pid):
 
 
 def launch_epoch():
-    """A moment no identifier of THIS launch can predate: the start of the process that started us (the launcher: torchrun's
-    agent, orted, slurmstepd -- it is older than every rank it starts, rank 0 included), else our own start."""
+    """A moment no identifier of THIS launch should predate: the start of the process that started us (a common launcher --
+    torchrun's agent, orted, slurmstepd -- is older than every rank it starts, rank 0 included), else our own start.  A HINT
+    (ADVICE r5): ranks started one by one (an ssh or srun step per rank with a shared LUDVM_RENDEZVOUS) have parents younger
+    than rank 0's file, and a container whose /proc/stat btime is virtualised reports start times in another clock -- so a value
+    later than now, or later than this process's own start, is discarded (None: no lower bound), and exchange_id accepts a
+    file whose non-empty launch tag matches whatever its age."""
+    now = time.time()
+    own = _process_start(os.getpid())
     t = _process_start(os.getppid())
     if t is None:
-        t = _process_start(os.getpid())
+        t = own
+    if t is None or t > now + 1.0 or (own is not None and t > own + 1.0):
+        return None
     return t
 
 
 def launch_tag():
-    """What the launcher tells every rank of one launch alike, as bytes (may be empty): travels behind the identifier so that
-    a reader can tell another launch's file by its content too."""
-    job = (os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("SLURM_JOB_ID") or os.environ.get("OMPI_MCA_ess_base_jobid") or "")
-    return f"{job}|{os.environ.get('MASTER_PORT', '')}".encode()
+    """What the launcher tells every rank of one launch alike, as bytes: "<launch name>|<port>" (either may be empty); travels
+    behind the identifier so that a reader can tell another launch's file by its content too."""
+    return f"{launch_name()}|{os.environ.get('MASTER_PORT', '')}".encode()
 
 
 def exchange_id(rank, make_id, path, timeout=600.0, not_before=None, tag=None):
@@ -118,8 +161,10 @@ def exchange_id(rank, make_id, path, timeout=600.0, not_before=None, tag=None):
     Rank 0 never writes through a link and first removes whatever a crashed launch left under the name; the readers take
     only a regular file that belongs to this user -- and only one of THIS launch (a non-zero rank that is faster
     than rank 0 could otherwise read the identifier a crashed launch left under the same name, join a dead communicator and
-    hang in ncclCommInitRank, which has no timeout): a file last written before `not_before` (default: launch_epoch(), less
-    two seconds for /proc's resolution) is waited out, and so is one whose tag (default: launch_tag()) is another launch's."""
+    hang in ncclCommInitRank, which has no timeout): a file whose tag (default: launch_tag()) is another launch's is waited
+    out; one whose tag carries this launch's NAME (launch_name(): unique per launch) is taken whatever its age; without a name
+    a file last written before `not_before` (default: launch_epoch() -- a hint, see there -- less two seconds for /proc's
+    resolution) is waited out as an earlier launch's.  The TimeoutError says what was rejected and why."""
     nofollow = getattr(os, "O_NOFOLLOW", 0)
     tag = launch_tag() if tag is None else bytes(tag)
     if rank == 0:
@@ -142,20 +187,29 @@ def exchange_id(rank, make_id, path, timeout=600.0, not_before=None, tag=None):
     if not_before is None:
         le = launch_epoch()
         not_before = (le - 2.0) if le is not None else 0.0
+    # a tag that names the launch vouches for the file by itself (a port alone does not: the next launch reuses it); the age
+    # test is for launches that have no name
+    tag_names_launch = bool(tag.split(b"|")[0])
     t0 = time.monotonic()
+    rejected = None
     while True:
         try:
             fd = os.open(path, os.O_RDONLY | nofollow)
             with os.fdopen(fd, "rb") as f:
                 st = os.fstat(f.fileno())
-                if stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and st.st_mtime >= not_before:
+                if stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid():
                     uid = f.read()
                     if len(uid) >= 128 and uid[128:] == tag:
-                        return uid[:128]
+                        if tag_names_launch or st.st_mtime >= not_before:
+                            return uid[:128]
+                        rejected = f"a file last written at {st.st_mtime:.1f} was taken for an earlier launch's (not_before {not_before:.1f})"
+                    elif len(uid) >= 128:
+                        rejected = f"a file carries another launch's tag {uid[128:]!r} (ours: {tag!r})"
         except OSError:
             pass
         if time.monotonic() - t0 > timeout:
-            raise TimeoutError(f"no communicator identifier at {path} after {timeout:.0f} s (is rank 0 running?)")
+            raise TimeoutError(f"no communicator identifier at {path} after {timeout:.0f} s (is rank 0 running?)"
+                               + (f"; {rejected}" if rejected else ""))
         time.sleep(0.01)
 
 

@@ -7,7 +7,7 @@ runs bench.main() with a stand-in "rig": CPU tensors, gloo, and the pair arithme
 (tests/oracle_shard_kernel.py).  Everything else is bench.py's own code: the self-launch of `--gpus N` without a launcher
 (the ranks it starts run THIS script, sys.argv[0]), the process group, ShardedWake, the timed regions and their agreement
 between the ranks, the budget, both step variants, the result checks, the collective micro-sweep, the deadline, the one JSON
-line.  The numbers it prints are meaningless as measurements (config.device says so); bench.py itself has no such path and
+line.  The hangs some tests ask for (LUDVM_BENCH_TEST_HANG*) are injected by this rig (tests/bench_hang_hooks.py), not by bench.py.  The numbers it prints are meaningless as measurements (config.device says so); bench.py itself has no such path and
 exits 2 without a GPU.  Used by tests/test_bench_cpu_rehearsal.py to rehearse 2, 4 and 8 ranks.
 """
 import os
@@ -71,7 +71,10 @@ class TimedOracleKernel:
         self.engine._timed(self._k.sym_accumulate, *a)
 
 
-class CpuRig:
+from bench_hang_hooks import HangHooks  # noqa: E402
+
+
+class CpuRig(HangHooks):
     name = "cpu-rehearsal"
     default_backend = "gloo"
 

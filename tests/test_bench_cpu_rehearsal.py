@@ -42,6 +42,8 @@ def test_self_launched_ranks_rehearse_config4(ranks, n):
     assert d["n_gpus"] == ranks and d["config"]["ranks"] == ranks and d["scaling"] == "strong" and "incomplete" not in d
     assert "bench.py itself" in d["config"]["launched_by"] and "torch.distributed.run" in p.stderr
     assert "config 4" in d["config"]["workload"] and d["config"]["collective_backend"] == "gloo"
+    # ONE behaviour on every way in: the ranks' environment carries the IPC mode, the line echoes it
+    assert d["config"]["hsa_enable_ipc_mode_legacy"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert abs(d["value"] - float(n) ** 2 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["repeat_values"] == [] and "cpu_baseline" not in d and "config4_one_gpu" not in d
     assert_self_checking_config4(d, ranks, min_value=1e6)
@@ -75,6 +77,15 @@ def test_deadline_before_anything_was_measured_is_an_error():
     p = subprocess.run([sys.executable, "-c", "import sys, time; sys.argv = ['x']; import bench; r = bench.Reporter(0, 1.0, "
                         "time.perf_counter()); time.sleep(30)"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=60)
     assert p.returncode == 3 and p.stdout == "" and "deadline of 1 s reached during: start-up" in p.stderr
+
+
+def test_the_measurement_program_reads_no_test_variable():
+    """bench.py's N > 1 path is frozen and carries no test hook -- the hangs above are injected by the rigs
+    (tests/bench_hang_hooks.py through HipRig.at_milestone / at_comm_join, which do nothing on the machine)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "LUDVM_BENCH_TEST" not in src
+    import bench
+    assert bench.HipRig.at_milestone(None, None, "x") is None and bench.HipRig.at_comm_join(None, "before", 1.0) is None
 
 
 def test_launcher_world_that_contradicts_gpus_is_refused():

@@ -27,11 +27,23 @@ def test_launcher_rank_reads_the_usual_launchers(monkeypatch):
 
 
 def test_default_rendezvous_is_per_launch(monkeypatch):
-    monkeypatch.delenv("LUDVM_RENDEZVOUS", raising=False)
+    for k in ("LUDVM_RENDEZVOUS", "LUDVM_LAUNCH_ID", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "OMPI_MCA_ess_base_jobid"):
+        monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("MASTER_PORT", "29500")
     a = comm.default_rendezvous()
     monkeypatch.setenv("MASTER_PORT", "29501")
     assert comm.default_rendezvous() != a and str(os.getppid()) in a
+    # a launch with a NAME needs no common parent (one ssh / srun step per rank): the name and the port make the file
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")                 # torchrun's default names nothing
+    assert comm.launch_name() == "" and str(os.getppid()) in comm.default_rendezvous()
+    monkeypatch.setenv("SLURM_JOB_ID", "4711")
+    monkeypatch.setenv("SLURM_STEP_ID", "3")
+    assert comm.launch_name() == "4711.3" and comm.default_rendezvous().endswith("rdv_4711.3_29501")
+    monkeypatch.setenv("LUDVM_LAUNCH_ID", "my run/7")
+    assert comm.launch_name() == "my run/7" and comm.default_rendezvous().endswith("rdv_my-run-7_29501")
+    assert comm.launch_tag() == b"my run/7|29501"
+    monkeypatch.delenv("LUDVM_LAUNCH_ID")
+    monkeypatch.delenv("SLURM_JOB_ID")
     d = os.path.dirname(a)                      # a directory of ours that nobody else can write to
     st = os.stat(d)
     assert st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0
@@ -80,15 +92,19 @@ def test_a_faster_rank_does_not_take_the_identifier_of_an_earlier_launch(tmp_pat
     """the file a crashed launch left under the same name (same LUDVM_RENDEZVOUS, or the same parent and port) is
     still there when a non-zero rank of the next launch looks, BEFORE rank 0 has replaced it.  It is older than this launch
     (its mtime predates the launcher's start) -- or carries another launch's tag -- and is waited out, not read."""
+    import time
+    for k in ("LUDVM_LAUNCH_ID", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "OMPI_MCA_ess_base_jobid"):
+        monkeypatch.delenv(k, raising=False)                                   # a launch without a name: the age test decides
     path = str(tmp_path / "rdv")
     stale, fresh = bytes([7]) * 128, bytes(range(128))
     assert comm.exchange_id(0, lambda: stale, path) == stale                   # the earlier launch ...
-    past = os.stat(path).st_mtime - 3600
-    os.utime(path, (past, past))                                               # ... an hour ago
     le = comm.launch_epoch()
-    assert le is not None and past < le <= __import__("time").time() + 1       # our launcher (pytest's parent) started since
-    with pytest.raises(TimeoutError):
+    assert le is not None and le <= time.time() + 1
+    past = le - 3600                                                           # ... an hour before our launcher started (ADVICE r5:
+    os.utime(path, (past, past))                                               #     derived from the epoch, not from "now")
+    with pytest.raises(TimeoutError) as ei:
         comm.exchange_id(1, None, path, timeout=0.3)                           # rank 1 is early: it does NOT join the dead one
+    assert "taken for an earlier launch's" in str(ei.value) and "not_before" in str(ei.value)
     got = {}
     t = threading.Thread(target=lambda: got.setdefault(1, comm.exchange_id(1, None, path, timeout=30)))
     t.start()
@@ -100,9 +116,60 @@ def test_a_faster_rank_does_not_take_the_identifier_of_an_earlier_launch(tmp_pat
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-A")
     assert comm.exchange_id(0, lambda: stale, path) == stale
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-B")
-    with pytest.raises(TimeoutError):
+    with pytest.raises(TimeoutError) as ei:
         comm.exchange_id(1, None, path, timeout=0.3)
+    assert "another launch's tag" in str(ei.value)
     assert comm.exchange_id(0, lambda: fresh, path) == fresh and comm.exchange_id(1, None, path, timeout=5) == fresh
+
+
+def test_the_launch_epoch_is_a_hint(tmp_path, monkeypatch):
+    """ranks started one by one (an ssh / srun step per rank, staggered) have parents YOUNGER than rank 0's file, and a
+    container with a virtualised /proc/stat btime reports start times in another clock.  A launch NAME in the tag vouches for
+    the file whatever its age; an epoch later than now or later than this process's own start is discarded."""
+    import time
+    path = str(tmp_path / "rdv")
+    uid = bytes(range(128))
+    monkeypatch.setenv("LUDVM_LAUNCH_ID", "launch-42")
+    assert comm.exchange_id(0, lambda: uid, path) == uid
+    old = time.time() - 7200
+    os.utime(path, (old, old))
+    # (this rank's launcher "started" after rank 0 wrote: with a named launch the file is taken all the same)
+    assert comm.exchange_id(1, None, path, timeout=5, not_before=time.time() + 60) == uid
+    monkeypatch.delenv("LUDVM_LAUNCH_ID")
+    for k in ("TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "OMPI_MCA_ess_base_jobid"):
+        monkeypatch.delenv(k, raising=False)
+    # a clock that runs ahead (btime virtualised): parent "started" in the future, or after this very process -> no bound
+    real = comm._process_start
+    monkeypatch.setattr(comm, "_process_start", lambda pid: time.time() + 5000 if pid == os.getppid() else real(pid))
+    assert comm.launch_epoch() is None
+    monkeypatch.setattr(comm, "_process_start", lambda pid: (real(os.getpid()) or time.time()) + 30 if pid == os.getppid() else real(pid))
+    assert comm.launch_epoch() is None
+    monkeypatch.setattr(comm, "_process_start", real)
+    assert comm.launch_epoch() is not None
+
+
+def test_ipc_mode_default_for_multi_process_launches(monkeypatch):
+    """ONE behaviour on every way into a multi-GPU run -- HSA_ENABLE_IPC_MODE_LEGACY defaults to "0" (dmabuf
+    IPC; the pool's image notes, ludvm_amd/comm.py) whenever a launcher announces more than one rank, a value the caller
+    exported wins, a lone process is left alone."""
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS", comm.IPC_MODE_VAR):
+        monkeypatch.delenv(k, raising=False)
+    env = {}
+    assert comm.prepare_ipc_environment(env) is None and env == {}                 # one process: nothing to share
+    assert comm.prepare_ipc_environment(env, force=True) == "0" and env == {comm.IPC_MODE_VAR: "0"}
+    env = {comm.IPC_MODE_VAR: "1"}
+    assert comm.prepare_ipc_environment(env, force=True) == "1"                    # the caller's choice stands
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert comm.prepare_ipc_environment() == "0" and os.environ[comm.IPC_MODE_VAR] == "0"
+    # ... and importing the package under a launcher does it before any HIP call
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = "import os, ludvm_amd; print(os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))"
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", comm.IPC_MODE_VAR)}
+    run = lambda e: subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, cwd=ROOT, timeout=120).stdout.strip()   # noqa: E731
+    assert run(base) == "None" and run(dict(base, WORLD_SIZE="2", RANK="1")) == "0"
+    assert run(dict(base, WORLD_SIZE="2", RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="1")) == "1"
 
 
 def test_thresholds_can_be_set_for_a_launch_from_the_environment():

@@ -11,6 +11,7 @@ from bench_checks import assert_self_checking_config4 as _assert_self_checking_c
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
+HANG_RIG = os.path.join(ROOT, "tests", "bench_hang_rig.py")      # bench.main() on the HIP rig + the hooks that hang on purpose
 
 
 def _run(*args):
@@ -145,11 +146,14 @@ def test_bench_two_ranks_through_the_launcher():
 
 
 def _self_launch(nproc, extra_env, *args, timeout=600):
-    """`python bench.py --gpus N ...` with NO launcher: bench.py starts its ranks itself."""
+    """`python bench.py --gpus N ...` with NO launcher: bench.py starts its ranks itself.  A test that asks
+    for a hang on purpose (LUDVM_BENCH_TEST_HANG*) runs tests/bench_hang_rig.py -- bench.main() on the same HIP rig plus the
+    hooks that hang; bench.py itself reads no test variable."""
     env = dict(os.environ, **extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *args], capture_output=True, text=True,
+    script = HANG_RIG if any(k.startswith("LUDVM_BENCH_TEST_HANG") for k in extra_env) else os.path.join(ROOT, "bench.py")
+    p = subprocess.run([sys.executable, script, "--gpus", str(nproc), *args], capture_output=True, text=True,
                        env=env, timeout=timeout)
     return p, [l for l in p.stdout.splitlines() if l.strip()]
 
@@ -303,7 +307,7 @@ def test_bench_deadline_prints_what_has_been_measured():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     t0 = time.time()
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--vortices", "40000", "--steps", "3", "--warmup", "1",
+    p = subprocess.run([sys.executable, HANG_RIG, "--vortices", "40000", "--steps", "3", "--warmup", "1",
                         "--cpu-rows", "0", "--deadline-s", "25"], capture_output=True, text=True, env=env, timeout=120)
     assert p.returncode == 0, p.stderr[-2000:]
     assert 20 < time.time() - t0 < 60
@@ -322,7 +326,7 @@ def test_bench_survives_a_communicator_join_that_never_returns():
     env = dict(os.environ, LUDVM_BENCH_TEST_HANG_COMM="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg4", "--vortices", "60000", "--steps", "2",
+    p = subprocess.run([sys.executable, HANG_RIG, "--workload", "cfg4", "--vortices", "60000", "--steps", "2",
                         "--warmup", "1", "--cpu-rows", "0", "--collectives", "library", "--comm-init-timeout", "3"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -341,7 +345,7 @@ def test_bench_leaves_a_communicator_alone_that_joined_late():
     env = dict(os.environ, LUDVM_BENCH_TEST_HANG_COMM="late")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg4", "--vortices", "60000", "--steps", "2",
+    p = subprocess.run([sys.executable, HANG_RIG, "--workload", "cfg4", "--vortices", "60000", "--steps", "2",
                         "--warmup", "1", "--cpu-rows", "0", "--collectives", "library", "--comm-init-timeout", "3"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -351,6 +355,31 @@ def test_bench_leaves_a_communicator_alone_that_joined_late():
     assert "did not return within 3 s" in d["config"]["collective_note"] and "torch.distributed" in d["config"]["collective"]
     assert "incomplete" not in d and d["value"] > 1e11
     _assert_self_checking_config4(d, 1, collectives_issued=False)
+
+
+def test_bench_falls_back_when_the_first_collective_on_the_library_communicator_raises():
+    """the known-sum proof runs on a side stream; if that first all-reduce RAISES (an RCCL error is what the torch
+    fallback exists for) the engine must be handed back to the stream the run measures on -- try / finally -- and the run goes
+    on with torch.distributed's collectives on the SAME engine (the join returned: nothing is abandoned).  The result checks of
+    both variants pass."""
+    env = dict(os.environ, LUDVM_BENCH_TEST_HANG_COMM="raise")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, HANG_RIG, "--workload", "cfg4", "--vortices", "60000", "--steps", "2",
+                        "--warmup", "1", "--cpu-rows", "0", "--collectives", "library", "--comm-init-timeout", "30"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert "raised on purpose" in d["config"]["collective_note"] and "torch.distributed" in d["config"]["collective"]
+    assert "incomplete" not in d and d["value"] > 1e11
+    _assert_self_checking_config4(d, 1, collectives_issued=False)
+
+
+def test_the_measurement_program_reads_no_test_variable():
+    """the hang hooks live in the test rigs (tests/bench_hang_hooks.py), not in bench.py."""
+    assert "LUDVM_BENCH_TEST" not in open(os.path.join(ROOT, "bench.py")).read()
 
 
 def test_rccl_ranks_that_would_share_a_card_are_refused_with_a_message():
