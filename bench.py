@@ -24,7 +24,13 @@ says so in `scaling_denominator`.
 Order of a run: CPU baseline (rank 0, N = 1 only) -> warmup -> the timed region of exactly --steps steps (barrier +
 synchronize on both sides) -> --repeats further regions of the same length, reported as `repeat_values` (box-to-box and
 run-to-run spread; they also keep the GPU busy long enough for a 5-second utilisation sampler to see the run) -> at
-N = 1, --cfg4-steps steps of config 4's workload (N = 8e6) on the one GPU, reported as `config4_one_gpu`.
+N = 1, --cfg4-steps steps of config 4's workload (N = 8e6) on the one GPU, reported as `config4_one_gpu`, then one leg per
+remaining BASELINE config, each outside `value` and each with its own check: `config5_flowfield` (4096 x 4096 grid over the
+N = 1e6 wake + vorticity: ms, pairs/s, credited fraction of the fp32 peak, 256 sampled grid points against the C oracle),
+`config2_time_loop` (the full 50 000-step LUDVM(dt=1e-3, tf=50): wall, roll-up pairs, pairs/s of the wall, pair-kernel seconds,
+final wake, first LEV step and max |dCl| over the first 600 steps against the reference's own first 1500 steps,
+tests/golden/g7_config2_first1500.npz) and `config1_readme` (the README case's wall time and `cpu_baseline_time_loop`: the same
+case by the oracle's restatement of the reference's time_loop on one host core).  ~25 s on top of the rest (--cfg5/2/1 0 skip).
 
 Config 4 (every N > 1 run) is a self-checking measurement, because nobody gets to debug it on the 8-GPU node:
   * `config.collective_ms_per_rank` beside `config.pair_kernel_ms_per_rank` (HIP events on the launch stream around the
@@ -123,6 +129,14 @@ def synthetic_wake(n):
     return x.astype(np.float32), z.astype(np.float32), g.astype(np.float32)
 
 
+def usable_cpus():
+    """CPUs this process may run on (affinity mask / cgroup cpuset), not the machine's count."""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(x, z, g, rows, budget_s):
     """The reference arithmetic as written (float64 NumPy broadcast, oracle/ludvm_oracle.py restating
     LUDVM.py:549-570) on a bounded sample: the first `rows` targets against all sources, one core.  Returns the
@@ -146,15 +160,23 @@ def cpu_baseline(x, z, g, rows, budget_s):
     # single-threaded form, never instead of it ("optionally also an all-cores figure")
     try:
         from oracle import c_oracle
-        cores = os.cpu_count() or 1
-        c_oracle.set_threads(cores)
-        t1 = time.perf_counter()
-        uc, wc = c_oracle.induced_velocity(gs, xs, zs, xs[:done], zs[:done], V_CORE)
+        c_oracle.set_threads(usable_cpus())          # (the affinity mask, not os.cpu_count(): ADVICE r5)
+        # bounded like the NumPy leg: chunks of targets until the sample is done or a quarter of --cpu-budget is spent
+        # (without OpenMP, or on a few cores, the whole sample would take tens of seconds)
+        uc, wc = np.empty(done), np.empty(done)
+        chunk = max(1, min(done, 64 * c_oracle.threads()))
+        done_c, t1 = 0, time.perf_counter()
+        while done_c < done and (time.perf_counter() - t1 < 0.25 * budget_s or done_c == 0):
+            b = min(done, done_c + chunk)
+            uc[done_c:b], wc[done_c:b] = c_oracle.induced_velocity(gs, xs, zs, xs[done_c:b], zs[done_c:b], V_CORE)
+            done_c = b
         el_c = time.perf_counter() - t1
         scale = max(np.abs(u[:done]).max(), np.abs(w[:done]).max())
-        rec["all_cores"] = {"value": done * len(xs) / el_c, "unit": "pairs/s", "cores": c_oracle.threads(), "kind": "port",
-                            "sample": f"the same {done} x {len(xs)} pairs by the C restatement, OpenMP over targets, {el_c:.2f} s",
-                            "vs_numpy_max_rel_diff": float(max(np.abs(uc - u[:done]).max(), np.abs(wc - w[:done]).max()) / scale)}
+        rec["all_cores"] = {"value": done_c * len(xs) / el_c, "unit": "pairs/s", "cores": c_oracle.threads(), "kind": "port",
+                            "sample": f"the first {done_c} of the same {done} targets x {len(xs)} sources by the C restatement, OpenMP over "
+                                      f"targets, {el_c:.2f} s",
+                            "vs_numpy_max_rel_diff": float(max(np.abs(uc[:done_c] - u[:done_c]).max(),
+                                                               np.abs(wc[:done_c] - w[:done_c]).max()) / scale)}
     except Exception as e:       # noqa: BLE001  (an extra; the contract's baseline is the record above)
         rec["all_cores"] = {"error": f"{type(e).__name__}: {e}"}
     return rec, u[:done], w[:done]
@@ -393,7 +415,7 @@ def check_wake(wake, g, rank, rig):
             wg = (wake.zs[:n][ti].cpu().numpy().astype(np.float64) - z0h[idx]) / CHECK_DT
             t0 = time.perf_counter()
             if c_oracle.threads() < 16:          # (launchers pin OMP_NUM_THREADS to 1 per rank; the other ranks are waiting)
-                c_oracle.set_threads(min(16, os.cpu_count() or 1))
+                c_oracle.set_threads(min(16, usable_cpus()))
             uo, wo = c_oracle.induced_velocity(np.asarray(g, dtype=np.float64), x0h, z0h, x0h[idx], z0h[idx], wake.v_core)
             scale = max(np.abs(uo).max(), np.abs(wo).max())
             err = max(np.abs(ug - uo).max(), np.abs(wg - wo).max()) / scale
@@ -522,6 +544,9 @@ def parse_args(argv):
                     help="config 4: result check after the timed regions (cross-rank checksum + sampled oracle check)")
     ap.add_argument("--sweep", type=int, choices=[0, 1], default=1,
                     help="config 4: collective micro-sweep at the class-level sharding's threshold sizes after the checks (< 1 s)")
+    ap.add_argument("--cfg5", type=int, choices=[0, 1], default=1, help="N = 1: config 5's flow field (4096^2 x 1e6, ~2 s per call) after config 4's leg")
+    ap.add_argument("--cfg2", type=int, choices=[0, 1], default=1, help="N = 1: config 2's full 50 000-step time_loop (~11 s)")
+    ap.add_argument("--cfg1", type=int, choices=[0, 1], default=1, help="N = 1: config 1 (README case) + its CPU baseline by the oracle (~5 s of CPU)")
     ap.add_argument("--cfg4-steps", type=int, default=2,
                     help="N = 1: steps of config 4's workload (N = 8e6, ~7 s each) timed on the one GPU after the config-3 run (0 = skip)")
     return ap.parse_args(argv)
@@ -779,8 +804,133 @@ def run_config3(R):
             R.publish("the result check of config4_one_gpu", repeats, None, dict(cfg4_rec))
             cfg4_rec["result_check"] = check_wake(wake4, g4, R.rank, rig)
         del wake4
-    return repeats, {}, cfg4_rec
+    # ... and the other BASELINE configs, each with its own check: 5 (flow field), 2 (full time_loop), 1 (README)
+    extra = {}
+    if R.world == 1 and not args.vortices and R.workload == "cfg3" and not args.tpl and not args.splits:
+        extra = other_configs(R, dx, dz, dg, repeats, cfg4_rec)
+    return repeats, extra, cfg4_rec
 
+
+
+# ======================================================================================================================
+# N = 1: a driver-timed figure for the other BASELINE configs (5, 2, 1) -- outside `value`, after config 4's leg
+# ======================================================================================================================
+README_CASE = dict(t0=0, tf=20, dt=5e-2, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2, Naca="0012")   # config 1
+
+
+def leg_config5(R, dx, dz, dg):
+    """BASELINE config 5: flowfield 4096 x 4096 grid over the N = 1e6 synthetic wake (LUDVM.flowfield, LUDVM.py:1186-1298:
+    grid targets + vorticity stencil, on the device), one untimed call, one timed; 256 sampled grid points against the float64
+    C oracle (the checker), bound 1e-5 of max|u| (the test's: tests/test_gpu_kernel.py::test_full_size_config5_flowfield)."""
+    torch, eng, rig, n = R.torch, R.eng, R.rig, R.n
+    nx = nz = 4096
+    xmin, zmin, dr = -8.0, -4.0, 8.0 / nx
+    du = torch.empty(nx * nz, dtype=torch.float32, device=R.device)
+    dw, dome = torch.empty_like(du), torch.empty_like(du)
+
+    def run():
+        eng.flowfield_dev(xmin, zmin, dr, nx, nz, dx.data_ptr(), dz.data_ptr(), dg.data_ptr(), n, V_CORE, du.data_ptr(), dw.data_ptr())
+        eng.vorticity_dev(du.data_ptr(), dw.data_ptr(), nx, nz, dr, dome.data_ptr())
+    run()
+    el, kms, nl, _, _ = R.timed_region(run, 1)
+    pairs = float(nx) * nz * n
+    rec = {"workload": f"config 5: flowfield {nx} x {nz} grid over the N={n} synthetic wake + vorticity stencil, fp32 (4 x 4 patch kernel)",
+           "ms": el * 1e3, "value": pairs / el, "unit": "pairs/s", "steps": 1, "warmup": 1, "pair_kernel_ms": kms,
+           "pair_kernel_launches": nl,
+           "credited_frac": FLOP_PER_PAIR * pairs / (kms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS if kms > 0 else None,
+           "omega_finite": bool(torch.isfinite(dome).all().item())}
+    from oracle import c_oracle          # the checker; never the thing measured
+    sel = np.sort(np.random.default_rng(5).choice(nx * nz, CHECK_SAMPLES, replace=False))
+    xt, zt = xmin + (sel // nz) * dr, zmin + (sel % nz) * dr
+    if c_oracle.threads() < 16:
+        c_oracle.set_threads(min(16, usable_cpus()))
+    uo, wo = c_oracle.induced_velocity(R.g.astype(np.float64), R.x.astype(np.float64), R.z.astype(np.float64), xt, zt, V_CORE)
+    st = torch.from_numpy(sel).to(R.device)
+    ug, wg = du[st].cpu().numpy().astype(np.float64), dw[st].cpu().numpy().astype(np.float64)
+    scale = max(np.abs(uo).max(), np.abs(wo).max())
+    rec.update(samples=CHECK_SAMPLES, gpu_vs_oracle_max_rel_err=float(max(np.abs(ug - uo).max(), np.abs(wg - wo).max()) / scale),
+               bound=1e-5)
+    return rec
+
+
+def leg_config2(R):
+    """BASELINE config 2: NACA0012 sinusoidal pitch, dt = 1e-3, t in [0, 50]: the full 50 000-step LUDVM.time_loop
+    (LUDVM.py:597-1171) in fp32 on a fresh engine, device-resident march, sparse history.  Checked against the REFERENCE's own
+    run of the first 1500 steps (tests/golden/g7_config2_first1500.npz, generated by importing the reference): first LEV at
+    step 1335, max |dCl| over the first 600 steps <= 1e-5 (the fp32 tier of tests/test_gpu_wake.py; chaos beyond ~1000)."""
+    from ludvm_amd import LUDVM
+    eng = R.rig.new_engine()
+    eng.kernel_timing(True)
+    eng.kernel_time_ms(reset=True)
+    R.fence()
+    t0 = time.perf_counter()
+    sim = LUDVM(**dict(README_CASE, dt=1e-3, tf=50), verbose=False, engine=eng, precision="f32", history="sparse", snapshot_steps=[],
+                run=False)
+    t_setup = time.perf_counter() - t0
+    sim.time_loop()
+    sim.compute_coefficients()
+    R.fence()
+    wall = time.perf_counter() - t0
+    kms, nl = eng.kernel_time_ms(reset=True)
+    eng.kernel_timing(False)
+    shed = sim.LEV_shed != -1
+    sizes = 1 + np.arange(1, sim.nt) + np.cumsum(shed[1:])            # wake size at every step's roll-up
+    pairs = float(np.sum((sizes + 80.0) * sizes))                     # ... x (wake + 80 bound vortices) sources
+    rec = {"workload": "config 2: NACA0012 sinusoidal pitch, dt=1e-3, t in [0,50], full time_loop, fp32, device-resident march",
+           "steps": int(sim.nt - 1), "wall_s": wall, "setup_s": t_setup, "time_loop_s": wall - t_setup, "final_wake": int(sizes[-1]),
+           "rollup_pairs": pairs, "pairs_per_s_wall": pairs / wall, "unit": "pairs/s", "pair_kernel_s": kms * nl * 1e-3,
+           "pair_kernel_launches": int(nl), "first_lev_step": int(np.argmax(shed)), "Cl_mean_last_period": float(np.mean(sim.Cl[-10000:]))}
+    g7 = np.load(os.path.join(ROOT, "tests", "golden", "g7_config2_first1500.npz"))
+    rec.update(first_lev_step_reference=int(g7["first_lev_step"]),
+               max_abs_dCl_first_600_steps_vs_reference=float(np.abs(sim.Cl[:601] - g7["Cl"][:601]).max()), bound=1e-5,
+               shedding_identical_through_step_1400=bool(np.array_equal(shed[:1401], g7["LEV_shed"][:1401] != -1)))
+    del sim, eng
+    return rec
+
+
+def leg_config1(R):
+    """BASELINE config 1 (the reference's README example, its own CPU-runnable case): wall time of LUDVM(**README_CASE) on the
+    GPU path (precision 'auto' = float64 pair sums at this size), and `cpu_baseline_time_loop`: the same case by the oracle's
+    restatement of LUDVM.py:597-1171 as the reference writes it (float64 NumPy, one core) -- BASELINE.md section 4's plan."""
+    from ludvm_amd import LUDVM
+    eng = R.rig.new_engine()
+    LUDVM(**README_CASE, verbose=False, engine=eng)                   # (allocations, first launches)
+    R.fence()
+    t0 = time.perf_counter()
+    sim = LUDVM(**README_CASE, verbose=False, engine=eng)
+    R.fence()
+    wall = time.perf_counter() - t0
+    from oracle import ludvm_oracle as O          # the reported-only CPU baseline and the checker
+    t0 = time.perf_counter()
+    ref = O.OracleLUDVM(**README_CASE)
+    cpu_s = time.perf_counter() - t0
+    rec = {"workload": "config 1: README case, NACA0012, dt=5e-2, t in [0,20], Npoints=81, Ncoeffs=30, LESPcrit=0.2 (401 steps)",
+           "wall_s": wall, "steps": int(sim.nt - 1), "precision": sim.precision,
+           "cpu_baseline_time_loop": {"value": cpu_s, "unit": "s", "cores": 1, "kind": "port",
+                                      "sample": "the whole case (401 steps) by oracle/ludvm_oracle.py::OracleLUDVM, float64 NumPy as the "
+                                                "reference writes it (LUDVM.py:597-1171)"},
+           "speedup_vs_cpu_baseline": cpu_s / wall,
+           "lev_shedding_identical": bool(np.array_equal(sim.LEV_shed, ref.LEV_shed)),
+           "max_abs_dCl_first_100_steps_vs_oracle": float(np.abs(sim.Cl[:101] - ref.Cl[:101]).max()), "bound": 1e-9}
+    del sim, eng
+    return rec
+
+
+def other_configs(R, dx, dz, dg, repeats, cfg4_rec):
+    """-> {"config5_flowfield": ..., "config2_time_loop": ..., "config1_readme": ...}; a leg that fails is reported, it does not
+    take the line with it."""
+    out = {}
+    for key, on, fn in (("config5_flowfield", R.args.cfg5, lambda: leg_config5(R, dx, dz, dg)),
+                        ("config2_time_loop", R.args.cfg2, lambda: leg_config2(R)),
+                        ("config1_readme", R.args.cfg1, lambda: leg_config1(R))):
+        if not on:
+            continue
+        R.publish(f"the {key} leg", repeats, dict(out), cfg4_rec)
+        try:
+            out[key] = fn()
+        except Exception as e:       # noqa: BLE001
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 # ======================================================================================================================
 # config 4: the sharded self-advection step

@@ -189,6 +189,7 @@ constexpr int kTileF32 = 1024;
 constexpr int kTileF32Small = 256;
 constexpr int kTileF64 = 512;
 constexpr int kTileF64Few = 128;         // fp64 launches with few targets (chord points): short tiles, more workgroups
+                                         // (64: more slabs than the shorter walks save, profiles/r06_march_chain_ab.txt)
 constexpr long long kFewTargets = 256;
 constexpr long long kTargetBlocks = 16384;  // total workgroups aimed for (2048 resident at 8/CU)
 constexpr int kMaxSplit = 2048;

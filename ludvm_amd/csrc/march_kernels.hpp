@@ -4,7 +4,7 @@
 // workgroup per step.
 //
 // Per time step i the device runs, in this order,
-//   pair_f64<128>       fp64 partial sums of the wake at Npanels + 3 targets: the chord points of step i
+//   pair_f64_few        fp64 partial sums of the wake at Npanels + 3 targets: the chord points of step i
 //                       (:746, :921), the two points where step i will shed its TEV and candidate LEV, and the
 //                       origin (where the reference keeps a zero-strength LEV slot that it convects, :1112-1118)
 //   march_chord_finish  sums the partials; unit influences of those two vortices at the chord points
@@ -15,6 +15,11 @@
 //   roll-up             (:1095-1127) the pair kernels of pair_kernels.hpp / pair_sym_kernels.hpp with the wake
 //                       size taken from MarchState; their Euler finisher also places the TEV / LEV of step i + 1
 //                       (:680-681, :797-800) and stages its chord points (TailDuty)
+// Round 6 (profiles/r06_march_chain_ab.txt): the waves of the first three raise their issue priority (they run beside a roll-up
+// kernel that keeps every SIMD busy) and march_solve's ~14 dependent workgroup reductions are done in 2 rounds (3 with
+// 'Ramesh'), each value by the same tree: the same bits, config 2 -0.07 s.  Measured and dropped: summing the slabs inside
+// march_solve with 12 helper wavefronts (a 1024-thread workgroup has to find a whole CU free: config 2 +1.2 s) and
+// 64-source tiles for the chord sums (more slabs than the shorter walks save).
 // Once the wake is large enough for the symmetric kernel the first three run on a second stream BESIDE the bulk of
 // the roll-up: old wake on old wake depends only on the positions after the previous roll-up, not on this step's
 // solve.  The shed vortices are then handled apart: what the old wake induces on them comes from the two extra
@@ -36,6 +41,26 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
   if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
   __syncthreads();
   return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+// K sums at once, each by block_sum's tree (the same bits per value): one pair of barriers for all of them instead of one
+// pair each -- march_solve is a chain of reductions, and two barriers + six dependent shuffles per value were most of its
+// time.  `scratch` holds 4 K doubles.
+template <int K>
+__device__ __forceinline__ void block_sum_n(double (&v)[K], double* scratch) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += __shfl_down(v[k], off, 64);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) scratch[4 * k + (threadIdx.x >> 6)] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = (scratch[4 * k] + scratch[4 * k + 1]) + (scratch[4 * k + 2] + scratch[4 * k + 3]);
 }
 
 // 2x2 solve as LAPACK's dgesv does it (partial pivoting), so that the result has the rounding of
@@ -140,6 +165,7 @@ march_begin(MarchState* S, const double* kin, int npan, int slot, const double* 
 __global__ void __launch_bounds__(kBlock)
 march_chord_finish(const double* part, long long nt_pad, int nsplit, const double* direct_u, int npan, MarchState* S,
                    double vc4) {
+  __builtin_amdgcn_s_setprio(3);                 // (see march_solve)
   const long long gtid = (long long)blockIdx.x * kBlock + threadIdx.x;
   const long long col = gtid >> 6;
   const int lane = threadIdx.x & 63;
@@ -178,7 +204,9 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
             double* g64, Mirrors mir, float* g32, unsigned long long* progress) {
   __shared__ double Wn[kMarchMaxPan];
   __shared__ double A[kMarchMaxCoef], Ad[kMarchMaxCoef];
-  __shared__ double scratch[kBlock / 64];
+  __shared__ double scratch[4 * 8];
+  // the chain runs beside a roll-up kernel that keeps every SIMD's issue slots busy: its few waves go first
+  __builtin_amdgcn_s_setprio(3);
   const int j = threadIdx.x;
   const int npan = m.npan, ncoef = m.ncoef;
   const bool on = j < npan;
@@ -187,6 +215,12 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
   const double ca = cos(al), sa = sin(al);
   const double* xg = kin + 7;
   const double* zg = kin + 7 + npan;
+
+  // what the solve reads of the state, before anything is rewritten
+  const long long n0 = S->n;
+  const double tev_x = S->place[0], lev_x = S->place[1], tev_z = S->place[2], lev_z = S->place[3];
+  const double pu0 = S->pvel[0], pu1 = S->pvel[1], pw0 = S->pvel[3], pw1 = S->pvel[4];
+  const double puo = S->pvel[2], pwo = S->pvel[5];
 
   double u1 = 0, w1 = 0, ut1 = 0, wt1 = 0, ul1 = 0, wl1 = 0, dedx = 0, cm1 = 0, wq = 0;
   if (on) {
@@ -206,16 +240,20 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
     const double ult = ul1 * ca - wl1 * sa, uln = ul1 * sa + wl1 * ca;
     t3 = dedx * ult - uln;
   }
-  const double I1 = block_sum(t1 * cm1, scratch);
-  const double I2 = block_sum(t2 * cm1, scratch);
+  // the six chord integrals at once (I3 and the J's are needed on shedding steps only: summed anyway, one pair of barriers)
+  double ij[6] = {t1 * cm1, t2 * cm1, t3 * cm1, t1 * wq, t2 * wq, t3 * wq};
+  block_sum_n<6>(ij, scratch);
+  const double I1 = ij[0], I2 = ij[1];
   const double kelvin = S->sum_tev + S->sum_lev + m.kelvin0;
   const bool ramesh = m.method == 1;
   RameshProj rp{};
   double g_tev;
   if (ramesh) {
     const double c0 = on ? m.cproj[j] / m.U : 0.0, c1 = on ? m.cproj[npan + j] / m.U : 0.0;
-    rp.p0[0] = block_sum(t1 * c0, scratch); rp.p0[1] = block_sum(t2 * c0, scratch); rp.p0[2] = block_sum(t3 * c0, scratch);
-    rp.p1[0] = block_sum(t1 * c1, scratch); rp.p1[1] = block_sum(t2 * c1, scratch); rp.p1[2] = block_sum(t3 * c1, scratch);
+    double pr[6] = {t1 * c0, t2 * c0, t3 * c0, t1 * c1, t2 * c1, t3 * c1};
+    block_sum_n<6>(pr, scratch);
+    rp.p0[0] = pr[0]; rp.p0[1] = pr[1]; rp.p0[2] = pr[2];
+    rp.p1[0] = pr[3]; rp.p1[1] = pr[4]; rp.p1[2] = pr[5];
     rp.ucpi = m.U * m.chord * pi;
     rp.kelvin = kelvin;
     g_tev = ramesh_tev(rp, m.maxerror, m.maxiter, m.epsilon);
@@ -241,10 +279,10 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
   __syncthreads();                                   // everyone has read A[0] before it is rewritten
   if (shed) {
     lesp_crit = A[0] < 0 ? -fabs(lesp_crit) : fabs(lesp_crit);     // :802-805
-    const double I3 = block_sum(t3 * cm1, scratch);
-    const double J1 = -1 / pi * block_sum(t1 * wq, scratch);
-    const double J2 = -1 / pi * block_sum(t2 * wq, scratch);
-    const double J3 = -1 / pi * block_sum(t3 * wq, scratch);
+    const double I3 = ij[2];
+    const double J1 = -1 / pi * ij[3];
+    const double J2 = -1 / pi * ij[4];
+    const double J3 = -1 / pi * ij[5];
     if (ramesh) ramesh_tev_lev(rp, lesp_crit, g_tev, m.maxerror, m.maxiter, m.epsilon, g_tev, g_lev);
     else solve2(1 + I2, 1 + I3, J2, J3, -(I1 + kelvin), lesp_crit - J1, g_tev, g_lev);   // :944-954
     if (on) Wn[j] = (t1 + g_tev * t2 + g_lev * t3) / m.U;
@@ -258,7 +296,6 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
     }
     __syncthreads();
     bound = ramesh ? ucpi * (A[0] + A[1] / 2) : I1 + g_tev * I2 + g_lev * I3;
-    __syncthreads();
   }
 
   // bound vorticity per panel (:987-1010)
@@ -269,47 +306,33 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
     gamma = 2 * m.U * (A[0] * m.opcs[j] + ssum);
     dgamma = gamma * m.hcsd[j];
   }
-  // loads (:1035-1090); tangential velocity on the chord from the whole wake by linearity
-  double fn_t = 0.0, m_t = 0.0;
+  const int k = shed ? 2 : 1;
+  // One more round of sums: the loads (:1035-1090; tangential velocity on the chord from the whole wake by linearity), and
+  // the velocity of the vortices shed now, for the roll-up that treats them apart (:1105-1124 restricted to them): the
+  // wake's part came with the chord sums; the bound vortices' part is summed here; plus each other.
+  // The reference convects LEV slot `ilev` -- zero strength, at the origin -- on a step that sheds no LEV and stores
+  // where it lands in path['LEV'][i] (:1112-1118); its velocity: wake (chord launch), the new TEV, the bound vortices.
+  double r8[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // fn, m, fu0, fw0, fu1, fw1, fuo, fwo
   if (on) {
     const double uc1 = u1 + g_tev * ut1 + (shed ? g_lev * ul1 : 0.0);
     const double wc1 = w1 + g_tev * wt1 + (shed ? g_lev * wl1 : 0.0);
     const double u = uc1 * ca - wc1 * sa;
-    fn_t = u * gamma * m.wx[j];
-    m_t = u * gamma * m.xpan[j] * m.wx[j];
-  }
-  const double fn_sum = block_sum(fn_t, scratch);
-  const double m_sum = block_sum(m_t, scratch);
-
-  const long long n0 = S->n;
-  const int k = shed ? 2 : 1;
-  const double tev_x = S->place[0], lev_x = S->place[1], tev_z = S->place[2], lev_z = S->place[3];
-  const double pu0 = S->pvel[0], pu1 = S->pvel[1], pw0 = S->pvel[3], pw1 = S->pvel[4];
-  const double puo = S->pvel[2], pwo = S->pvel[5];
-
-  // Velocity of the vortices shed now, for the roll-up that treats them apart (:1105-1124 restricted to them):
-  // the wake's part came with the chord sums; the bound vortices' part is summed here; plus each other.
-  double fu0 = 0, fw0 = 0, fu1 = 0, fw1 = 0;
-  if (on) {
+    r8[0] = u * gamma * m.wx[j];
+    r8[1] = u * gamma * m.xpan[j] * m.wx[j];
     double uu, ww;
     unit_pair_f64(tev_x, tev_z, xg[j], zg[j], m.vc4, uu, ww);
-    fu0 = dgamma * uu; fw0 = dgamma * ww;
+    r8[2] = dgamma * uu; r8[3] = dgamma * ww;
     if (shed) {
       unit_pair_f64(lev_x, lev_z, xg[j], zg[j], m.vc4, uu, ww);
-      fu1 = dgamma * uu; fw1 = dgamma * ww;
+      r8[4] = dgamma * uu; r8[5] = dgamma * ww;
+    } else {
+      unit_pair_f64(0.0, 0.0, xg[j], zg[j], m.vc4, uu, ww);
+      r8[6] = dgamma * uu; r8[7] = dgamma * ww;
     }
   }
-  const double su0 = block_sum(fu0, scratch), sw0 = block_sum(fw0, scratch);
-  const double su1 = block_sum(fu1, scratch), sw1 = block_sum(fw1, scratch);
-  // The reference convects LEV slot `ilev` -- zero strength, at the origin -- on a step that sheds no LEV and stores
-  // where it lands in path['LEV'][i] (:1112-1118); its velocity: wake (chord launch), the new TEV, the bound vortices.
-  double fuo = 0, fwo = 0;
-  if (on && !shed) {
-    double uu, ww;
-    unit_pair_f64(0.0, 0.0, xg[j], zg[j], m.vc4, uu, ww);
-    fuo = dgamma * uu; fwo = dgamma * ww;
-  }
-  const double suo = block_sum(fuo, scratch), swo = block_sum(fwo, scratch);
+  block_sum_n<8>(r8, scratch);
+  const double fn_sum = r8[0], m_sum = r8[1];
+  const double su0 = r8[2], sw0 = r8[3], su1 = r8[4], sw1 = r8[5], suo = r8[6], swo = r8[7];
   __syncthreads();                                   // all reads of S are done; it is rewritten below
 
   // Local-origin mirrors of the entries written now -- wake index n0 (TEV), n0 + 1 (LEV when shed), then the npan

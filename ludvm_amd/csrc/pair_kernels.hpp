@@ -470,6 +470,9 @@ pair_f64_few(PairArgs a) {
 #define LUDVM_FEW_PAD 2
 #endif
   constexpr int kPad = LUDVM_FEW_PAD;
+  // few waves with a dependent launch waiting for them (the march's solve chain runs them beside a roll-up kernel that
+  // keeps every SIMD's issue slots busy): they go first
+  __builtin_amdgcn_s_setprio(3);
   __shared__ __attribute__((aligned(16))) double lx[kFewGroupsMax][TILE + kPad];
   __shared__ __attribute__((aligned(16))) double lz[kFewGroupsMax][TILE + kPad];
   __shared__ __attribute__((aligned(16))) double lg[kFewGroupsMax][TILE + kPad];

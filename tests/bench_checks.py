@@ -56,3 +56,28 @@ def assert_sweep(d, ranks, issuers):
             assert v["allreduce_us"] >= 0.5 * v["saved_us"]
     if sug is not None:
         assert m[str(sug)]["allreduce_us"] < 0.5 * m[str(sug)]["saved_us"]
+
+
+def assert_other_configs(d):
+    """The N = 1 line's legs for BASELINE configs 5, 2 and 1: a driver-timed figure for each, outside
+    `value`, each with its own check against the oracle / the reference's golden run."""
+    c5 = d["config5_flowfield"]
+    assert "error" not in c5, c5
+    assert "4096 x 4096" in c5["workload"] and c5["unit"] == "pairs/s" and c5["samples"] == 256 and c5["omega_finite"] is True
+    assert c5["value"] == pytest.approx(4096.0 * 4096.0 * 1e6 / (c5["ms"] * 1e-3), rel=1e-9) and c5["value"] > 5e12
+    assert c5["pair_kernel_ms"] <= c5["ms"] * 1.02 and 0.5 < c5["credited_frac"] < 1.0
+    assert c5["gpu_vs_oracle_max_rel_err"] < c5["bound"] == 1e-5, c5
+    c2 = d["config2_time_loop"]
+    assert "error" not in c2, c2
+    assert c2["steps"] == 50000 and 60000 < c2["final_wake"] < 75000 and 5.0 < c2["wall_s"] < 30.0
+    assert c2["rollup_pairs"] > 5e13 and c2["pairs_per_s_wall"] == pytest.approx(c2["rollup_pairs"] / c2["wall_s"], rel=1e-9)
+    assert 0 < c2["pair_kernel_s"] < c2["wall_s"] and c2["pair_kernel_launches"] == 50000
+    assert c2["first_lev_step"] == c2["first_lev_step_reference"] == 1335 and c2["shedding_identical_through_step_1400"] is True
+    assert c2["max_abs_dCl_first_600_steps_vs_reference"] <= c2["bound"] == 1e-5, c2
+    c1 = d["config1_readme"]
+    assert "error" not in c1, c1
+    assert c1["steps"] == 400 and 0 < c1["wall_s"] < 1.0 and c1["lev_shedding_identical"] is True
+    assert c1["max_abs_dCl_first_100_steps_vs_oracle"] <= c1["bound"] == 1e-9, c1
+    b = c1["cpu_baseline_time_loop"]
+    assert b["unit"] == "s" and b["cores"] == 1 and b["kind"] == "port" and b["value"] > 0.5
+    assert c1["speedup_vs_cpu_baseline"] == pytest.approx(b["value"] / c1["wall_s"], rel=1e-9)

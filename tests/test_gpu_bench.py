@@ -7,7 +7,7 @@ import sys
 
 import pytest
 
-from bench_checks import assert_self_checking_config4 as _assert_self_checking_config4, assert_sweep
+from bench_checks import assert_other_configs, assert_self_checking_config4 as _assert_self_checking_config4, assert_sweep
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
@@ -51,6 +51,18 @@ def test_bench_json_contract(symmetric):
     assert c["gpu_vs_oracle_max_rel_err"] < 1e-5
     a = c["all_cores"]                      # the same sample by the C restatement on every core: reported beside, never instead
     assert "error" not in a and a["cores"] >= 1 and a["value"] > 1e6 and a["vs_numpy_max_rel_diff"] < 1e-12
+
+
+def test_bench_line_carries_every_baseline_config():
+    """the default N = 1 line (config 3 at N = 1e6, shortened here to 3 steps and without config 4's 15 s
+    leg) also times config 5's flow field, config 2's full 50 000-step time_loop and the README case, each with its check."""
+    d = _run("--steps", "3", "--warmup", "1", "--repeats", "0", "--cpu-rows", "256", "--cpu-budget", "4", "--cfg4-steps", "0")
+    assert "config 3" in d["config"]["workload"] and d["config"]["n_vortices"] == 1_000_000 and "config4_one_gpu" not in d
+    assert d["cpu_baseline"]["gpu_vs_oracle_max_rel_err"] < 1e-5
+    assert_other_configs(d)
+    # a run at another size, or with forced tuning, measures that one thing only
+    d = _run("--vortices", "40000", "--steps", "2", "--warmup", "1", "--repeats", "0", "--cpu-rows", "0")
+    assert not any(k in d for k in ("config5_flowfield", "config2_time_loop", "config1_readme"))
 
 
 def test_bench_config4_shape_on_one_gpu():

@@ -1,5 +1,8 @@
-"""GPU tier: BASELINE config 2 over its WHOLE horizon (dt = 1e-3, t in [0, 50]: 50 000 steps of LUDVM.time_loop,
-reference LUDVM.py:597-1171) -- the statistical side of parity.
+"""NOT a comparison with the reference or the oracle: the ensemble this file tests against is the PRODUCT'S OWN float64 path on
+the GPU (HIP fp32 against HIP fp64: a statistical self-consistency check; the float64 path itself is pinned by G2 / G7).
+GPU tier: BASELINE config 2 over its WHOLE horizon (dt = 1e-3, t in [0, 50]: 50 000 steps of LUDVM.time_loop,
+reference LUDVM.py:597-1171) -- the statistical side of parity; the reference cannot run this case (80 GB of
+history) and the flow is chaotic from ~1450 steps, so there is nothing better to pin the long horizon to.
 
 Why statistics.  At these parameters the discretised vortex sheets amplify a rounding difference ~10x per 65 steps: two
 float64 evaluations of the reference's own scheme that differ only in how a sum is split agree to 1e-12 for 600 steps,

@@ -465,6 +465,48 @@ def test_fp32_accuracy_does_not_depend_on_the_callers_order(eng, n, vc, route):
         eng.wake_clear()
 
 
+@pytest.mark.parametrize("n", [8192, 20000])
+def test_a_thin_sheet_near_the_extent_bound_keeps_its_tier_in_its_own_order_and_in_a_scrambled_one(eng, n):
+    """ADVICE r5 (order.hip:77).  Two thresholds decide a LUDVM_PREC_F32 call's route: the thin-set rule (class extents within
+    3 x of a line across the bounding box: the given order stays, no keys, no sort) and the extent bound (mean class extent
+    <= 300 v_core for a set kept as given, 150 v_core in Morton order; beyond: hi+lo positions).  The calibration of round 4
+    covered Morton-ordered clouds and config 2's wake; this pins a SHEET just inside both lines: a wavy sheet stored along
+    itself whose mean class extent is ~280 v_core -- kept as given (identity order), fp32 on local origins, 1e-5 of max|u|
+    against the float64 oracle on every point -- and the same sheet stored in four interleaved strands (classes span 4 x the
+    line bound: over the 3 x rule), which takes the sort and keeps the tier too."""
+    vc = 1.3e-3
+    s = np.arange(n, dtype=np.float64)
+    spacing = 280.0 * vc / 256.0 / 1.02                  # a class = every other one of 256 consecutive points
+    x = -40.0 + spacing * s
+    z = 0.02 * np.sin(2 * np.pi * s / 2000.0)            # gentle: ~2 % on the class extent
+    g = np.random.default_rng(11).standard_normal(n) * 1e-3
+    ur, wr = c_oracle.induced_velocity(g, x, z, x, z, vc)
+    scale = max(np.abs(ur).max(), np.abs(wr).max())
+    order, reordered, extent = eng.spatial_order(x, z, with_extent=True)
+    assert not reordered and np.array_equal(order, np.arange(n))
+    assert 250 * vc < extent < 300 * vc, extent / vc     # just inside the bound of a set that is compact as given
+    try:
+        for sym in (1, 0):
+            eng.set_symmetric(sym)
+            u, w = eng.induce(g, x, z, x, z, vc, precision="f32")
+            err = max(np.abs(u - ur).max(), np.abs(w - wr).max()) / scale
+            assert err < 1e-5, (n, sym, err)
+        # four interleaved strands: stored point k is sheet point 4 (k mod n/4) + k // (n/4)
+        perm = np.arange(n).reshape(n // 4, 4).T.ravel()
+        xp, zp, gp = x[perm].copy(), z[perm].copy(), g[perm].copy()
+        order, reordered, extent_p = eng.spatial_order(xp, zp, with_extent=True)
+        assert reordered and np.array_equal(np.sort(order), np.arange(n))
+        assert extent_p < 1.3 * extent                   # Morton order of a line is the line again, up to key resolution
+        for sym in (1, 0):
+            eng.set_symmetric(sym)
+            u, w = eng.induce(gp, xp, zp, xp, zp, vc, precision="f32")
+            # (150 v_core applies to a reordered set: at ~280 this one takes hi+lo positions -- either way the tier holds)
+            err = max(np.abs(u - ur[perm]).max(), np.abs(w - wr[perm]).max()) / scale
+            assert err < 1e-5, (n, sym, err)
+    finally:
+        eng.set_symmetric(1)
+
+
 def test_a_shed_wake_keeps_its_order_and_its_bits(eng):
     """The spatial order applies only where the given order is not compact: a shed wake -- single sheet, the alternating
     TEV / LEV order, rolled up -- is evaluated as stored (ludvm_spatial_order: identity), so its results are the bits they
