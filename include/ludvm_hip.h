@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LUDVM_ABI_VERSION 4
+#define LUDVM_ABI_VERSION 5
 
 enum {
   LUDVM_OK = 0,
@@ -132,6 +132,15 @@ int ludvm_set_shard(ludvm_ctx* ctx, int rank, int world, size_t min_vortices, lu
  *                          accumulators and their NaN counter, issued by the library between the symmetric kernel and the
  *                          Euler finisher.  Integer sums commute: every rank reads the bits one GPU would have produced.
  *                          Roll-ups of fewer than min_vortices vortices are done whole by every rank, without a collective.
+ *   ludvm_comm_init_all    ONE PROCESS, several devices ("one RCCL communicator, single process, ncclCommInitAll"):
+ *                          the n contexts -- one per device, ctxs[k] becomes rank k -- join a new communicator in one call
+ *                          from one thread; no identifier, nothing to exchange.  Each context is sharded exactly as by
+ *                          ludvm_comm_init.  From then on every context is driven by a HOST THREAD OF ITS OWN, which issues
+ *                          the same calls in the same order as a process-per-GPU rank would (RCCL: one thread per device, or
+ *                          grouped calls; the entry points that contain the collective -- ludvm_wake_advect*, ludvm_wake_step,
+ *                          ludvm_march_run: LUDVM.time_loop's roll-up, LUDVM.py:1095-1127 -- enqueue it between their own
+ *                          kernels, so grouping them from one thread would mean cutting each entry point in two).
+ *                          ludvm_amd/multi.py is that driver: LUDVM(..., devices=[0, 1, ...]) with no launcher.  ABI 5.
  *   ludvm_comm_destroy     leaves the communicator (collective in RCCL's sense: every rank calls it) and unshards the context.
  *   ludvm_comm_info        rank and world of the context's communicator (world = 0: none).
  *   ludvm_comm_allreduce_i64_dev / ludvm_comm_allgather_dev
@@ -147,6 +156,7 @@ int ludvm_set_shard(ludvm_ctx* ctx, int rank, int world, size_t min_vortices, lu
 #define LUDVM_COMM_ID_BYTES 128
 int ludvm_comm_unique_id(void* id_out, size_t id_bytes);
 int ludvm_comm_init(ludvm_ctx* ctx, int rank, int world, const void* id, size_t id_bytes, size_t min_vortices);
+int ludvm_comm_init_all(ludvm_ctx** ctxs, int n, size_t min_vortices);
 int ludvm_comm_destroy(ludvm_ctx* ctx);
 int ludvm_comm_info(ludvm_ctx* ctx, int* rank, int* world);
 int ludvm_comm_allreduce_i64_dev(ludvm_ctx* ctx, long long* d_buf, size_t count);

@@ -18,7 +18,7 @@ OK, E_ARG, E_HIP, E_NOMEM, E_NODEVICE, E_STATE, E_COMM = range(7)
 PREC_F32, PREC_F32X2, PREC_F64 = 0, 1, 2
 SYM_TILE = 512
 SYM_OWNER_ALIGN = 4      # tiles: an owner's block of the tile ring is a whole number of these quads (include/ludvm_hip.h)
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128
 SYM_SCALE_BYTES = 32
 
@@ -40,6 +40,7 @@ SIGNATURES = {
     "ludvm_set_sym_tuning": [c_void_p, c_int, c_int],
     "ludvm_comm_unique_id": [c_void_p, c_size_t],
     "ludvm_comm_init": [c_void_p, c_int, c_int, c_void_p, c_size_t, c_size_t],
+    "ludvm_comm_init_all": [POINTER(c_void_p), c_int, c_size_t],
     "ludvm_comm_destroy": [c_void_p],
     "ludvm_comm_info": [c_void_p, POINTER(c_int), POINTER(c_int)],
     "ludvm_comm_allreduce_i64_dev": [c_void_p, c_void_p, c_size_t],

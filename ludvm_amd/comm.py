@@ -242,6 +242,16 @@ class LibraryGroup:
             except OSError:
                 pass
 
+    @classmethod
+    def joined(cls, engine, rank, world, min_targets=MIN_TARGETS, min_wake=MIN_WAKE, min_pairs=MIN_PAIRS):
+        """The group of an engine that HAS joined its communicator already (Engine.comm_init_all: the one-process form,
+        ludvm_amd/multi.py) -- no rendezvous, no identifier."""
+        g = cls.__new__(cls)
+        g.engine, g.rank, g.world = engine, int(rank), int(world)
+        g.min_targets, g.min_wake, g.min_pairs = int(min_targets), int(min_wake), int(min_pairs)
+        g._path = None
+        return g
+
     def close(self):
         if self.engine is not None:
             self.engine.comm_destroy()

@@ -15,6 +15,7 @@ struct Rccl {
   void* handle = nullptr;
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
@@ -41,6 +42,7 @@ Rccl& rccl() {
     };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
@@ -84,6 +86,25 @@ void comm_release(ludvm_ctx* c) {
 
 }  // namespace ludvm_host
 
+namespace {
+
+// what ludvm_comm_init and ludvm_comm_init_all leave in a context that has joined a communicator
+void comm_adopt(ludvm_ctx* c, ncclComm_t comm, int rank, int world, size_t min_vortices) {
+  c->comm = comm;
+  const char* force = std::getenv("LUDVM_COMM_FORCE");
+  c->comm_force = force && force[0] == '1';
+  c->comm_rank = rank;
+  c->comm_world = world;
+  c->shard_rank = rank;
+  c->shard_world = world;
+  c->shard_min_n = (long long)min_vortices;
+  c->reduce_hook = nullptr;
+  c->ext_acc = nullptr;
+  c->ext_acc_bytes = 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 /* ---- the library's own communicator (RCCL over xGMI) --------------------------------------------- */
@@ -113,17 +134,34 @@ int ludvm_comm_init(ludvm_ctx* c, int rank, int world, const void* id, size_t id
   std::memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
   ncclComm_t comm = nullptr;
   RCCLCHK(c, r.CommInitRank(&comm, world, uid, rank));     // collective: returns when every rank has joined
-  c->comm = comm;
-  const char* force = std::getenv("LUDVM_COMM_FORCE");
-  c->comm_force = force && force[0] == '1';
-  c->comm_rank = rank;
-  c->comm_world = world;
-  c->shard_rank = rank;
-  c->shard_world = world;
-  c->shard_min_n = (long long)min_vortices;
-  c->reduce_hook = nullptr;
-  c->ext_acc = nullptr;
-  c->ext_acc_bytes = 0;
+  comm_adopt(c, comm, rank, world, min_vortices);
+  return LUDVM_OK;
+}
+
+int ludvm_comm_init_all(ludvm_ctx** ctxs, int n, size_t min_vortices) {
+  if (!ctxs || n < 1 || !ctxs[0]) return LUDVM_E_ARG;
+  ludvm_ctx* c0 = ctxs[0];                       // (errors are reported on the first context)
+  if (n > 64) return fail(c0, LUDVM_E_ARG, "comm: at most 64 contexts");
+  int devs[64];
+  for (int k = 0; k < n; ++k) {
+    ludvm_ctx* c = ctxs[k];
+    if (!c) return fail(c0, LUDVM_E_ARG, "comm: null context");
+    if (c->comm) return fail(c0, LUDVM_E_STATE, "comm: a context already owns a communicator");
+    if (c->shard_world > 1) return fail(c0, LUDVM_E_STATE, "comm: a context is sharded through ludvm_set_shard");
+    for (int q = 0; q < k; ++q)
+      if (ctxs[q] == c || ctxs[q]->device == c->device)
+        return fail(c0, LUDVM_E_ARG, "comm: one context per device, one device per context (RCCL ranks cannot share a GPU)");
+    devs[k] = c->device;
+  }
+  Rccl& r = rccl();
+  if (!r.handle) return fail(c0, LUDVM_E_COMM, "comm: " + r.error);
+  for (int k = 0; k < n; ++k) {
+    HIPCHK(c0, hipSetDevice(ctxs[k]->device));
+    HIPCHK(c0, hipStreamSynchronize(ctxs[k]->stream));
+  }
+  ncclComm_t comms[64];
+  RCCLCHK(c0, r.CommInitAll(comms, n, devs));    // one call, this thread: no identifier, nothing to exchange
+  for (int k = 0; k < n; ++k) comm_adopt(ctxs[k], comms[k], k, n, min_vortices);
   return LUDVM_OK;
 }
 

@@ -150,6 +150,16 @@ class Engine:
             raise ValueError("comm_init: the identifier is 128 bytes (Engine.comm_unique_id)")
         self._check(self._lib.ludvm_comm_init(self._ctx, int(rank), int(world), uid, len(uid), int(min_vortices)))
 
+    @staticmethod
+    def comm_init_all(engines, min_vortices=0):
+        """ONE process, one engine per device: the engines join a new communicator in one call (ncclCommInitAll; engines[k]
+        becomes rank k) and are sharded as by comm_init.  Each engine is then driven by a host thread of its own
+        (ludvm_amd/multi.py)."""
+        _ffi.prefer_matching_rccl()
+        engines = list(engines)
+        arr = (c_void_p * len(engines))(*[e._ctx for e in engines])
+        engines[0]._check(engines[0]._lib.ludvm_comm_init_all(arr, len(engines), int(min_vortices)))
+
     def comm_destroy(self):
         self._check(self._lib.ludvm_comm_destroy(self._ctx))
 

@@ -98,6 +98,10 @@ class LUDVM:
       march      True (default): stretches of time steps whose history row is not recorded run as a
                  device-resident march (Gamma solve on the GPU, no host round trip per step);
                  False: one device round trip per step throughout
+      devices    several GPUs of this node in ONE process, no launcher: an int G (devices 0 .. G-1) or a list of ordinals.  One host
+                 thread, one engine and one replica per device, the library's own RCCL communicator over them (ncclCommInitAll);
+                 the object returned is a front whose attributes are replica 0's and whose methods run on all replicas
+                 (ludvm_amd/multi.py; `close()` ends the threads).  One device: an ordinary run on it
       distributed  None (default): one GPU.  'rccl': the simulation is shared by the processes of one launch (one per GPU;
                  rank and world from the launcher's environment), connected by the library's own RCCL communicator --
                  no torch.distributed (ludvm_amd/comm.py).  True or a torch.distributed process group: the same through
@@ -107,6 +111,16 @@ class LUDVM:
                  reference's full result arrays
     """
 
+    def __new__(cls, *args, devices=None, **kwargs):
+        # devices=[...] with more than one GPU: ONE process, one host thread and one replica per device, the library's own
+        # communicator over them (ludvm_amd/multi.py) -- the object returned is that front, not an instance of this class
+        if devices is not None and cls is LUDVM:
+            from .multi import MultiDeviceLUDVM, normalise_devices
+            devs = normalise_devices(devices)
+            if len(devs) > 1:
+                return MultiDeviceLUDVM(args, kwargs, devs)
+        return super().__new__(cls)
+
     def __init__(self, t0=0, tf=12, dt=1.5e-2, chord=1, rho=1.225, Uinf=1,
                  Npoints=80, Ncoeffs=30, LESPcrit=0.2, Naca='0012',
                  foil_filename=None, G=1, T=2, alpha_m=0,
@@ -114,7 +128,10 @@ class LUDVM:
                  verbose=True, method='Faure',
                  circulation_freevort=None, xy_freevort=None, *,
                  engine=None, device=0, precision='auto', history='auto', snapshot_steps=(), run=True,
-                 checkpoint_every=0, checkpoint_path=None, march=True, distributed=None):
+                 checkpoint_every=0, checkpoint_path=None, march=True, distributed=None, devices=None):
+        if devices is not None:             # (one device: an ordinary single-GPU run on it)
+            from .multi import normalise_devices
+            device = normalise_devices(devices)[0]
         self._ctor = dict(t0=t0, tf=tf, dt=dt, chord=chord, rho=rho, Uinf=Uinf, Npoints=Npoints, Ncoeffs=Ncoeffs,
                           LESPcrit=LESPcrit, Naca=Naca, foil_filename=foil_filename, G=G, T=T, alpha_m=alpha_m,
                           alpha_max=alpha_max, k=k, phi=phi, h_max=h_max, method=method, precision=precision,
