@@ -231,7 +231,10 @@ constexpr long long kSymMinN = 16384;   // below this the direct kernel's launch
 // halving the rotation / LDS-read cost per pair wins 2-7 % (with the rotation steps of a tile pair shared by two or four
 // waves below ~8e4); 4 (tile 256, 70-90 VGPRs) below, where more and smaller tiles balance better, and for hi+lo
 // positions (not instantiated for the 512-vortex tile: hi+lo is instruction-bound either way).
-constexpr long long kSymT8MinN = 34816;
+// Round 6 (profiles/r06_mid_size_variant_table.txt: every candidate forced at 22 sizes, ordered sheet, sustained load): between
+// 35 000 and 44 000 vortices the two tiles alternate within +-2 % with the parity of their tile counts; the one size where the
+// pick lost more (36 000: 512-vortex tiles 3.5 % behind) is what moved the switch from 34 816 to 36 864 = 72 tiles of 512.
+constexpr long long kSymT8MinN = 36864;
 static_assert(64 * 8 == LUDVM_SYM_TILE, "the multi-GPU entry points always use the 512-vortex tile");
 
 // The symmetric kernel accumulates in fixed point, which needs the bound sum|Gamma| / (sqrt(2) v_core) on the raw
