@@ -93,18 +93,18 @@ EXECUTED_FLOP_PER_PAIR = {"direct": 13, "symmetric": 9}   # the symmetric kernel
 # Units as the guide's HBM section prescribes: FETCH_SIZE counts 64 B per 128-B streaming request (doubled here for
 # the direct kernel's coalesced reads); WRITE_SIZE is exact for the atomics (one 8-B integer per lane).
 PMC_TRAFFIC_CFG3 = {
-    # round 5 passes on the current code (tools/r05_profile_batch.sh; tools/roofline_table.py recomputes DESIGN.md's table
-    # from the same files).  2 x FETCH_SIZE 71 412 KB + WRITE_SIZE 70 313 KB (the partial slabs of the source splits)
-    "ludvm::pair_f32<2,1024> direct, partial slabs": {"bytes": (2 * 71411.8 + 70312.5) * 1024,
-                                                      "source": "profiles/r05_bench_cfg3_direct_pmc_{fetch,write}.csv"},
+    # round 6 passes on the current code (tools/profile_batch.sh r06; tools/roofline_table.py recomputes DESIGN.md's table
+    # from the same files).  2 x FETCH_SIZE 71 484 KB + WRITE_SIZE 70 313 KB (the partial slabs of the source splits)
+    "ludvm::pair_f32<2,1024> direct, partial slabs": {"bytes": (2 * 71484.0 + 70312.5) * 1024,
+                                                      "source": "profiles/r06_bench_cfg3_direct_pmc_{fetch,write}.csv"},
     # The quad variant (four I tiles of a workgroup share each partner tile: one fixed-point atomic per J vortex and
     # workgroup instead of one per wave) + a launch of the plain kernel for the diagonal tiles.
-    # 2 x FETCH_SIZE (107 113 + 6 006) KB (gfx950 tallies the 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section)
-    # + WRITE_SIZE (6.045e6 + 16 602) KB (exact for stores and 8-byte atomics: 1.024e8 + 2.8e5 64-B atomic requests,
+    # 2 x FETCH_SIZE (105 629 + 6 024) KB (gfx950 tallies the 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section)
+    # + WRITE_SIZE (6.045e6 + 16 604) KB (exact for stores and 8-byte atomics: 1.024e8 + 2.8e5 64-B atomic requests,
     # memory-side, mostly Infinity-Cache resident: the accumulators are 16 MB)
     "ludvm::pair_sym_quad_f32<8> (+ pair_sym_f32<8> on the diagonal tiles), fixed-point accumulation": {
-        "bytes": (2 * (107113.0 + 6006.0) + 6045030.0 + 16601.6) * 1024,
-        "source": "profiles/r05_bench_cfg3_sym_pmc_{fetch,write}.csv"},
+        "bytes": (2 * (105629.0 + 6024.2) + 6045030.0 + 16603.5) * 1024,
+        "source": "profiles/r06_bench_cfg3_sym_pmc_{fetch,write}.csv"},
 }
 V_CORE = 0.065
 DT = 5e-2

@@ -1,8 +1,11 @@
 """CPU tier: DESIGN.md section 5's per-kernel roofline table is recomputable from the committed rocprofv3 summaries
-(tools/roofline_table.py over profiles/r05_*; r04_* for round 4's), and the figures the docs quote follow from those files."""
+(tools/roofline_table.py over profiles/r06_*; r05_* / r04_* for the rounds before), and the figures the docs quote follow from
+those files."""
 import os
 import subprocess
 import sys
+
+import pytest
 
 from conftest import ROOT
 
@@ -15,10 +18,12 @@ def _table(rnd):
     return [[c.strip() for c in r.strip("|").split("|")] for r in rows], p.stdout
 
 
-def test_roofline_table_recomputes_from_profiles():
-    """Round 5's table: configs 3 / 4 / 5 as before, and config 2's rows from config 2's OWN full run (no
-    proxy) -- one row per variant of the symmetric kernel the 50 000 steps went through."""
-    cells, out = _table("r05")
+@pytest.mark.parametrize("rnd,t8_switch", [("r06", 36864), ("r05", 34816)])
+def test_roofline_table_recomputes_from_profiles(rnd, t8_switch):
+    """The current table (round 6: after the T = 8 switch moved and the chain's waves got their priority) and round 5's: configs
+    3 / 4 / 5, and config 2's rows from config 2's OWN full run (no proxy) -- one row per variant of the
+    symmetric kernel the 50 000 steps went through."""
+    cells, out = _table(rnd)
     assert len(cells) == 7, out
     by = {c[0].split("`")[1]: c for c in cells}
     quad = by["pair_sym_quad_f32<8>"]
@@ -31,33 +36,38 @@ def test_roofline_table_recomputes_from_profiles():
         assert float(c[4]) <= frac(c) + 1e-9 and frac(c) > 0.40, c
         assert 0.5 < float(c[7]) <= 1.0, c                 # measured time never beats the issue model
         assert c[8] == "0", c                              # no LDS bank conflict in any pair kernel
-        assert c[10].startswith("`r05_"), c                # every row names the files (and thereby the box) it comes from
+        assert c[10].startswith(f"`{rnd}_"), c             # every row names the files (and thereby the box) it comes from
     for c in (quad, direct, patch):
         assert 1.0 <= float(c[5].split("(")[1].split("x")[0]) < 1.2, c      # VALU instructions within 20 % of the model
     # the direct kernel's distance from its 54 % ceiling is the held clock: >= 95 % of the issue model
     assert float(direct[7]) > 0.95
     # config 2: the rows ARE the run -- their kernels are the symmetric kernels of the full run's statistics file, their
-    # launches add up to the steps the symmetric kernel served, the step ranges are contiguous and end at step 50 000
+    # launches are that file's call counts, and the steps the library's rule (restated in tools/roofline_table.py) gives each
+    # variant add up to the run (round 6: a variant may serve more than one range of wake sizes -- the waves-per-item rule
+    # follows the parity of the tile count -- so the rows name their ranges instead of assuming one each)
     import csv
     import re
-    cfg2 = [c for c in cells if "config 2, steps" in c[0]]
+    cfg2 = [c for c in cells if "config 2, " in c[0]]
     assert [c[0].split("`")[1] for c in cfg2] == ["pair_sym_f32<4, false, 4, true>", "pair_sym_f32<4, false, 0, true>",
                                                   "pair_sym_f32<8, false, 4, true>", "pair_sym_f32<8, false, 0, true>"]
-    with open(os.path.join(ROOT, "profiles", "r05_config2_kernel_stats.csv")) as f:
+    with open(os.path.join(ROOT, "profiles", f"{rnd}_config2_kernel_stats.csv")) as f:
         stats = {r["Name"]: (int(r["Calls"]), float(r["AverageNs"]), float(r["Percentage"])) for r in csv.DictReader(f)}
     sym = {k: v for k, v in stats.items() if "pair_sym_f32<" in k}
     assert len(sym) == 4 and sum(v[2] for v in sym.values()) > 60.0          # > 60 % of the run's kernel time
-    prev_end = None
+    direct_calls = next(v[0] for k, v in stats.items() if "pair_f32<1, 256, false, 0, true>(" in k)
+    total = direct_calls
     for c in cfg2:
         name = c[0].split("`")[1]
         calls, avg_ns, _ = next(v for k, v in sym.items() if name + "(" in k)
-        a, b = (int(v) for v in re.search(r"steps (\d+)-(\d+)", c[0]).groups())
-        assert b - a + 1 == calls and (prev_end is None or a == prev_end + 1)
+        assert int(re.search(r"config 2, (\d+) steps", c[0]).group(1)) == calls
         assert abs(float(c[2].split()[0]) - avg_ns * 1e-6) < 1e-3            # the row's duration IS the full run's
-        prev_end = b
-    assert prev_end == 50000
-    # the T = 8 tile takes over at 34 816 vortices (launch.hip, kSymT8MinN), whatever the proxy once showed
-    assert abs(int(re.search(r"wake (\d+)-", cfg2[2][0]).group(1)) - 34816) < 1500
+        assert 0.55 < frac(c) < 0.75, c                                      # mid sizes: between 0.58 and 0.71 credited
+        total += calls
+    assert total == 50000
+    # the T = 8 tile takes over at 36 864 vortices (launch.hip, kSymT8MinN; 34 816 through round 5), whatever the proxy once showed
+    assert abs(int(re.search(r"wakes of (\d+)-", cfg2[2][0]).group(1)) - t8_switch) < 1500
+    # ... and the four-waves-per-item kernel comes back below the switch (the tile count's parity): two ranges
+    assert " and " in cfg2[0][0] and " and " in cfg2[2][0] and " and " not in cfg2[1][0]
 
 
 def test_round_4_table_still_recomputes():

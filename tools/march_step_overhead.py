@@ -4,7 +4,7 @@ free vortices behind the foil, stored in order along itself, stands for an old w
 which the order-independent fp32 tier of round 4 turned into another case -- too sparse for its core, hi+lo positions, other
 kernels than a shed wake takes); `steps` steps of config 2's dt are marched (sparse history, fp32) and timed as a whole; the pair
 kernel's own time comes from HIP events around it (ludvm_kernel_timing) in a second, equal run.  NOT the source of DESIGN.md's
-config-2 roofline rows any more: those come from config 2's own run (tools/r05_profile_batch.sh, tools/roofline_table.py).
+config-2 roofline rows any more: those come from config 2's own run (tools/profile_batch.sh, tools/roofline_table.py).
     python tools/march_step_overhead.py [nf ...]        STEPS=600"""
 import json
 import os

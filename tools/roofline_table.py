@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-config roofline table of DESIGN.md section 4, recomputed from the rocprofv3 summaries under profiles/ (no GPU needed).
 
-    python tools/roofline_table.py [round_prefix]            # default r05
+    python tools/roofline_table.py [round_prefix]            # default r06
 
 Per kernel: pairs per launch (stated in DESIGN.md section 4), average duration from `*_kernel_stats.csv`, credited fraction =
 13 FLOP x pairs / ns / 157.3e12, issued fraction (the FLOP per ordered pair the kernel really executes), VALU
@@ -34,6 +34,9 @@ ROWS = [
 ]
 
 
+T8_SWITCH = {"r05": 34816}
+
+
 def stats(prefix):
     out = {}
     with open(prefix + "_kernel_stats.csv") as f:
@@ -54,9 +57,9 @@ def config2_rows(rnd):
     """Config 2's rows from config 2's OWN run (round 5): `{rnd}_config2_{kernel_stats,pmc_*}.csv` are
     rocprofv3 passes of the full 50 000-step time loop (tools/run_configs.py cfg2) and `{rnd}_config2_under_rocprof.out` its JSON
     line with the wake size after every 250th step.  The wake only grows and the launch geometry is a function of the wake size
-    alone, so the symmetric kernel's variants follow each other -- direct (small wakes), <4,.,4>, <4,.,0> (mixed granularity),
-    <8,.,4>, <8,.,0> -- and a variant's call count is a contiguous range of steps; pairs per launch = the mean of n^2 over
-    that range.  Rounds without these files (r04) fall back to the proxy rows in ROWS."""
+    alone, so which variant of the symmetric kernel served a step -- direct (small wakes), <4,.,4>, <4,.,0> (mixed granularity),
+    <8,.,4>, <8,.,0> -- follows from the step's wake size by the library's rule; pairs per launch = the mean of n^2 over a
+    variant's steps.  Rounds without these files (r04) fall back to the proxy rows in ROWS."""
     import json
     import re
     p = os.path.join(ROOT, "profiles", f"{rnd}_config2")
@@ -73,32 +76,52 @@ def config2_rows(rnd):
         t = (step - step_of[k]) / 250.0
         return every[k] + t * (every[k + 1] - every[k])
     st = stats(p)
-    order = []           # (sort key, kernel name, calls): the sequence of the roll-up's pair kernels over the run
-    for name, (calls, _) in st.items():
-        m = re.search(r"pair_sym_f32<(\d+), (\w+), (\d+), (\w+)>", name)
-        if m:
-            order.append(((int(m.group(1)), int(m.group(3)) == 0), name, calls))
-        elif "pair_f32<1, 256, false, 0, true>" in name:
-            order.append(((0, False), name, calls))
-    order.sort()
-    rows, step = [], 1
-    for _, name, calls in order:
-        a, b = step, step + calls
-        step = b
-        if "pair_sym_f32" not in name:
-            continue
-        n2 = sum(wake_at(s) ** 2 for s in range(a, b)) / calls
-        short = name.split("ludvm::")[1].split("(")[0]
-        rows.append((f"config 2, steps {a}-{b - 1}: wake {wake_at(a):.0f}-{wake_at(b - 1):.0f} vortices", f"config2", short, n2, 9,
+    # Which kernel served which step: the library's own rule (launch.hip: sym_tile_t; pair_sym_kernels.hpp: sym_geometry_t),
+    # restated here, applied to the wake size of every step.  Round 6: rounds 3-5 assumed that each variant serves ONE contiguous
+    # range of steps; the waves-per-item rule follows the tile count's parity where the d-chunks stop dividing evenly, so
+    # <4,.,4> comes back between ~32 900 and the T = 8 switch and <8,.,4> for the last ~900 steps -- the old attribution put
+    # those launches' pairs into the wrong rows (the call counts below are checked against the statistics file instead).
+    t8 = T8_SWITCH.get(rnd, 36864)
+
+    def variant(n):
+        if n < 11264:
+            return "pair_f32<1, 256, false, 0, true>"
+        T = 8 if n >= t8 else 4
+        W = 64 * T
+        nt = max(1, (n + W - 1) // W)
+        dtot = (nt - 1) // 2 + (1 if (nt % 2 == 0 and nt > 1) else 0)
+        ys = max(1, min(64, dtot))
+        if dtot > 0:
+            per0 = (dtot + ys - 1) // ys
+            ys = (dtot + per0 - 1) // per0
+        rs = 1
+        while rs < 4 and nt * ys * rs < 10500:
+            rs *= 2
+        return f"pair_sym_f32<{T}, false, {0 if rs < 4 else 4}, true>"
+    served = {}
+    for s_ in range(1, run["steps"] + 1):
+        served.setdefault(variant(int(wake_at(s_))), []).append(s_)
+    rows = []
+    for short in ("pair_sym_f32<4, false, 4, true>", "pair_sym_f32<4, false, 0, true>", "pair_sym_f32<8, false, 4, true>",
+                  "pair_sym_f32<8, false, 0, true>"):
+        steps = served.get(short, [])
+        calls = [c for name, (c, _) in st.items() if short + "(" in name]
+        assert steps and calls and abs(len(steps) - calls[0]) <= 0.03 * calls[0] + 5, (short, len(steps), calls)
+        n2 = sum(wake_at(q) ** 2 for q in steps) / len(steps)
+        ranges, lo = [], steps[0]
+        for q0, q1 in zip(steps, steps[1:] + [None]):
+            if q1 != q0 + 1:
+                ranges.append(f"{wake_at(lo):.0f}-{wake_at(q0):.0f}")
+                lo = q1
+        rows.append((f"config 2, {calls[0]} steps: wakes of {' and '.join(ranges)} vortices", "config2", short, n2, 9,
                      13 / 4, (11 * 4 + 2 * 8) / 4, 28.0 * n2 ** 0.5))
-    assert step - 1 == run["steps"] + 1 or abs(step - 1 - run["steps"]) <= 2, (step, run["steps"])
-    t8 = [r for r in rows if "<8," in r[2]]
-    assert t8 and abs(float(t8[0][0].split("wake ")[1].split("-")[0]) - 34816) < 1500, t8[0][0]     # T = 8 from 34 816 vortices
+    direct = [c for name, (c, _) in st.items() if "pair_f32<1, 256, false, 0, true>(" in name]
+    assert direct and abs(len(served["pair_f32<1, 256, false, 0, true>"]) - direct[0]) <= 5
     return rows
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
     own = config2_rows(rnd)
     table = [r for r in ROWS if r[1] != "config2_sizes"] + own if own else ROWS
     print("| kernel (workload) | pairs / launch | avg ms | credited frac (13 FLOP) | issued frac | VALU insts / launch (vs model) | "
