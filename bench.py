@@ -907,8 +907,9 @@ def leg_config1(R):
     rec = {"workload": "config 1: README case, NACA0012, dt=5e-2, t in [0,20], Npoints=81, Ncoeffs=30, LESPcrit=0.2 (401 steps)",
            "wall_s": wall, "steps": int(sim.nt - 1), "precision": sim.precision,
            "cpu_baseline_time_loop": {"value": cpu_s, "unit": "s", "cores": 1, "kind": "port",
-                                      "sample": "the whole case (401 steps) by oracle/ludvm_oracle.py::OracleLUDVM, float64 NumPy as the "
-                                                "reference writes it (LUDVM.py:597-1171)"},
+                                      "sample": "the whole case (401 steps) by oracle/ludvm_oracle.py::OracleLUDVM, the float64 NumPy "
+                                                "restatement of LUDVM.py:597-1171 (pair sums as the reference writes them, :549-570; the "
+                                                "reference's own file took 4.4 s in the build container, SURVEY section 6)"},
            "speedup_vs_cpu_baseline": cpu_s / wall,
            "lev_shedding_identical": bool(np.array_equal(sim.LEV_shed, ref.LEV_shed)),
            "max_abs_dCl_first_100_steps_vs_oracle": float(np.abs(sim.Cl[:101] - ref.Cl[:101]).max()), "bound": 1e-9}

@@ -144,8 +144,6 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   hs.ilev = (long long)state[2];
   hs.shed = state[3] != 0.0;
   hs.tail = 0;
-  hs.solve_step = (unsigned long long)(first_step - 1);       // (every step before this call is solved and rolled up)
-  hs.join_timeout = 0;
   hs.lesp_crit = state[4]; hs.sum_tev = state[5]; hs.sum_lev = state[6];
   for (int k = 0; k < 4; ++k) hs.place[k] = state[7 + k];
   for (int k = 0; k < m.ncoef; ++k) hs.prevA[k] = state[16 + k];
@@ -227,10 +225,6 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   bool overlapped = false;          // the accumulators have been zeroed for the overlapped steps
   bool fork_signalled = false;      // the previous step's finisher already signals ev_fork
   static const bool ext_fork = [] { const char* e = LUDVM_EXP_ENV("LUDVM_MARCH_EXT_EVENTS"); return !(e && e[0] == '0'); }();
-  // the join of an overlapped step: a flag the solve releases and the finisher reads (MarchState::solve_step) instead of an
-  // event record + a wait packet in front of the finisher: -4 us per overlapped step [MI355X, profiles/r06_march_flag_join.txt].
-  // LUDVM_MARCH_FLAG_JOIN=0 (measurement build) brings the packets back; same bits either way
-  static const bool flag_join = [] { const char* e = LUDVM_EXP_ENV("LUDVM_MARCH_FLAG_JOIN"); return !(e && e[0] == '0'); }();
   // LUDVM_MARCH_OVERLAP=0 keeps every step serial (A/B measurements; results agree to fp32 rounding)
   const char* ov_env = LUDVM_EXP_ENV("LUDVM_MARCH_OVERLAP");
   const bool overlap_ok = !(ov_env && ov_env[0] == '0');
@@ -298,7 +292,7 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
       }
       c->stream = main_stream;
       CHK(rc);
-      if (!flag_join) HIPCHK(c, hipEventRecord(c->ev_join, c->stream_b));
+      HIPCHK(c, hipEventRecord(c->ev_join, c->stream_b));
       const long long nb = std::max<long long>(n_before, 1);
       const int T = sym_tile_t(c, nb, hilo, !hilo);
       const long long ntiles = (nb + 64LL * T - 1) / (64LL * T);
@@ -317,18 +311,17 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
       if (sharded) shard_tiles(c, ntiles, &first, &cnt);
       CHK(launch_sym_tiles(c, T, o, nb, first, cnt, vc4, &S->n_old[s & 1], n_lo, sharded));
       if (sharded) CHK(reduce_accumulators(c, acc, nt_pad));
-      if (!flag_join) HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
-      const unsigned long long join_step = flag_join ? (unsigned long long)s : 0ULL;
+      HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
       if (ext_fork) {
         hipExtLaunchKernelGGL(march_finish_sym, dim3(fin_blocks(n_ub)), dim3(kFinBlock), 0, c->stream, nullptr, c->ev_fork, 0,
                               acc, acc + nt_pad, (const SymScale*)&S->sc[s & 1], S,
                               (const long long*)&S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->mir(), c->g32, td,
-                              bad_step, bad_next, join_step);
+                              bad_step, bad_next);
         fork_signalled = true;
       } else {
         hipLaunchKernelGGL(march_finish_sym, dim3(fin_blocks(n_ub)), dim3(kFinBlock), 0, c->stream, acc, acc + nt_pad,
                            &S->sc[s & 1], S, &S->n_old[s & 1], (int)nfoil, (float)vc4, m.dt, c->x64, c->z64, c->mir(), c->g32, td,
-                           bad_step, bad_next, join_step);
+                           bad_step, bad_next);
       }
       HIPCHK(c, hipGetLastError());
     }
@@ -339,7 +332,6 @@ int ludvm_march_run(ludvm_ctx* c, long long first_step, long long count, int pre
   if (hist) HIPCHK(c, hipMemcpyAsync(hist, c->march_hist.p, (size_t)count * 2 * hist_nmax * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&hs, S, sizeof(MarchState), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (hs.join_timeout) return fail(c, LUDVM_E_STATE, "march: an Euler finisher gave up waiting for its step's solve (MarchState::solve_step)");
   if (hs.n < n0 + count || hs.n > n0 + 2 * count) return fail(c, LUDVM_E_STATE, "march: inconsistent wake size on the device");
   c->wake_n = (size_t)hs.n;
   state[0] = (double)hs.n; state[1] = (double)hs.itev; state[2] = (double)hs.ilev; state[3] = (double)hs.shed;

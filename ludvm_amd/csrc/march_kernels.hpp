@@ -426,12 +426,6 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
     x64[i] = x; z64[i] = z; g64[i] = dgamma;
     store_mirrors(mir, i, x, z, ox, oz); g32[i] = (float)dgamma;
   }
-  // everything this step's Euler finisher reads of the solve is written: tell it (MarchState::solve_step).  Every wave
-  // releases its own stores at agent scope (its stores are out of the CU and this XCD's L2 is written back: the finisher's
-  // workgroups run on all eight XCDs), then the barrier, then the flag.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  if (j == 0) __hip_atomic_store(&S->solve_step, (unsigned long long)step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Euler finisher of the overlapped roll-up.  The symmetric kernel ran on the wake as it was BEFORE this step's
@@ -439,32 +433,13 @@ march_solve(MarchSetup m, MarchState* S, const double* kin, double* row, long lo
 // shed this step (S->newv) and the bound vortices (staged at [n, n + nfoil)), and the shed vortices move with the
 // velocities march_solve left in S->newvel.  The raw sums are zeroed after use, so the accumulators need no memset
 // between steps.  One workgroup = one origin block (see finish_wake_advect).
-// join_step: the step whose solve this launch must have seen finished before it reads anything the solve writes (0: the host
-// put a hipStreamWaitEvent in front of the launch instead -- measurement builds, LUDVM_MARCH_FLAG_JOIN=0).
 __global__ void __launch_bounds__(kFinBlock)
 march_finish_sym(long long* acc_u, long long* acc_w, const SymScale* sc, MarchState* S, const long long* n_old_p,
                  int nfoil, float vc4, double dt, double* x64, double* z64, Mirrors m, const float* g32, TailDuty td,
-                 long long* bad_step = nullptr, long long* bad_next = nullptr, unsigned long long join_step = 0) {
+                 long long* bad_step = nullptr, long long* bad_next = nullptr) {
   // bad_step / bad_next (sharded roll-up): this step's count of non-finite partial sums, summed over all owners by
   // the all-reduce that also summed acc_u / acc_w, and the next step's counter, cleared here; S->sym_bad keeps it
   __shared__ float org[4];
-  if (join_step != 0) {
-    if (threadIdx.x == 0) {
-      unsigned long long seen = __hip_atomic_load(&S->solve_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int it = 0; seen < join_step && it < kJoinSpinMax; ++it) {
-        __builtin_amdgcn_s_sleep(32);
-        seen = __hip_atomic_load(&S->solve_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (seen < join_step) __hip_atomic_store(&S->join_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // what the solve wrote before its release is what we read from here on
-    }
-    __syncthreads();
-    // (the acquire invalidates the vector caches; a uniform load the compiler turns into a scalar one must not find a line another
-    // queue's kernel brought into the scalar cache before the solve wrote it)
-    __builtin_amdgcn_s_dcache_inv();
-    // (loading the old wake's positions and raw sums before the join, so that they are in flight while lane 0 looks at the
-    // flag, was measured: no gain -- profiles/r06_march_flag_join.txt)
-  }
   const bool bad = S->sym_bad != 0 || (bad_step && *bad_step != 0);
   const long long n = S->n, n_old = *n_old_p;
   const int k = (int)(n - n_old);

@@ -26,14 +26,6 @@ struct MarchState {
                         // as it stands after that step's shedding; an overlapped step s (old wake x old wake beside
                         // its own solve) reads sc[s & 1], a serial symmetric step s reads sc[(s + 1) & 1]
   long long sym_bad;    // a symmetric launch met a non-finite partial sum (sticky: NaN from there on)
-  // The join of an overlapped step without a packet in the queue (round 6): march_solve, at its very end, release-stores
-  // the step it has finished; the Euler finisher of that step -- launched on the main stream straight behind the
-  // symmetric kernel, with no hipStreamWaitEvent in front of it -- has one lane per workgroup read it (the chain finishes
-  // long before the symmetric kernel at every size where that kernel is the longer one: one load) and, where the chain is
-  // the longer one, wait for it, bounded: past kJoinSpinMax polls the workgroup goes on and raises join_timeout, which
-  // ludvm_march_run turns into an error -- every wave reaches its exit whatever the other queue does.
-  unsigned long long solve_step;
-  int join_timeout;
   double prevA[kMarchMaxCoef];
   double chord[6 * kMarchMaxPan];          // coming step: u1 | w1 | u_tev | w_tev | u_lev | w_lev at the chord points
   double tgt[2 * (kMarchMaxPan + 3)];      // targets of the chord launch: x[npan + 3] | z[npan + 3]
@@ -57,7 +49,6 @@ struct MarchSetup {
 // it derives for the launches it enqueues next depends on the call's arguments only, not on how far the host happens
 // to run ahead: the launch geometry -- and with it every bit of the results -- repeats from run to run.
 constexpr int kProgressRing = 1024;
-constexpr int kJoinSpinMax = 1 << 18;   // polls of ~1 us each (s_sleep 32): a quarter of a second, then the step is declared lost
 constexpr int kMarchRowHead = 12;   // g_tev, g_lev, shed, bound, LESP_prev, LESP, Fn, Fs, M, slot, phantom u, w
 
 inline TailDuty make_tail_duty(MarchState* S, long long step, const double* kin_next, int npan) {

@@ -638,9 +638,7 @@ __device__ __forceinline__ void tail_duty(const TailDuty& td, long long i, long 
   if (td.hist_row) { td.hist_row[i] = xn; td.hist_row[td.hist_nmax + i] = zn; }
   if (td.kin_next == nullptr) return;
   const int np = td.npan, ntt = np + 3;
-  // (written by this step's solve, which in an overlapped march step runs on another queue while this kernel may already be
-  // resident -- MarchState::solve_step: read past the scalar cache, which no acquire invalidates)
-  const int tail = __hip_atomic_load(td.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int tail = *td.tail;
   if (i == n - tail) {
     const double tex = td.kin_next[3], tez = td.kin_next[4];
     const double px = tex + (xn - tex) / 3, pz = tez + (zn - tez) / 3;
@@ -650,7 +648,7 @@ __device__ __forceinline__ void tail_duty(const TailDuty& td, long long i, long 
   if (i == n - 1) {
     const double lex = td.kin_next[5], lez = td.kin_next[6];
     double px = lex, pz = lez;
-    if (__hip_atomic_load(td.shed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && tail == 2) { px = lex + (xn - lex) / 3; pz = lez + (zn - lez) / 3; }
+    if (*td.shed && tail == 2) { px = lex + (xn - lex) / 3; pz = lez + (zn - lez) / 3; }
     td.place[1] = px; td.place[3] = pz;
     td.tgt[np + 1] = px; td.tgt[ntt + np + 1] = pz;
   }
