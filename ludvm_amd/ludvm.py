@@ -940,12 +940,22 @@ class LUDVM:
 
     @classmethod
     def resume(cls, path, engine=None, device=0, verbose=True, checkpoint_every=0, checkpoint_path=None, march=True,
-               distributed=None):
+               distributed=None, devices=None):
         """Continue a run from a checkpoint written with `checkpoint_every` / `checkpoint_path`: rebuilds
         geometry and kinematics from the stored constructor arguments, uploads the wake and marches
         from the stored step to the end.  `distributed` as in the constructor: every rank of the group resumes from the
-        same file."""
+        same file; `devices` as in the constructor: one process, a replica per device, each resumed from the file."""
         import json
+        if devices is not None:
+            from .multi import MultiDeviceLUDVM, normalise_devices
+            devs = normalise_devices(devices)
+            if len(devs) > 1:
+                if engine is not None or distributed is not None:
+                    raise ValueError("devices=[...] creates the engines and their communicator itself: do not pass engine= / distributed=")
+                return MultiDeviceLUDVM((), {}, devs, builder=lambda r, eng, grp: cls.resume(
+                    path, engine=eng, verbose=verbose and r == 0, checkpoint_every=checkpoint_every, checkpoint_path=checkpoint_path,
+                    march=march, distributed=grp))
+            device = devs[0]
         R = np.load(path, allow_pickle=False)
         kw = json.loads(str(R['ctor']))
         free = {}

@@ -112,7 +112,7 @@ class MultiDeviceLUDVM:
     _OWN = ("_team", "_sims", "_groups", "_engines", "devices", "world", "_closed")
 
     def __init__(self, args, kwargs, devices, engine_factory=None, join=join_with_rccl, min_targets=None, min_wake=None,
-                 min_pairs=None):
+                 min_pairs=None, builder=None):
         from . import comm
         from .ludvm import LUDVM
         if kwargs.get("engine") is not None or kwargs.get("distributed") is not None:
@@ -140,9 +140,12 @@ class MultiDeviceLUDVM:
                           comm.MIN_WAKE if min_wake is None else min_wake, comm.MIN_PAIRS if min_pairs is None else min_pairs)
             object.__setattr__(self, "_groups", groups)
             verbose = kwargs.pop("verbose", True)
-            # (the reference prints its progress once, not G times)
-            sims = self._team.run(lambda r: LUDVM(*args, **kwargs, verbose=verbose and r == 0, engine=self._engines[r],
-                                                  distributed=groups[r]))
+            if builder is None:
+                # (the reference prints its progress once, not G times)
+                def builder(r, engine, group):
+                    return LUDVM(*args, **kwargs, verbose=verbose and r == 0, engine=engine, distributed=group)
+            # builder(rank, engine, group) -> that rank's replica (LUDVM.resume(..., devices=...) passes its own)
+            sims = self._team.run(lambda r: builder(r, self._engines[r], groups[r]))
             object.__setattr__(self, "_sims", sims)
         except BaseException:
             self._shutdown(wait_for_peers=False)

@@ -187,3 +187,26 @@ def test_devices_keyword_of_the_class():
             break
         threading.Event().wait(0.1)
     assert threading.active_count() <= n0
+
+
+def test_checkpoints_and_resume_through_the_replicas(tmp_path):
+    """A multi-replica run writes its checkpoints once (rank 0; the others wait at the barrier that carries the success bit) and
+    `LUDVM.resume(path, devices=...)` resumes every replica from the file: the continuation equals the uninterrupted
+    single-engine run bit for bit (here through the builder seam: the fake engines stand in for the devices)."""
+    import os
+    ck = str(tmp_path / "run.npz")
+    kw = dict(CONFIG1, tf=10, verbose=False, history="sparse", snapshot_steps=[50, 120])
+    one = LUDVM(**kw, engine=FakeEngine())
+    with MultiDeviceLUDVM((), dict(kw, checkpoint_every=70, checkpoint_path=ck), [0, 1, 2], engine_factory=lambda d: FakeEngine(),
+                          join=mem_join) as multi:
+        assert np.array_equal(multi.Cl, one.Cl) and os.path.exists(ck)
+        assert not [f for f in os.listdir(tmp_path) if f.endswith(".tmp") or ".tmp." in f]      # one writer, nothing left over
+    with MultiDeviceLUDVM((), {}, [0, 1], engine_factory=lambda d: FakeEngine(), join=mem_join,
+                          builder=lambda r, eng, grp: LUDVM.resume(ck, engine=eng, verbose=False, distributed=grp)) as res:
+        for rep in res.replicas():
+            for name in ("Cl", "Cd", "Cm", "LESP", "LEV_shed"):
+                assert np.array_equal(getattr(rep, name), getattr(one, name)), name
+            assert np.array_equal(np.asarray(rep.path["TEV"][120]), np.asarray(one.path["TEV"][120]))
+    with pytest.raises(ValueError, match="do not pass engine"):
+        LUDVM.resume(ck, engine=FakeEngine(), devices=[0, 1])
+    assert isinstance(LUDVM.resume(ck, engine=FakeEngine(), verbose=False, devices=[0]), LUDVM)   # one device: an ordinary resume
