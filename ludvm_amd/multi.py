@@ -186,12 +186,14 @@ class MultiDeviceLUDVM:
             return
         object.__setattr__(self, "_closed", True)
         team, groups = self._team, self._groups
-        if groups is not None and team.broken is None and wait_for_peers:
+        alive = all(t.is_alive() for t in team._threads)      # (a finalizer at interpreter exit finds the daemon threads gone)
+        if groups is not None and team.broken is None and wait_for_peers and alive:
             try:
                 team.run(lambda r: groups[r].close(), timeout=60.0)      # (ncclCommDestroy: every rank, together)
             except BaseException:       # noqa: BLE001
                 pass
-        team.stop()
+        if alive:
+            team.stop()
 
     def close(self):
         """Leave the communicator and end the rank threads; the results stay readable."""

@@ -1,5 +1,7 @@
 """GPU tier: resident-wake entry points (backing time_loop) against the oracle, and the drop-in
 LUDVM class end to end against the golden runs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1076,3 +1078,33 @@ def test_march_fuzz_against_the_per_step_path():
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-1500:])
     last = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
     assert last["cases"] == 24 and last["failures"] == 0 and last["worst_fp64"]["dCl"] < 1e-8
+
+
+def test_a_run_does_not_depend_on_who_serialises_its_kernels():
+    """Round 6's lesson (profiles/r06_march_flag_join.txt): every dependency between the march's two streams is a packet in a
+    queue -- never a kernel spinning on another queue's progress -- so a tool that serialises dispatches (rocprofv3's counter
+    passes, a debugger, HIP_LAUNCH_BLOCKING / AMD_SERIALIZE_KERNEL) neither breaks a run nor moves a bit.  A marched fp32 run with
+    overlapped symmetric steps from 40 vortices on, in a child process under HIP_LAUNCH_BLOCKING=1 and AMD_SERIALIZE_KERNEL=3, gives
+    the fingerprint of the undisturbed run."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import hashlib, sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from ludvm_amd import LUDVM, Engine\n"
+        "e = Engine(0); e.set_symmetric(40)\n"
+        "kw = dict(t0=0, tf=12, dt=5e-2, chord=1, rho=1.225, Uinf=1, Npoints=81, Ncoeffs=30, LESPcrit=0.2, Naca='0012')\n"
+        "h = hashlib.sha256()\n"
+        "for prec in ('f32', 'f32x2'):\n"
+        "    s = LUDVM(**kw, verbose=False, engine=e, precision=prec, history='sparse')\n"
+        "    for v in (s.Cl, s.Cd, s.Cm, s.LEV_shed, s.circulation['TEV'], s.path['TEV'][s.nt - 1]):\n"
+        "        h.update(np.ascontiguousarray(v, dtype=np.float64).tobytes())\n"
+        "print('FP', h.hexdigest())\n")
+    base = {k: v for k, v in os.environ.items() if k not in ("HIP_LAUNCH_BLOCKING", "AMD_SERIALIZE_KERNEL", "AMD_SERIALIZE_COPY")}
+    out = []
+    for extra in ({}, {"HIP_LAUNCH_BLOCKING": "1", "AMD_SERIALIZE_KERNEL": "3", "AMD_SERIALIZE_COPY": "3"}):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(base, **extra), timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out.append([l for l in p.stdout.splitlines() if l.startswith("FP ")][-1])
+    assert out[0] == out[1], out
