@@ -44,6 +44,8 @@ def rule_pick(n):
 
 
 CANDS = [("T4 mixed", 4, -1), ("T4 x4", 4, 4), ("T8 mixed", 8, -1), ("T8 x4", 8, 4), ("direct", 0, 0), ("rule", 0, 0)]
+if os.environ.get("SWEEP_MORE"):            # two and one waves per item too (not among VERDICT r5 item 4's candidates)
+    CANDS = CANDS[:4] + [("T4 x2", 4, 2), ("T8 x2", 8, 2), ("T8 x1", 8, 1)] + CANDS[4:]
 sizes = [int(a) * 1000 for a in sys.argv[1:]] or [12000, 16000, 20000, 24000, 28000, 32000, 33000, 34000, 35000, 36000, 37000, 38000, 39000,
                                                    40000, 41000, 42000, 43000, 44000, 45000, 46000, 48000, 52000]
 eng = Engine(0)
@@ -90,7 +92,7 @@ for n in sizes:
         v = table[(n, name)]
         mark = "*" if name == pick else ("!" if (name not in ("rule",) and v < tp / 1.02) else " ")
         cells.append(f"{v:9.1f}{mark}")
-    sym_best = min((table[(n, c)], c) for c in ("T4 mixed", "T4 x4", "T8 mixed", "T8 x4"))
+    sym_best = min((table[(n, c)], c) for c, _, _ in CANDS if c not in ("direct", "rule"))
     allbest = min((table[(n, c)], c) for c, _, _ in CANDS[:-1])
     worst = max(worst, tp / sym_best[0] - 1.0)
     print(f"{n:>9} | " + " | ".join(cells) + f" | {table[(n, 'rule')] / tp - 1.0:+6.1%}       {allbest[1]} ({tp / allbest[0] - 1.0:+.1%} to the pick)")
