@@ -126,3 +126,45 @@ def test_scaling_table_divides_by_the_same_work_figure():
     assert abs(rows[1]["efficiency"] - 0.5) < 0.05          # two ranks SHARING one card: the rehearsal, as it must, scales by 1.0
     assert rows[1]["symmetric_check"]["ranks_agree"] is True and rows[1]["min_wake_suggested"] == two[0]["min_wake_suggested"]
     assert "config4_one_gpu.value" in two[0]["scaling_denominator"]
+
+
+def test_the_tables_rule_is_the_librarys_rule(tmp_path):
+    """DESIGN section 5's config-2 rows and profiles/r06_mid_size_variant_table.txt attribute steps / mark picks by a Python
+    restatement of the library's launch rule (tools/roofline_table.py::config2_rows, tools/r06_mid_size_sweep.py::rule_pick).
+    The rule itself is host-callable C++ (pair_sym_kernels.hpp: sym_geometry; launch.hip: kSymT8MinN): a small host program
+    built from the library's own header prints it for a ladder of wake sizes, and the restatements must agree everywhere."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "ludvm_amd", "csrc")
+    t8 = int(re.search(r"constexpr long long kSymT8MinN = (\d+);", open(os.path.join(csrc, "launch.hip")).read()).group(1))
+    src = tmp_path / "rule.hip"
+    src.write_text('#include <cstdio>\n#include "pair_sym_kernels.hpp"\nint main() {\n'
+                   f'  for (long long n = 11264; n <= 70000; n += 97) {{\n    const int T = n >= {t8} ? 8 : 4;\n'
+                   '    const ludvm::SymGeom g = ludvm::sym_geometry(n, T, 0, 0);\n'
+                   '    std::printf("%lld %d %d\\n", n, T, g.rsplit);\n  }\n  return 0;\n}\n')
+    exe = tmp_path / "rule"
+    p = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", f"-I{csrc}", "-o", str(exe), str(src)],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lib = {int(a): (int(b), int(c)) for a, b, c in (l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True,
+                                                                                      timeout=60).stdout.splitlines())}
+    assert len(lib) > 600
+    # restatement 1: the sweep's rule_pick (cut out of the tool: importing it would need an engine)
+    text = open(os.path.join(ROOT, "tools", "r06_mid_size_sweep.py")).read()
+    ns = {"os": os}
+    exec(text[text.index("K_TARGET_WAVES, K_MAX_SPLIT"):text.index("CANDS =")], ns)
+    assert ns["K_T8_MIN_N"] == t8
+    # restatement 2: roofline_table's variant(), same cut
+    text2 = open(os.path.join(ROOT, "tools", "roofline_table.py")).read()
+    body = text2[text2.index("    def variant(n):"):text2.index("    served = {}")]
+    ns2 = {"t8": t8}
+    exec("def make(t8):\n" + body + "    return variant\n", ns2)
+    variant = ns2["make"](t8)
+    for n, (T, rs) in lib.items():
+        # rsplit: 0 = mixed granularity (the size rule left room below four waves per item), 4 = four waves per item
+        assert rs in (0, 4), (n, rs)
+        assert ns["rule_pick"](n) == (T, "mixed" if rs == 0 else "x4"), n
+        assert variant(n) == f"pair_sym_f32<{T}, false, {rs}, true>", n
